@@ -1,0 +1,231 @@
+/*
+ * osr.h -- C ABI of libosr_hip.so: the MI355X (gfx950) implementation of Openset R-CNN's per-image
+ * detection hot path.
+ *
+ * The reference (Yifei-Y/Openset-RCNN) has NO FFI of its own: its boundary is detectron2's registries and
+ * nn.Module call signatures. Each entry point below therefore cites the reference call site
+ * (file:line under /root/reference) -- or the un-vendored detectron2/torchvision primitive invoked there,
+ * marked [d2] -- whose arithmetic it replaces. INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every data pointer is a DEVICE pointer unless named host_*;
+ *   - the caller owns every buffer including workspace (sizes from osr_*_workspace_bytes); the library never
+ *     allocates, frees or synchronises; all work is enqueued on `stream` (a hipStream_t passed as void*);
+ *   - return value: 0 = OSR_OK, negative = error (osr_last_error() gives a thread-local message);
+ *     no C++ exception crosses the boundary; no global mutable state (re-entrant across threads/streams);
+ *   - activations are NHWC ("channels last"); element types are named by osr_dtype.
+ */
+#ifndef OSR_H_
+#define OSR_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OSR_ABI_VERSION 1
+
+typedef int32_t osr_status;
+enum {
+    OSR_OK = 0,
+    OSR_ERR_INVALID_ARG = -1,
+    OSR_ERR_UNSUPPORTED = -2,
+    OSR_ERR_LAUNCH = -3,
+    OSR_ERR_WORKSPACE = -4
+};
+
+typedef enum { OSR_F32 = 0, OSR_F16 = 1, OSR_BF16 = 2 } osr_dtype;
+
+#define OSR_MAX_LEVELS 8
+
+int32_t osr_abi_version(void);
+const char* osr_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Pre-processing  ([d2] GeneralizedRCNN.preprocess_image + ImageList.from_tensors, called from train.py:135)
+ * src: (n,3,h,w) NCHW, uint8 (src_is_u8=1) or float32. dst: (n, hp+6, wpad, 4) NHWC fp16/bf16 where the
+ * normalised image sits at row offset 3 / column offset 3, everything else (3-pixel halo, the /32 padding,
+ * the 4th channel) is zero. wpad = osr_stem_padded_width(wp). This is the layout the 7x7/s2 stem reads
+ * without bounds checks.
+ * --------------------------------------------------------------------------------------------------------- */
+int32_t osr_stem_padded_width(int32_t wp);
+osr_status osr_preprocess(const void* src, int32_t src_is_u8, int32_t n, int32_t h, int32_t w, int32_t hp, int32_t wp,
+                          const float mean[3], const float std[3], void* dst, int32_t dst_dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Dense contractions on MFMA  ([d2] Conv2d / FrozenBatchNorm2d (folded) / nn.Linear of build_resnet_fpn_backbone
+ * (Base-RCNN-FPN.yaml:3-8), ClsFreeRPNHead.conv (classification_free_rpn.py:158), FastRCNNConvFCHead
+ * (osrcnn_roi_heads.py:308)).  Implicit GEMM:  out[n,oh,ow,co] = act( sum_{kh,kw,ci} in[n,oh*sh-ph+kh,
+ * ow*sw-pw+kw,ci] * w[co,kh,kw,ci] + bias[co] (+ residual) ).
+ * in/weight: fp16 or bf16; accumulate fp32; out: fp16/bf16/fp32. cin must be a multiple of 32, cout of 8.
+ * A fully connected layer is the 1x1 case with hi=rows, wi=1.
+ * res_mode: 0 none; 1 residual[n,oh,ow,co] (bottleneck shortcut); 2 residual[n,oh/2,ow/2,co]
+ * (FPN top-down nearest-2x upsample-add). Strides are in ELEMENTS; the channel stride is 1.
+ * pad_mode: 0 = bounds-checked zero padding; 1 = the input buffer already holds the halo (stem view).
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct osr_conv_params {
+    int32_t n, hi, wi, cin;
+    int32_t ho, wo, cout;
+    int32_t kh, kw, stride_h, stride_w, pad_h, pad_w;
+    int64_t in_stride_n, in_stride_h, in_stride_w;
+    int64_t out_stride_n, out_stride_h, out_stride_w;
+    int64_t res_stride_n, res_stride_h, res_stride_w;
+    int32_t relu;
+    int32_t res_mode;
+    int32_t pad_mode;
+    int32_t in_dtype;  /* osr_dtype of in, weight, residual */
+    int32_t out_dtype; /* osr_dtype of out */
+    int32_t reserved;
+} osr_conv_params;
+
+osr_status osr_conv2d_fwd(const osr_conv_params* p, const void* in, const void* weight, const float* bias,
+                          const void* residual, void* out, void* stream);
+
+/* [d2] F.max_pool2d(k=3,s=2,p=1) of the ResNet stem, NHWC contiguous. */
+osr_status osr_maxpool3x3s2(const void* in, int32_t n, int32_t hi, int32_t wi, int32_t c, void* out, int32_t dtype,
+                            void* stream);
+/* [d2] LastLevelMaxPool: p6 = max_pool2d(p5, k=1, s=2) = stride-2 subsample, NHWC contiguous. */
+osr_status osr_subsample2(const void* in, int32_t n, int32_t hi, int32_t wi, int32_t c, void* out, int32_t dtype,
+                          void* stream);
+
+/* fp32 GEMM out[m,n] = a[m,k] * w[n,k]^T + bias[n] on the exact-f32 MFMA (PLN encoder/decoder,
+ * prototype_learning_network.py:204-205; cls_score, softmax_classifier.py:306). lda/ldo in elements. */
+osr_status osr_gemm_f32(const float* a, int64_t lda, const float* w, const float* bias, float* out, int64_t ldo,
+                        int32_t m, int32_t n, int32_t k, int32_t relu, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * CF-RPN head tail: ClsFreeRPNHead.forward after the 3x3 conv+ReLU (classification_free_rpn.py:159-161):
+ * t/max(||t||_2,1e-12) over channels, 1x1 -> 4 ltrb deltas, 1x1 -> centerness, sigmoid.
+ * t: (rows, c) channels-last hidden state; w_delta (4,c), w_ctr (1,c) fp32. Outputs fp32.
+ * --------------------------------------------------------------------------------------------------------- */
+osr_status osr_cfrpn_head_tail(const void* t, int32_t t_dtype, int64_t rows, int32_t c, const float* w_delta,
+                               const float* b_delta, const float* w_ctr, const float* b_ctr, float* deltas,
+                               float* ctr, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Proposal selection: ClsFreeRPN.predict_proposals -> _decode_proposals (classification_free_rpn.py:558-610)
+ * + find_top_rpn_proposals (find_top_proposals.py:60-127) for all images and levels in two launches.
+ * Level l holds ctr[l_off + img*hw_l*a + i] and deltas[(same)*4]. Per (image, level): stable top-k of
+ * centerness (value-descending, lower index first), ltrb decode of the k survivors around their anchors
+ * ([d2] DefaultAnchorGenerator + Box2BoxTransformLinear), finite filter, clip to the image, drop empty boxes;
+ * levels concatenated level-major (no NMS, no cross-level re-sort: the reference has both commented out).
+ * Outputs are padded to cap = osr_rpn_select_capacity(): boxes (n,cap,4), scores (n,cap), src_index (n,cap)
+ * (index into the image's concatenated anchor list), batch_idx (n*cap: image id, -1 for padding), counts (n).
+ * status_flags[0] is set non-zero when any non-finite prediction was met (training raises on it).
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct osr_rpn_levels {
+    int32_t num_levels;
+    int32_t num_anchors;            /* A: cell anchors per location */
+    int32_t h[OSR_MAX_LEVELS];
+    int32_t w[OSR_MAX_LEVELS];
+    int32_t stride[OSR_MAX_LEVELS];
+    int64_t offset[OSR_MAX_LEVELS]; /* element offset of level l in ctr (x4 in deltas) */
+} osr_rpn_levels;
+
+int32_t osr_rpn_select_capacity(const osr_rpn_levels* lv, int32_t pre_nms_topk);
+int64_t osr_rpn_select_workspace_bytes(const osr_rpn_levels* lv, int32_t n, int32_t pre_nms_topk);
+osr_status osr_rpn_select(const osr_rpn_levels* lv, const float* cell_anchors /* (L,A,4) */, const float* ctr,
+                          const float* deltas, int32_t n, const int32_t* image_hw /* (n,2) */, int32_t pre_nms_topk,
+                          float min_box_size, float* boxes, float* scores, int32_t* src_index, int32_t* batch_idx,
+                          int32_t* counts, int32_t* status_flags, void* workspace, int64_t workspace_bytes,
+                          void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * RoIAlign over the pyramid: [d2] ROIPooler.forward (level = floor(4+log2(sqrt(area)/224+1e-8)) clamped to
+ * [min,max]) -> torchvision roi_align(aligned=True, sampling_ratio=0) (osrcnn_roi_heads.py:108-113,306).
+ * feats[l]: (n, h_l, w_l, c) NHWC. boxes (m,4) fp32, batch_idx (m) (<0 => row of zeros).
+ * out: (m, p, p, c) i.e. out[m][(ph*p+pw)*c + ch]  (the reference's (m,c,p,p) is the same data permuted;
+ * the FC1 weight is permuted once at load time instead).
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct osr_pyramid {
+    int32_t num_levels;
+    int32_t c;
+    int32_t h[OSR_MAX_LEVELS];
+    int32_t w[OSR_MAX_LEVELS];
+    float scale[OSR_MAX_LEVELS];
+    const void* data[OSR_MAX_LEVELS];
+} osr_pyramid;
+
+osr_status osr_roi_align_fwd(const osr_pyramid* feats, int32_t feat_dtype, int32_t n, const float* boxes,
+                             const int32_t* batch_idx, int64_t m, int32_t pooled, int32_t canonical_level,
+                             int32_t canonical_size, int32_t min_level, void* out, int32_t out_dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Box predictor tail: OpensetFastRCNNOutputLayers.forward + predict_boxes + predict_ious
+ * (osrcnn_fast_rcnn.py:262-263,423,443-446) and the per-row part of fast_rcnn_inference_single_image
+ * (:109-126): deltas = x W_b^T + b, iou = sigmoid(x w_i + b), box = Box2BoxTransform.apply_deltas (weights
+ * wx,wy,ww,wh; scale clamp log(1000/16)), score = sqrt(iou*ctr) (mean_type 0) or (iou+ctr)/2 (1), finite filter,
+ * clip, score > thresh. x: (m, k) fp32 box-head features. w: (5,k): rows 0-3 bbox_pred, row 4 iou_pred.
+ * Outputs: pred_deltas (m,4) raw, pred_iou (m), boxes (m,4) clipped, score (m), cand (m) int32 0/1.
+ * --------------------------------------------------------------------------------------------------------- */
+osr_status osr_box_predictor_tail(const float* x, int64_t m, int32_t k, const float* w, const float* b,
+                                  const float* proposals, const float* ctr, const int32_t* batch_idx,
+                                  const int32_t* image_hw, const float reg_weights[4], int32_t mean_type,
+                                  float score_thresh, float* pred_deltas, float* pred_iou, float* boxes,
+                                  float* score, int32_t* cand, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Segmented stable sort + greedy per-class NMS + top-k: [d2] detectron2.layers.batched_nms -> torchvision
+ * nms (osrcnn_fast_rcnn.py:135-137; softmax_classifier.py:93-95,154-156), vanilla per-class semantics:
+ * candidates ordered by score descending (ties: lower index first); a candidate is suppressed by an already
+ * kept one of the same class when inter/(a_i+a_j-inter) > thr; the first `topk` kept are returned, in order.
+ * thr >= 1 suppresses nothing (pure sort + top-k). Segment s covers elements
+ * [s*seg_stride, s*seg_stride + seg_len[s]) of boxes/scores/cls/cand; cand==0 elements are skipped.
+ * keep: (num_segments, topk) indices relative to the segment start; keep_count: (num_segments).
+ * --------------------------------------------------------------------------------------------------------- */
+int64_t osr_nms_topk_workspace_bytes(int32_t num_segments, int64_t seg_stride);
+osr_status osr_nms_topk(const float* boxes, const float* scores, const int32_t* cls /* nullable: one class */,
+                        const int32_t* cand /* nullable: all */, int32_t num_segments, int64_t seg_stride,
+                        const int32_t* seg_len, float thr, int32_t topk, int32_t* keep, int32_t* keep_count,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Gather rows: dst[s, j, :] = src[s*seg_stride + keep[s, j], :] for j < keep_count[s], else 0
+ * (boxes[keep], scores[keep], feats[keep] at osrcnn_fast_rcnn.py:138). row_elems fp32 elements per row. */
+osr_status osr_gather_rows(const float* src, int64_t seg_stride, int32_t row_elems, const int32_t* keep,
+                           const int32_t* keep_count, int32_t num_segments, int32_t topk, float* dst, void* stream);
+
+/* Row-wise L2 normalisation x/max(||x||,1e-12) (F.normalize; prototype_learning_network.py:199). */
+osr_status osr_l2_normalize_rows(const float* x, int32_t rows, int32_t d, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * PLN inference tail (prototype_learning_network.py:206-223, COS distance): normalise each embedding, cosine
+ * distance to the (already normalised) prototypes, min over reps then min/argmin over classes (ties: lower
+ * class), unknown if min > unk_thr. class_map (nullable, (num_known)): GraspNet class_id remap (:222).
+ * emb: (rows, d). rows_valid (nullable): per-segment valid counts for padded (segments, seg_rows) layouts;
+ * padded rows get class -1. Outputs: pred_class (rows) int64, min_dist (rows).
+ * --------------------------------------------------------------------------------------------------------- */
+osr_status osr_pln_tail(const float* emb, int64_t rows, int32_t d, const float* protos_normed, int32_t num_known,
+                        int32_t reps, float unk_thr, int64_t unknown_id, const int64_t* class_map,
+                        const int32_t* rows_valid, int32_t seg_rows, int64_t* pred_class, float* min_dist,
+                        void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Softmax classifier candidates: SoftMaxClassifier.inference up to the NMS calls (softmax_classifier.py:300-307,
+ * 66-88, 126-149). Per image (segment of seg_rows detections, det_count[s] valid): known detections
+ * (pred_class != unknown_id): softmax over num_known+1 logits, drop the background column, candidate for every
+ * (det, class) with prob > known_thresh in row-major order; unknown detections: candidate if objectness score >
+ * unknown_thresh. Candidate arrays are padded per image: known cap = seg_rows*num_known, unknown cap = seg_rows.
+ * Outputs (k = known, u = unknown): *_boxes (n,cap,4), *_scores (n,cap), k_cls (n,cap) int32, *_det (n,cap)
+ * int32 source detection, *_count (n).
+ * --------------------------------------------------------------------------------------------------------- */
+osr_status osr_softmax_candidates(const float* logits, int32_t num_known, const float* det_boxes,
+                                  const float* det_scores, const int64_t* pred_class, const int32_t* det_count,
+                                  int32_t n, int32_t seg_rows, int64_t unknown_id, float known_thresh,
+                                  float unknown_thresh, float* k_boxes, float* k_scores, int32_t* k_cls, int32_t* k_det,
+                                  int32_t* k_count, float* u_boxes, float* u_scores, int32_t* u_det, int32_t* u_count,
+                                  void* stream);
+
+/* Final assembly: output order [unknown..., known...] (softmax_classifier.py:328-334), class ids int64
+ * (unknown_id for the unknown group, class_map[c] or c for known). out_* padded to (n, u_topk + k_topk). */
+osr_status osr_assemble_detections(const float* k_boxes, const float* k_scores, const int32_t* k_cls,
+                                   const int32_t* k_keep, const int32_t* k_keep_count, int64_t k_stride, int32_t k_topk,
+                                   const float* u_boxes, const float* u_scores, const int32_t* u_keep,
+                                   const int32_t* u_keep_count, int64_t u_stride, int32_t u_topk, int32_t n,
+                                   int64_t unknown_id, const int64_t* class_map, float* out_boxes, float* out_scores,
+                                   int64_t* out_classes, int32_t* out_count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OSR_H_ */

@@ -1,0 +1,329 @@
+// CF-RPN head tail + proposal selection for gfx950 (include/osr.h: osr_cfrpn_head_tail, osr_rpn_select).
+//
+// Replaces, for all images and pyramid levels at once,
+//   ClsFreeRPNHead.forward after the 3x3 conv     classification_free_rpn.py:159-161
+//   ClsFreeRPN._decode_proposals                   classification_free_rpn.py:591-610
+//   find_top_rpn_proposals                         find_top_proposals.py:60-127
+// Compile with -ffp-contract=off: the decode/clip arithmetic must round exactly like the oracle's.
+#include "osr_common.h"
+
+// ------------------------------------------------------------------------------------------------------
+// head tail: one wave per pixel row of t (c channels, channels-last). 5 dot products + sum of squares.
+// ------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void cfrpn_tail_kernel(const T* __restrict__ t, long long rows, int c,
+                                                         const float* __restrict__ w_delta, const float* __restrict__ b_delta,
+                                                         const float* __restrict__ w_ctr, const float* __restrict__ b_ctr,
+                                                         float* __restrict__ deltas, float* __restrict__ ctr) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];  // [5][c]
+    for (int i = threadIdx.x; i < 5 * c; i += blockDim.x) s_w[i] = i < 4 * c ? w_delta[i] : w_ctr[i - 4 * c];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (long long r = (long long)blockIdx.x * nw + wid; r < rows; r += (long long)gridDim.x * nw) {
+        float ss = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f, d4 = 0.f;
+        const T* row = t + r * c;
+        for (int k = lane * 4; k < c; k += 256) {
+            float v[4];
+            if constexpr (sizeof(T) == 4) {
+                float4 q = *reinterpret_cast<const float4*>(row + k);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            } else {
+                typedef T t4 __attribute__((ext_vector_type(4)));
+                t4 q = *reinterpret_cast<const t4*>(row + k);
+                v[0] = (float)q[0]; v[1] = (float)q[1]; v[2] = (float)q[2]; v[3] = (float)q[3];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ss += v[j] * v[j];
+                d0 += v[j] * s_w[k + j];
+                d1 += v[j] * s_w[c + k + j];
+                d2 += v[j] * s_w[2 * c + k + j];
+                d3 += v[j] * s_w[3 * c + k + j];
+                d4 += v[j] * s_w[4 * c + k + j];
+            }
+        }
+        ss = osr_wave_sum(ss); d0 = osr_wave_sum(d0); d1 = osr_wave_sum(d1);
+        d2 = osr_wave_sum(d2); d3 = osr_wave_sum(d3); d4 = osr_wave_sum(d4);
+        if (lane == 0) {
+            // F.normalize: t / max(||t||_2, 1e-12); the 1x1 convs are linear, so scale the dot products
+            const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+            float4 o = make_float4(d0 * inv + b_delta[0], d1 * inv + b_delta[1], d2 * inv + b_delta[2], d3 * inv + b_delta[3]);
+            *reinterpret_cast<float4*>(deltas + r * 4) = o;
+            const float z = d4 * inv + b_ctr[0];
+            ctr[r] = 1.0f / (1.0f + expf(-z));
+        }
+    }
+}
+
+extern "C" osr_status osr_cfrpn_head_tail(const void* t, int32_t t_dtype, int64_t rows, int32_t c, const float* w_delta,
+                                          const float* b_delta, const float* w_ctr, const float* b_ctr, float* deltas,
+                                          float* ctr, void* stream) {
+    OSR_REQUIRE(t && w_delta && b_delta && w_ctr && b_ctr && deltas && ctr, OSR_ERR_INVALID_ARG, "osr_cfrpn_head_tail: null pointer");
+    OSR_REQUIRE(osr_dtype_ok(t_dtype), OSR_ERR_INVALID_ARG, "osr_cfrpn_head_tail: bad dtype %d", t_dtype);
+    OSR_REQUIRE(c > 0 && c % 4 == 0 && c <= 2048, OSR_ERR_UNSUPPORTED, "osr_cfrpn_head_tail: c must be a multiple of 4 and <= 2048, got %d", c);
+    OSR_REQUIRE(rows >= 0, OSR_ERR_INVALID_ARG, "osr_cfrpn_head_tail: rows < 0");
+    if (rows == 0) return OSR_OK;
+    long long blocks = (rows + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    size_t smem = (size_t)5 * c * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (t_dtype == OSR_F32)
+        hipLaunchKernelGGL(cfrpn_tail_kernel<float>, dim3((unsigned)blocks), dim3(256), smem, st, (const float*)t, rows, c, w_delta, b_delta, w_ctr, b_ctr, deltas, ctr);
+    else if (t_dtype == OSR_F16)
+        hipLaunchKernelGGL(cfrpn_tail_kernel<f16_t>, dim3((unsigned)blocks), dim3(256), smem, st, (const f16_t*)t, rows, c, w_delta, b_delta, w_ctr, b_ctr, deltas, ctr);
+    else
+        hipLaunchKernelGGL(cfrpn_tail_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), smem, st, (const bf16_t*)t, rows, c, w_delta, b_delta, w_ctr, b_ctr, deltas, ctr);
+    OSR_CHECK_LAUNCH("osr_cfrpn_head_tail");
+    return OSR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// proposal selection
+// ------------------------------------------------------------------------------------------------------
+#define SEL_THREADS 1024
+#define SEL_MAXK 2048
+
+struct SelLevels {
+    int num_levels, num_anchors;
+    int h[OSR_MAX_LEVELS], w[OSR_MAX_LEVELS], stride[OSR_MAX_LEVELS];
+    long long offset[OSR_MAX_LEVELS];
+    int klevel[OSR_MAX_LEVELS];  // min(h*w*a, topk)
+    int koff[OSR_MAX_LEVELS];    // prefix of klevel
+    int aoff[OSR_MAX_LEVELS];    // prefix of h*w*a (index into the image's concatenated anchor list)
+    int cap;
+};
+
+// descending bitonic sort of 64-bit keys in LDS, n power of two
+__device__ __forceinline__ void bitonic_desc(unsigned long long* buf, int n) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    unsigned long long a = buf[i], b = buf[ixj];
+                    bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) { buf[i] = b; buf[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Stage A: grid (level, image). Stable top-k by radix select + bitonic sort, ltrb decode, filters.
+// Writes staging arrays st_box/st_score/st_src/st_flag at [img][koff[l] + rank].
+__global__ __launch_bounds__(SEL_THREADS) void rpn_select_kernel(SelLevels lv, const float* __restrict__ cell_anchors,
+                                                                 const float* __restrict__ ctr, const float* __restrict__ deltas,
+                                                                 int n_img, const int* __restrict__ image_hw, float min_box_size,
+                                                                 float* __restrict__ st_box, float* __restrict__ st_score,
+                                                                 int* __restrict__ st_src, int* __restrict__ st_flag,
+                                                                 int* __restrict__ status_flags) {
+    const int l = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const int A = lv.num_anchors, W = lv.w[l];
+    const int cnt = lv.h[l] * W * A;
+    const int k = lv.klevel[l];
+    const float* sc = ctr + lv.offset[l] + (long long)img * cnt;
+    const float* dl = deltas + (lv.offset[l] + (long long)img * cnt) * 4;
+
+    __shared__ unsigned long long s_sel[SEL_MAXK];
+    __shared__ int s_hist[256];
+    __shared__ int s_scan[32];
+    __shared__ unsigned int s_prefix, s_remaining;
+
+    // ---- 1. radix select: key T of the k-th largest element (4 passes x 8 bits, MSB first) ----
+    unsigned int prefix = 0, mask = 0;
+    int remaining = k;  // rank (1-based, from the top) still to resolve inside the current prefix bucket
+    if (cnt > k) {
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            for (int i = tid; i < 256; i += blockDim.x) s_hist[i] = 0;
+            __syncthreads();
+            for (int i = tid; i < cnt; i += blockDim.x) {
+                unsigned int key = osr_float_key(sc[i]);
+                if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int acc = 0, d = 255;
+                for (; d > 0; --d) {
+                    if (acc + s_hist[d] >= remaining) break;
+                    acc += s_hist[d];
+                }
+                s_prefix = prefix | ((unsigned int)d << shift);
+                s_remaining = remaining - acc;
+            }
+            __syncthreads();
+            prefix = s_prefix;
+            remaining = s_remaining;
+            mask |= 255u << shift;
+            __syncthreads();
+        }
+    }
+    // Now: elements with key > prefix are all selected; of those with key == prefix the first `remaining`
+    // in index order are selected (stable tie rule). If cnt <= k everything is selected.
+    const unsigned int T = prefix;
+    const bool all = cnt <= k;
+
+    // ---- 2. ordered compaction into s_sel as (key << 32) | ~index ----
+    int base_gt = 0, base_eq = 0;  // running counts (uniform across the block)
+    int ngt_total = 0;
+    if (!all) {
+        // first count strictly-greater elements so that they go to [0, ngt) and ties to [ngt, k)
+        int c = 0;
+        for (int i = tid; i < cnt; i += blockDim.x) c += osr_float_key(sc[i]) > T;
+        int tot;
+        osr_block_excl_scan(c, s_scan, &tot);
+        ngt_total = tot;
+    }
+    for (int i0 = 0; i0 < cnt; i0 += blockDim.x) {
+        const int i = i0 + tid;
+        unsigned int key = 0;
+        int gt = 0, eq = 0;
+        if (i < cnt) {
+            key = osr_float_key(sc[i]);
+            if (all) gt = 1; else { gt = key > T; eq = key == T; }
+        }
+        int tot;
+        int packed = osr_block_excl_scan(gt | (eq << 16), s_scan, &tot);
+        const int pg = base_gt + (packed & 0xffff), pe = base_eq + (packed >> 16);
+        const unsigned long long comp = ((unsigned long long)key << 32) | (unsigned int)(0xffffffffu - (unsigned int)i);
+        if (gt && pg < SEL_MAXK) s_sel[pg] = comp;
+        if (eq && pe < remaining && ngt_total + pe < SEL_MAXK) s_sel[ngt_total + pe] = comp;
+        base_gt += tot & 0xffff;
+        base_eq += tot >> 16;
+        if (!all && base_eq >= remaining && base_gt >= ngt_total) break;  // uniform
+    }
+    int kp = 1;
+    while (kp < k) kp <<= 1;
+    for (int i = k + tid; i < kp; i += blockDim.x) s_sel[i] = 0ull;  // padding sorts last
+    __syncthreads();
+
+    // ---- 3. sort the survivors: score descending, index ascending ----
+    bitonic_desc(s_sel, kp);
+
+    // ---- 4. decode + filters ----
+    const float ih = (float)image_hw[img * 2 + 0], iw = (float)image_hw[img * 2 + 1];
+    const float fstride = (float)lv.stride[l];
+    bool bad = false;
+    for (int j = tid; j < k; j += blockDim.x) {
+        const unsigned long long comp = s_sel[j];
+        const int idx = (int)(0xffffffffu - (unsigned int)(comp & 0xffffffffull));
+        const float s = sc[idx];
+        const float4 d = *reinterpret_cast<const float4*>(dl + (long long)idx * 4);
+        const int a = idx % A, cell = idx / A;
+        const float sx = (float)(cell % W) * fstride, sy = (float)(cell / W) * fstride;
+        const float* ca = cell_anchors + ((long long)l * A + a) * 4;
+        const float ax1 = sx + ca[0], ay1 = sy + ca[1], ax2 = sx + ca[2], ay2 = sy + ca[3];
+        // [d2] Box2BoxTransformLinear(normalize_by_size=True).apply_deltas
+        const float cx = 0.5f * (ax1 + ax2), cy = 0.5f * (ay1 + ay2);
+        const float aw = ax2 - ax1, ah = ay2 - ay1;
+        const float dl_ = fmaxf(d.x, 0.f) * aw, dt_ = fmaxf(d.y, 0.f) * ah, dr_ = fmaxf(d.z, 0.f) * aw, db_ = fmaxf(d.w, 0.f) * ah;
+        float x1 = cx - dl_, y1 = cy - dt_, x2 = cx + dr_, y2 = cy + db_;
+        // relu(NaN) must stay NaN like torch's: fmaxf drops NaN, so test the raw deltas too
+        const bool dnan = (d.x != d.x) || (d.y != d.y) || (d.z != d.z) || (d.w != d.w);
+        const bool valid = osr_finite(x1) && osr_finite(y1) && osr_finite(x2) && osr_finite(y2) && osr_finite(s) && !dnan;
+        bad |= !valid;
+        x1 = fminf(fmaxf(x1, 0.f), iw); y1 = fminf(fmaxf(y1, 0.f), ih);
+        x2 = fminf(fmaxf(x2, 0.f), iw); y2 = fminf(fmaxf(y2, 0.f), ih);
+        const bool keep = valid && (x2 - x1 > min_box_size) && (y2 - y1 > min_box_size);
+        const long long o = (long long)img * lv.cap + lv.koff[l] + j;
+        *reinterpret_cast<float4*>(st_box + o * 4) = make_float4(x1, y1, x2, y2);
+        st_score[o] = s;
+        st_src[o] = lv.aoff[l] + idx;
+        st_flag[o] = keep ? 1 : 0;
+    }
+    if (bad) atomicOr(status_flags, 1);
+}
+
+// Stage B: one block per image; order-preserving compaction of the staged slots.
+__global__ __launch_bounds__(SEL_THREADS) void rpn_compact_kernel(int cap, const float* __restrict__ st_box,
+                                                                  const float* __restrict__ st_score, const int* __restrict__ st_src,
+                                                                  const int* __restrict__ st_flag, float* __restrict__ boxes,
+                                                                  float* __restrict__ scores, int* __restrict__ src_index,
+                                                                  int* __restrict__ batch_idx, int* __restrict__ counts) {
+    const int img = blockIdx.x, tid = threadIdx.x;
+    __shared__ int s_scan[32];
+    const long long base = (long long)img * cap;
+    int running = 0;
+    for (int i0 = 0; i0 < cap; i0 += blockDim.x) {
+        const int i = i0 + tid;
+        const int f = i < cap ? st_flag[base + i] : 0;
+        int tot;
+        const int pos = running + osr_block_excl_scan(f, s_scan, &tot);
+        if (f) {
+            *reinterpret_cast<float4*>(boxes + (base + pos) * 4) = *reinterpret_cast<const float4*>(st_box + (base + i) * 4);
+            scores[base + pos] = st_score[base + i];
+            src_index[base + pos] = st_src[base + i];
+            batch_idx[base + pos] = img;
+        }
+        running += tot;
+    }
+    for (int i = running + tid; i < cap; i += blockDim.x) {
+        *reinterpret_cast<float4*>(boxes + (base + i) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        scores[base + i] = 0.f;
+        src_index[base + i] = -1;
+        batch_idx[base + i] = -1;
+    }
+    if (tid == 0) counts[img] = running;
+}
+
+static bool fill_levels(const osr_rpn_levels* in, int topk, SelLevels* o) {
+    if (!in || in->num_levels < 1 || in->num_levels > OSR_MAX_LEVELS || in->num_anchors < 1 || topk < 1 || topk > SEL_MAXK) return false;
+    o->num_levels = in->num_levels;
+    o->num_anchors = in->num_anchors;
+    int ko = 0;
+    long long ao = 0;
+    for (int l = 0; l < in->num_levels; ++l) {
+        if (in->h[l] < 1 || in->w[l] < 1 || in->stride[l] < 1 || in->offset[l] < 0) return false;
+        long long cnt = (long long)in->h[l] * in->w[l] * in->num_anchors;
+        if (cnt > (1ll << 30) || ao + cnt > (1ll << 30)) return false;
+        o->h[l] = in->h[l]; o->w[l] = in->w[l]; o->stride[l] = in->stride[l]; o->offset[l] = in->offset[l];
+        o->klevel[l] = (int)(cnt < topk ? cnt : topk);
+        o->koff[l] = ko;
+        o->aoff[l] = (int)ao;
+        ko += o->klevel[l];
+        ao += cnt;
+    }
+    o->cap = ko;
+    return true;
+}
+
+extern "C" int32_t osr_rpn_select_capacity(const osr_rpn_levels* lv, int32_t pre_nms_topk) {
+    SelLevels s;
+    if (!fill_levels(lv, pre_nms_topk, &s)) { osr_set_error("osr_rpn_select_capacity: bad level table / topk (1..%d)", SEL_MAXK); return OSR_ERR_INVALID_ARG; }
+    return s.cap;
+}
+
+extern "C" int64_t osr_rpn_select_workspace_bytes(const osr_rpn_levels* lv, int32_t n, int32_t pre_nms_topk) {
+    SelLevels s;
+    if (!fill_levels(lv, pre_nms_topk, &s) || n < 1) { osr_set_error("osr_rpn_select_workspace_bytes: bad arguments"); return OSR_ERR_INVALID_ARG; }
+    return (int64_t)n * s.cap * (4 * 4 + 4 + 4 + 4);
+}
+
+extern "C" osr_status osr_rpn_select(const osr_rpn_levels* lv, const float* cell_anchors, const float* ctr, const float* deltas,
+                                     int32_t n, const int32_t* image_hw, int32_t pre_nms_topk, float min_box_size, float* boxes,
+                                     float* scores, int32_t* src_index, int32_t* batch_idx, int32_t* counts, int32_t* status_flags,
+                                     void* workspace, int64_t workspace_bytes, void* stream) {
+    SelLevels s;
+    OSR_REQUIRE(fill_levels(lv, pre_nms_topk, &s), OSR_ERR_INVALID_ARG, "osr_rpn_select: bad level table / topk (1..%d)", SEL_MAXK);
+    OSR_REQUIRE(cell_anchors && ctr && deltas && image_hw && boxes && scores && src_index && batch_idx && counts && status_flags && workspace,
+                OSR_ERR_INVALID_ARG, "osr_rpn_select: null pointer");
+    OSR_REQUIRE(n >= 1 && n <= 65535, OSR_ERR_INVALID_ARG, "osr_rpn_select: n out of range");
+    const int64_t need = (int64_t)n * s.cap * 28;
+    OSR_REQUIRE(workspace_bytes >= need, OSR_ERR_WORKSPACE, "osr_rpn_select: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+    OSR_REQUIRE(((uintptr_t)workspace & 15) == 0, OSR_ERR_INVALID_ARG, "osr_rpn_select: workspace must be 16-byte aligned");
+    char* ws = (char*)workspace;
+    float* st_box = (float*)ws;
+    float* st_score = (float*)(ws + (int64_t)n * s.cap * 16);
+    int* st_src = (int*)(ws + (int64_t)n * s.cap * 20);
+    int* st_flag = (int*)(ws + (int64_t)n * s.cap * 24);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(status_flags, 0, sizeof(int32_t), st) != hipSuccess) { osr_set_error("osr_rpn_select: memset failed"); return OSR_ERR_LAUNCH; }
+    hipLaunchKernelGGL(rpn_select_kernel, dim3(s.num_levels, n), dim3(SEL_THREADS), 0, st, s, cell_anchors, ctr, deltas, n, image_hw,
+                       min_box_size, st_box, st_score, st_src, st_flag, status_flags);
+    OSR_CHECK_LAUNCH("osr_rpn_select(select)");
+    hipLaunchKernelGGL(rpn_compact_kernel, dim3(n), dim3(SEL_THREADS), 0, st, s.cap, st_box, st_score, st_src, st_flag, boxes, scores,
+                       src_index, batch_idx, counts);
+    OSR_CHECK_LAUNCH("osr_rpn_select(compact)");
+    return OSR_OK;
+}

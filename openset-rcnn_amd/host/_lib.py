@@ -1,0 +1,106 @@
+"""ctypes binding of libosr_hip.so (include/osr.h). The product path has no fallback: if the library is
+missing or an entry point fails, an exception is raised -- never a silent eager/CPU substitute."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported first: libosr_hip.so then binds to torch's libamdhip64.so.7)
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG_DIR, "libosr_hip.so")
+
+OSR_MAX_LEVELS = 8
+OSR_F32, OSR_F16, OSR_BF16 = 0, 1, 2
+ABI_VERSION = 1
+
+
+class OsrError(RuntimeError):
+    pass
+
+
+class ConvParams(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("hi", C.c_int32), ("wi", C.c_int32), ("cin", C.c_int32),
+        ("ho", C.c_int32), ("wo", C.c_int32), ("cout", C.c_int32),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("stride_h", C.c_int32), ("stride_w", C.c_int32),
+        ("pad_h", C.c_int32), ("pad_w", C.c_int32),
+        ("in_stride_n", C.c_int64), ("in_stride_h", C.c_int64), ("in_stride_w", C.c_int64),
+        ("out_stride_n", C.c_int64), ("out_stride_h", C.c_int64), ("out_stride_w", C.c_int64),
+        ("res_stride_n", C.c_int64), ("res_stride_h", C.c_int64), ("res_stride_w", C.c_int64),
+        ("relu", C.c_int32), ("res_mode", C.c_int32), ("pad_mode", C.c_int32),
+        ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class RpnLevels(C.Structure):
+    _fields_ = [
+        ("num_levels", C.c_int32), ("num_anchors", C.c_int32),
+        ("h", C.c_int32 * OSR_MAX_LEVELS), ("w", C.c_int32 * OSR_MAX_LEVELS),
+        ("stride", C.c_int32 * OSR_MAX_LEVELS), ("offset", C.c_int64 * OSR_MAX_LEVELS),
+    ]
+
+
+class Pyramid(C.Structure):
+    _fields_ = [
+        ("num_levels", C.c_int32), ("c", C.c_int32),
+        ("h", C.c_int32 * OSR_MAX_LEVELS), ("w", C.c_int32 * OSR_MAX_LEVELS),
+        ("scale", C.c_float * OSR_MAX_LEVELS), ("data", C.c_void_p * OSR_MAX_LEVELS),
+    ]
+
+
+P, I32, I64, F32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+F32x3, F32x4 = C.c_float * 3, C.c_float * 4
+
+# name -> (restype, argtypes); mirrors include/osr.h one to one
+PROTOTYPES = {
+    "osr_abi_version": (I32, []),
+    "osr_last_error": (C.c_char_p, []),
+    "osr_stem_padded_width": (I32, [I32]),
+    "osr_preprocess": (I32, [P, I32, I32, I32, I32, I32, I32, C.POINTER(C.c_float), C.POINTER(C.c_float), P, I32, P]),
+    "osr_conv2d_fwd": (I32, [C.POINTER(ConvParams), P, P, P, P, P, P]),
+    "osr_maxpool3x3s2": (I32, [P, I32, I32, I32, I32, P, I32, P]),
+    "osr_subsample2": (I32, [P, I32, I32, I32, I32, P, I32, P]),
+    "osr_gemm_f32": (I32, [P, I64, P, P, P, I64, I32, I32, I32, I32, P]),
+    "osr_cfrpn_head_tail": (I32, [P, I32, I64, I32, P, P, P, P, P, P, P]),
+    "osr_rpn_select_capacity": (I32, [C.POINTER(RpnLevels), I32]),
+    "osr_rpn_select_workspace_bytes": (I64, [C.POINTER(RpnLevels), I32, I32]),
+    "osr_rpn_select": (I32, [C.POINTER(RpnLevels), P, P, P, I32, P, I32, F32, P, P, P, P, P, P, P, I64, P]),
+    "osr_roi_align_fwd": (I32, [C.POINTER(Pyramid), I32, I32, P, P, I64, I32, I32, I32, I32, P, I32, P]),
+    "osr_box_predictor_tail": (I32, [P, I64, I32, P, P, P, P, P, P, C.POINTER(C.c_float), I32, F32, P, P, P, P, P, P]),
+    "osr_nms_topk_workspace_bytes": (I64, [I32, I64]),
+    "osr_nms_topk": (I32, [P, P, P, P, I32, I64, P, F32, I32, P, P, P, I64, P]),
+    "osr_gather_rows": (I32, [P, I64, I32, P, P, I32, I32, P, P]),
+    "osr_l2_normalize_rows": (I32, [P, I32, I32, P, P]),
+    "osr_pln_tail": (I32, [P, I64, I32, P, I32, I32, F32, I64, P, P, I32, P, P, P]),
+    "osr_softmax_candidates": (I32, [P, I32, P, P, P, P, I32, I32, I64, F32, F32, P, P, P, P, P, P, P, P, P, P]),
+    "osr_assemble_detections": (I32, [P, P, P, P, P, I64, I32, P, P, P, P, I64, I32, I32, I64, P, P, P, P, P, P]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libosr_hip.so; raises OsrError when it has not been built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OsrError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950). There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError => header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.osr_abi_version()
+    if ver != ABI_VERSION:
+        raise OsrError(f"libosr_hip.so ABI version {ver} != binding version {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(status: int, name: str) -> None:
+    if status != 0:
+        msg = load().osr_last_error()
+        raise OsrError(f"{name} failed (status {status}): {msg.decode() if msg else ''}")

@@ -1,0 +1,327 @@
+"""Thin torch-tensor wrappers over the C ABI (include/osr.h). torch is plumbing here: device memory, the
+current HIP stream and output allocation. Every op runs on the HIP library or raises; there is no eager path."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvParams, OsrError, Pyramid, RpnLevels, check
+
+_DT = {torch.float32: _lib.OSR_F32, torch.float16: _lib.OSR_F16, torch.bfloat16: _lib.OSR_BF16}
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need(t: torch.Tensor, dtype=None, name="tensor"):
+    if not t.is_cuda:
+        raise OsrError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if dtype is not None and t.dtype != dtype:
+        raise OsrError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise OsrError(f"{name} must be contiguous")
+    return t
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    return _DT[dt]
+
+
+# ----------------------------------------------------------------------------------------------------------
+def stem_padded_width(wp: int) -> int:
+    return int(_lib.load().osr_stem_padded_width(wp))
+
+
+def preprocess(images: torch.Tensor, hp: int, wp: int, mean, std, dtype=torch.float16) -> torch.Tensor:
+    """(n,3,h,w) uint8/float32 -> normalised, zero-haloed (n, hp+6, wpad, 4) NHWC tensor for the stem."""
+    lib = _lib.load()
+    _need(images, name="images")
+    if images.dtype not in (torch.uint8, torch.float32):
+        raise OsrError("images must be uint8 or float32")
+    n, c, h, w = images.shape
+    assert c == 3
+    out = torch.empty((n, hp + 6, stem_padded_width(wp), 4), dtype=dtype, device=images.device)
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s = (C.c_float * 3)(*[float(v) for v in std])
+    check(lib.osr_preprocess(_p(images), int(images.dtype == torch.uint8), n, h, w, hp, wp, m, s, _p(out), _DT[dtype], _stream()),
+          "osr_preprocess")
+    return out
+
+
+def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, stride: int = 1, pad: int = 0, relu: bool = False,
+           residual: Optional[torch.Tensor] = None, res_mode: int = 0, out_dtype: Optional[torch.dtype] = None,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """NHWC implicit-GEMM convolution. x (n,h,w,cin) f16/bf16; weight (cout,kh,kw,cin) same dtype; bias f32."""
+    lib = _lib.load()
+    _need(x, name="x"); _need(weight, x.dtype, "weight"); _need(bias, torch.float32, "bias")
+    n, hi, wi, cin = x.shape
+    cout, kh, kw, cin2 = weight.shape
+    if cin2 != cin:
+        raise OsrError(f"weight cin {cin2} != input cin {cin}")
+    ho = (hi + 2 * pad - kh) // stride + 1
+    wo = (wi + 2 * pad - kw) // stride + 1
+    out_dtype = out_dtype or x.dtype
+    if out is None:
+        out = torch.empty((n, ho, wo, cout), dtype=out_dtype, device=x.device)
+    else:
+        _need(out, out_dtype, "out")
+        assert out.numel() == n * ho * wo * cout
+    p = ConvParams()
+    p.n, p.hi, p.wi, p.cin, p.ho, p.wo, p.cout = n, hi, wi, cin, ho, wo, cout
+    p.kh, p.kw, p.stride_h, p.stride_w, p.pad_h, p.pad_w = kh, kw, stride, stride, pad, pad
+    p.in_stride_n, p.in_stride_h, p.in_stride_w = hi * wi * cin, wi * cin, cin
+    p.out_stride_n, p.out_stride_h, p.out_stride_w = ho * wo * cout, wo * cout, cout
+    p.relu, p.res_mode, p.pad_mode = int(relu), int(res_mode), 0
+    p.in_dtype, p.out_dtype = _DT[x.dtype], _DT[out_dtype]
+    if res_mode:
+        _need(residual, x.dtype, "residual")
+        rn, rh, rw, rc = residual.shape
+        exp = (n, ho, wo, cout) if res_mode == 1 else (n, (ho + 1) // 2, (wo + 1) // 2, cout)
+        if (rn, rh, rw, rc) != exp:
+            raise OsrError(f"residual shape {tuple(residual.shape)} != expected {exp} for res_mode {res_mode}")
+        p.res_stride_n, p.res_stride_h, p.res_stride_w = rh * rw * rc, rw * rc, rc
+    check(lib.osr_conv2d_fwd(C.byref(p), _p(x), _p(weight), _p(bias), _p(residual) if res_mode else None, _p(out), _stream()),
+          "osr_conv2d_fwd")
+    return out
+
+
+def stem_conv(xpad: torch.Tensor, w_view: torch.Tensor, bias: torch.Tensor, hp: int, wp: int, relu: bool = True) -> torch.Tensor:
+    """7x7/s2/p3 stem on the pre-padded NHWC4 image (see preprocess): a (kh=7, kw=1, cin=32) implicit GEMM whose
+    'pixels' are 4-element groups, 8 of which (7 taps + a zero-weight one) form one K slice."""
+    lib = _lib.load()
+    _need(xpad, name="xpad"); _need(w_view, xpad.dtype, "w_view"); _need(bias, torch.float32, "bias")
+    n, hd, wd, c4 = xpad.shape
+    assert c4 == 4 and hd == hp + 6 and wd == stem_padded_width(wp)
+    cout = w_view.shape[0]
+    assert tuple(w_view.shape[1:]) == (7, 1, 32)
+    ho, wo = hp // 2, wp // 2
+    out = torch.empty((n, ho, wo, cout), dtype=xpad.dtype, device=xpad.device)
+    p = ConvParams()
+    p.n, p.hi, p.wi, p.cin, p.ho, p.wo, p.cout = n, hd, wd, 32, ho, wo, cout
+    p.kh, p.kw, p.stride_h, p.stride_w, p.pad_h, p.pad_w = 7, 1, 2, 2, 0, 0
+    p.in_stride_n, p.in_stride_h, p.in_stride_w = hd * wd * 4, wd * 4, 4
+    p.out_stride_n, p.out_stride_h, p.out_stride_w = ho * wo * cout, wo * cout, cout
+    p.relu, p.res_mode, p.pad_mode = int(relu), 0, 1
+    p.in_dtype = p.out_dtype = _DT[xpad.dtype]
+    check(lib.osr_conv2d_fwd(C.byref(p), _p(xpad), _p(w_view), _p(bias), None, _p(out), _stream()), "osr_conv2d_fwd(stem)")
+    return out
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, relu: bool = False,
+           out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """Fully connected layer on the MFMA path: x (m,k) f16/bf16, weight (n,k)."""
+    m, k = x.shape
+    y = conv2d(x.view(1, m, 1, k), weight.view(weight.shape[0], 1, 1, k), bias, relu=relu, out_dtype=out_dtype)
+    return y.view(m, weight.shape[0])
+
+
+def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _need(x, name="x")
+    n, h, w, c = x.shape
+    out = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=x.dtype, device=x.device)
+    check(lib.osr_maxpool3x3s2(_p(x), n, h, w, c, _p(out), _DT[x.dtype], _stream()), "osr_maxpool3x3s2")
+    return out
+
+
+def subsample2(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _need(x, name="x")
+    n, h, w, c = x.shape
+    out = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=x.dtype, device=x.device)
+    check(lib.osr_subsample2(_p(x), n, h, w, c, _p(out), _DT[x.dtype], _stream()), "osr_subsample2")
+    return out
+
+
+def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = False) -> torch.Tensor:
+    lib = _lib.load()
+    _need(a, torch.float32, "a"); _need(w, torch.float32, "w")
+    if bias is not None:
+        _need(bias, torch.float32, "bias")
+    m, k = a.shape
+    n = w.shape[0]
+    assert w.shape[1] == k
+    out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    check(lib.osr_gemm_f32(_p(a), k, _p(w), _p(bias), _p(out), n, m, n, k, int(relu), _stream()), "osr_gemm_f32")
+    return out
+
+
+def cfrpn_head_tail(t: torch.Tensor, w_delta, b_delta, w_ctr, b_ctr) -> Tuple[torch.Tensor, torch.Tensor]:
+    lib = _lib.load()
+    _need(t, name="t")
+    rows, c = t.shape
+    for x in (w_delta, b_delta, w_ctr, b_ctr):
+        _need(x, torch.float32, "head weight")
+    deltas = torch.empty((rows, 4), dtype=torch.float32, device=t.device)
+    ctr = torch.empty((rows,), dtype=torch.float32, device=t.device)
+    check(lib.osr_cfrpn_head_tail(_p(t), _DT[t.dtype], rows, c, _p(w_delta), _p(b_delta), _p(w_ctr), _p(b_ctr), _p(deltas), _p(ctr),
+                                  _stream()), "osr_cfrpn_head_tail")
+    return deltas, ctr
+
+
+def make_rpn_levels(shapes: Sequence[Tuple[int, int]], strides: Sequence[int], n: int, num_anchors: int = 1) -> RpnLevels:
+    lv = RpnLevels()
+    lv.num_levels, lv.num_anchors = len(shapes), num_anchors
+    off = 0
+    for i, ((h, w), s) in enumerate(zip(shapes, strides)):
+        lv.h[i], lv.w[i], lv.stride[i], lv.offset[i] = h, w, s, off
+        off += n * h * w * num_anchors
+    return lv
+
+
+def rpn_select(lv: RpnLevels, cell_anchors: torch.Tensor, ctr: torch.Tensor, deltas: torch.Tensor, n: int,
+               image_hw: torch.Tensor, pre_nms_topk: int, min_box_size: float = 0.0):
+    """ctr/deltas: level-major concatenation (see osr.h). Returns dict of padded outputs."""
+    lib = _lib.load()
+    _need(cell_anchors, torch.float32, "cell_anchors"); _need(ctr, torch.float32, "ctr"); _need(deltas, torch.float32, "deltas")
+    _need(image_hw, torch.int32, "image_hw")
+    cap = lib.osr_rpn_select_capacity(C.byref(lv), pre_nms_topk)
+    if cap < 0:
+        check(cap, "osr_rpn_select_capacity")
+    wsb = lib.osr_rpn_select_workspace_bytes(C.byref(lv), n, pre_nms_topk)
+    dev = ctr.device
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    boxes = torch.empty((n, cap, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((n, cap), dtype=torch.float32, device=dev)
+    src = torch.empty((n, cap), dtype=torch.int32, device=dev)
+    bidx = torch.empty((n * cap,), dtype=torch.int32, device=dev)
+    counts = torch.empty((n,), dtype=torch.int32, device=dev)
+    flags = torch.zeros((1,), dtype=torch.int32, device=dev)
+    check(lib.osr_rpn_select(C.byref(lv), _p(cell_anchors), _p(ctr), _p(deltas), n, _p(image_hw), pre_nms_topk, float(min_box_size),
+                             _p(boxes), _p(scores), _p(src), _p(bidx), _p(counts), _p(flags), _p(ws), wsb, _stream()), "osr_rpn_select")
+    return dict(boxes=boxes, scores=scores, src_index=src, batch_idx=bidx, counts=counts, status_flags=flags, cap=cap)
+
+
+def roi_align(feats: List[torch.Tensor], scales: Sequence[float], boxes: torch.Tensor, batch_idx: torch.Tensor,
+              pooled: int = 7, out_dtype: Optional[torch.dtype] = None, canonical_level: int = 4, canonical_size: int = 224,
+              min_level: int = 2) -> torch.Tensor:
+    """feats: NHWC per level; boxes (m,4) fp32; batch_idx (m) int32. Returns (m, pooled, pooled, c)."""
+    lib = _lib.load()
+    _need(boxes, torch.float32, "boxes"); _need(batch_idx, torch.int32, "batch_idx")
+    py = Pyramid()
+    py.num_levels, py.c = len(feats), feats[0].shape[3]
+    for i, (f, s) in enumerate(zip(feats, scales)):
+        _need(f, feats[0].dtype, f"feats[{i}]")
+        py.h[i], py.w[i], py.scale[i], py.data[i] = f.shape[1], f.shape[2], float(s), f.data_ptr()
+    m = boxes.shape[0]
+    out_dtype = out_dtype or feats[0].dtype
+    out = torch.empty((m, pooled, pooled, py.c), dtype=out_dtype, device=boxes.device)
+    check(lib.osr_roi_align_fwd(C.byref(py), _DT[feats[0].dtype], feats[0].shape[0], _p(boxes), _p(batch_idx), m, pooled,
+                                canonical_level, canonical_size, min_level, _p(out), _DT[out_dtype], _stream()), "osr_roi_align_fwd")
+    return out
+
+
+def box_predictor_tail(x, w, b, proposals, ctr, batch_idx, image_hw, reg_weights=(10.0, 10.0, 5.0, 5.0), mean_type=0,
+                       score_thresh=0.05):
+    lib = _lib.load()
+    for t, nme in ((x, "x"), (w, "w"), (b, "b"), (proposals, "proposals"), (ctr, "ctr")):
+        _need(t, torch.float32, nme)
+    _need(batch_idx, torch.int32, "batch_idx"); _need(image_hw, torch.int32, "image_hw")
+    m, k = x.shape
+    dev = x.device
+    pd = torch.empty((m, 4), dtype=torch.float32, device=dev)
+    pi = torch.empty((m,), dtype=torch.float32, device=dev)
+    bx = torch.empty((m, 4), dtype=torch.float32, device=dev)
+    sc = torch.empty((m,), dtype=torch.float32, device=dev)
+    cd = torch.empty((m,), dtype=torch.int32, device=dev)
+    rw = (C.c_float * 4)(*[float(v) for v in reg_weights])
+    check(lib.osr_box_predictor_tail(_p(x), m, k, _p(w), _p(b), _p(proposals), _p(ctr), _p(batch_idx), _p(image_hw), rw, mean_type,
+                                     float(score_thresh), _p(pd), _p(pi), _p(bx), _p(sc), _p(cd), _stream()), "osr_box_predictor_tail")
+    return dict(pred_deltas=pd, pred_iou=pi, boxes=bx, score=sc, cand=cd)
+
+
+def nms_topk(boxes, scores, cls, cand, num_segments: int, seg_stride: int, seg_len, thr: float, topk: int):
+    lib = _lib.load()
+    _need(boxes, torch.float32, "boxes"); _need(scores, torch.float32, "scores"); _need(seg_len, torch.int32, "seg_len")
+    if cls is not None:
+        _need(cls, torch.int32, "cls")
+    if cand is not None:
+        _need(cand, torch.int32, "cand")
+    dev = boxes.device
+    wsb = lib.osr_nms_topk_workspace_bytes(num_segments, seg_stride)
+    if wsb < 0:
+        check(int(wsb), "osr_nms_topk_workspace_bytes")
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    keep = torch.empty((num_segments, topk), dtype=torch.int32, device=dev)
+    cnt = torch.empty((num_segments,), dtype=torch.int32, device=dev)
+    check(lib.osr_nms_topk(_p(boxes), _p(scores), _p(cls), _p(cand), num_segments, seg_stride, _p(seg_len), float(thr), topk, _p(keep),
+                           _p(cnt), _p(ws), wsb, _stream()), "osr_nms_topk")
+    return keep, cnt
+
+
+def gather_rows(src, seg_stride: int, keep, keep_count) -> torch.Tensor:
+    lib = _lib.load()
+    _need(src, torch.float32, "src"); _need(keep, torch.int32, "keep"); _need(keep_count, torch.int32, "keep_count")
+    nseg, topk = keep.shape
+    row = src.shape[-1] if src.dim() > 1 else 1
+    dst = torch.empty((nseg, topk, row), dtype=torch.float32, device=src.device)
+    check(lib.osr_gather_rows(_p(src), seg_stride, row, _p(keep), _p(keep_count), nseg, topk, _p(dst), _stream()), "osr_gather_rows")
+    return dst
+
+
+def l2_normalize_rows(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _need(x, torch.float32, "x")
+    out = torch.empty_like(x)
+    check(lib.osr_l2_normalize_rows(_p(x), x.shape[0], x.shape[1], _p(out), _stream()), "osr_l2_normalize_rows")
+    return out
+
+
+def pln_tail(emb, protos_normed, num_known: int, reps: int, unk_thr: float, unknown_id: int, class_map=None, rows_valid=None,
+             seg_rows: int = 0):
+    lib = _lib.load()
+    _need(emb, torch.float32, "emb"); _need(protos_normed, torch.float32, "protos")
+    if class_map is not None:
+        _need(class_map, torch.int64, "class_map")
+    if rows_valid is not None:
+        _need(rows_valid, torch.int32, "rows_valid")
+    rows, d = emb.shape
+    pc = torch.empty((rows,), dtype=torch.int64, device=emb.device)
+    md = torch.empty((rows,), dtype=torch.float32, device=emb.device)
+    check(lib.osr_pln_tail(_p(emb), rows, d, _p(protos_normed), num_known, reps, float(unk_thr), int(unknown_id), _p(class_map),
+                           _p(rows_valid), seg_rows, _p(pc), _p(md), _stream()), "osr_pln_tail")
+    return pc, md
+
+
+def softmax_candidates(logits, num_known, det_boxes, det_scores, pred_class, det_count, n, seg_rows, unknown_id, known_thresh,
+                       unknown_thresh):
+    lib = _lib.load()
+    _need(logits, torch.float32, "logits"); _need(det_boxes, torch.float32, "det_boxes"); _need(det_scores, torch.float32, "det_scores")
+    _need(pred_class, torch.int64, "pred_class"); _need(det_count, torch.int32, "det_count")
+    dev = logits.device
+    kcap = seg_rows * num_known
+    o = dict(
+        k_boxes=torch.empty((n, kcap, 4), dtype=torch.float32, device=dev), k_scores=torch.empty((n, kcap), dtype=torch.float32, device=dev),
+        k_cls=torch.empty((n, kcap), dtype=torch.int32, device=dev), k_det=torch.empty((n, kcap), dtype=torch.int32, device=dev),
+        k_count=torch.empty((n,), dtype=torch.int32, device=dev),
+        u_boxes=torch.empty((n, seg_rows, 4), dtype=torch.float32, device=dev), u_scores=torch.empty((n, seg_rows), dtype=torch.float32, device=dev),
+        u_det=torch.empty((n, seg_rows), dtype=torch.int32, device=dev), u_count=torch.empty((n,), dtype=torch.int32, device=dev))
+    check(lib.osr_softmax_candidates(_p(logits), num_known, _p(det_boxes), _p(det_scores), _p(pred_class), _p(det_count), n, seg_rows,
+                                     int(unknown_id), float(known_thresh), float(unknown_thresh), _p(o["k_boxes"]), _p(o["k_scores"]),
+                                     _p(o["k_cls"]), _p(o["k_det"]), _p(o["k_count"]), _p(o["u_boxes"]), _p(o["u_scores"]), _p(o["u_det"]),
+                                     _p(o["u_count"]), _stream()), "osr_softmax_candidates")
+    return o
+
+
+def assemble_detections(cands, k_keep, k_keep_count, u_keep, u_keep_count, n, unknown_id, class_map=None):
+    lib = _lib.load()
+    k_topk, u_topk = k_keep.shape[1], u_keep.shape[1]
+    dev = k_keep.device
+    cap = k_topk + u_topk
+    ob = torch.empty((n, cap, 4), dtype=torch.float32, device=dev)
+    os_ = torch.empty((n, cap), dtype=torch.float32, device=dev)
+    oc = torch.empty((n, cap), dtype=torch.int64, device=dev)
+    on = torch.empty((n,), dtype=torch.int32, device=dev)
+    check(lib.osr_assemble_detections(_p(cands["k_boxes"]), _p(cands["k_scores"]), _p(cands["k_cls"]), _p(k_keep), _p(k_keep_count),
+                                      cands["k_boxes"].shape[1], k_topk, _p(cands["u_boxes"]), _p(cands["u_scores"]), _p(u_keep),
+                                      _p(u_keep_count), cands["u_boxes"].shape[1], u_topk, n, int(unknown_id), _p(class_map), _p(ob),
+                                      _p(os_), _p(oc), _p(on), _stream()), "osr_assemble_detections")
+    return ob, os_, oc, on

@@ -1,0 +1,450 @@
+"""GPU parity tests: every HIP entry point (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact for index / integer outputs (top-k order, kept lists, counts, classes) and for the fp32 box
+arithmetic that feeds them (decode, clip); 1e-4 relative for fp32 values produced by reductions (the kernels
+sum in a different order than torch-CPU); fp16/bf16 MFMA contractions are compared on identically rounded
+inputs with fp32 accumulation on both sides.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import c_binding as CO
+from oracle import osr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops(osr):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: the HIP path has no CPU fallback")
+    osr._lib.load()
+    return osr.ops
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def nhwc(x):  # (N,C,H,W) -> contiguous NHWC
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def assert_close(a, b, rtol=1e-4, atol=None, name=""):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    if atol is None:
+        atol = rtol * max(float(b.abs().max()), 1e-6)
+    bad = (a - b).abs() > atol + rtol * b.abs()
+    assert not bool(bad.any()), f"{name}: {int(bad.sum())}/{bad.numel()} mismatches, max abs err {float((a - b).abs().max()):.3e}"
+
+
+# ------------------------------------------------------------------------------------------------------
+def test_preprocess(ops):
+    img = torch.randint(0, 256, (2, 3, 37, 50), generator=g(0), dtype=torch.uint8)
+    mean, std = (103.53, 116.28, 123.675), (1.0, 2.0, 0.5)
+    for src in (img, img.float() + 0.25):
+        out = ops.preprocess(src.to(DEV), 64, 64, mean, std, torch.float16).cpu()
+        assert out.shape == (2, 70, 72, 4)
+        ref = torch.zeros(2, 70, 72, 4)
+        nrm = (src.float() - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+        ref[:, 3:40, 3:53, :3] = nrm.permute(0, 2, 3, 1)
+        assert torch.equal(out.float(), ref.half().float())
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, stride, pad, relu, res_mode, dtype, out_dtype
+    (2, 20, 28, 64, 128, 3, 1, 1, True, 0, torch.float16, torch.float32),
+    (2, 20, 28, 64, 64, 3, 1, 1, True, 0, torch.float16, torch.float16),      # BN=64 tile
+    (1, 23, 17, 96, 200, 1, 1, 0, False, 0, torch.float16, torch.float32),    # M and N tails
+    (2, 21, 30, 128, 256, 1, 2, 0, False, 0, torch.float16, torch.float32),   # strided 1x1 (MSRA)
+    (2, 14, 18, 64, 256, 1, 1, 0, True, 1, torch.float16, torch.float16),     # bottleneck shortcut add
+    (1, 10, 12, 256, 256, 1, 1, 0, False, 2, torch.float16, torch.float16),   # FPN top-down upsample add
+    (1, 9, 11, 32, 8, 3, 1, 1, False, 0, torch.float16, torch.float32),       # smallest legal channels
+    (2, 20, 28, 64, 128, 3, 1, 1, True, 1, torch.bfloat16, torch.bfloat16),
+    (1, 16, 16, 512, 512, 3, 2, 1, True, 0, torch.bfloat16, torch.float32),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(ops, case):
+    n, h, w, cin, cout, k, stride, pad, relu, res_mode, dt, odt = case
+    gg = g(hash(case[:8]) % 1000)
+    x = (torch.randn(n, cin, h, w, generator=gg)).to(dt)
+    wt = (torch.randn(cout, cin, k, k, generator=gg) / math.sqrt(cin * k * k)).to(dt)
+    b = torch.randn(cout, generator=gg)
+    ref = F.conv2d(x.float(), wt.float(), b, stride=stride, padding=pad)
+    res = None
+    if res_mode == 1:
+        res = torch.randn(ref.shape, generator=gg).to(dt)
+        ref = ref + res.float()
+    elif res_mode == 2:
+        res = torch.randn(n, cout, (ref.shape[2] + 1) // 2, (ref.shape[3] + 1) // 2, generator=gg).to(dt)
+        ref = ref + F.interpolate(res.float(), scale_factor=2.0, mode="nearest")[:, :, : ref.shape[2], : ref.shape[3]]
+    if relu:
+        ref = F.relu(ref)
+    out = ops.conv2d(nhwc(x).to(DEV), wt.permute(0, 2, 3, 1).contiguous().to(DEV), b.to(DEV), stride=stride, pad=pad, relu=relu,
+                     residual=None if res is None else nhwc(res).to(DEV), res_mode=res_mode, out_dtype=odt)
+    out = out.cpu().float().permute(0, 3, 1, 2)
+    if odt == torch.float32:
+        assert_close(out, ref, rtol=1e-4, name="conv fp32 out")
+    else:
+        eps = 2.0 ** -10 if odt == torch.float16 else 2.0 ** -7  # one rounding of the stored result
+        assert_close(out, ref, rtol=eps, atol=eps * float(ref.abs().max()) * 0.01 + 1e-6, name="conv half out")
+
+
+def test_stem_conv_matches_7x7(ops):
+    gg = g(5)
+    img = torch.randint(0, 256, (2, 3, 61, 90), generator=gg, dtype=torch.uint8)
+    hp, wp = 64, 96
+    mean, std = (103.53, 116.28, 123.675), (1.0, 1.0, 1.0)
+    w7 = torch.randn(64, 3, 7, 7, generator=gg) * 0.02
+    b = torch.randn(64, generator=gg)
+    xpad = ops.preprocess(img.to(DEV), hp, wp, mean, std, torch.float16)
+    # stem view weight: [co][kh][0][kw*4 + c], 8th tap and 4th channel zero
+    wv = torch.zeros(64, 7, 1, 32)
+    wv.view(64, 7, 8, 4)[:, :, :7, :3] = w7.half().float().permute(0, 2, 3, 1)
+    out = ops.stem_conv(xpad, wv.half().to(DEV), b.to(DEV), hp, wp, relu=True).cpu().float().permute(0, 3, 1, 2)
+    batch, _ = O.preprocess_images([im for im in img], mean, std)
+    batch = F.pad(batch, (0, wp - batch.shape[3], 0, hp - batch.shape[2]))
+    ref = F.relu(F.conv2d(batch.half().float(), w7.half().float(), b, stride=2, padding=3))
+    assert out.shape == ref.shape
+    eps = 2.0 ** -10
+    assert_close(out, ref, rtol=eps, atol=eps * float(ref.abs().max()) * 0.01 + 1e-5, name="stem")
+
+
+def test_linear_large_k(ops):
+    gg = g(6)
+    x = torch.randn(300, 12544, generator=gg).half()
+    w = (torch.randn(1024, 12544, generator=gg) / 112).half()
+    b = torch.randn(1024, generator=gg)
+    out = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), relu=True, out_dtype=torch.float32).cpu()
+    ref = F.relu(x.double() @ w.double().t() + b.double()).float()
+    assert_close(out, ref, rtol=1e-4, name="fc1")
+
+
+def test_maxpool_and_subsample(ops):
+    x = torch.randn(2, 64, 21, 30, generator=g(7)).half()
+    out = ops.maxpool3x3s2(nhwc(x).to(DEV)).cpu().permute(0, 3, 1, 2)
+    assert torch.equal(out, F.max_pool2d(x.float(), 3, 2, 1).half())
+    out = ops.subsample2(nhwc(x).to(DEV)).cpu().permute(0, 3, 1, 2)
+    assert torch.equal(out, F.max_pool2d(x.float(), 1, 2, 0).half())
+
+
+@pytest.mark.parametrize("m,n,k,relu", [(1000, 256, 1024, False), (333, 1024, 256, True), (130, 21, 1024, False), (1, 7, 16, False)])
+def test_gemm_f32(ops, m, n, k, relu):
+    gg = g(m + n)
+    a = torch.randn(m, k, generator=gg)
+    w = torch.randn(n, k, generator=gg) / math.sqrt(k)
+    b = torch.randn(n, generator=gg)
+    out = ops.gemm_f32(a.to(DEV), w.to(DEV), b.to(DEV), relu=relu).cpu()
+    ref = a.double() @ w.double().t() + b.double()
+    if relu:
+        ref = F.relu(ref)
+    assert_close(out, ref.float(), rtol=1e-5, name="gemm_f32")
+
+
+# ------------------------------------------------------------------------------------------------------
+def test_cfrpn_head_tail(ops):
+    p = O.make_head_params(0)
+    for dt in (torch.float32, torch.float16):
+        t = F.relu(torch.randn(5000, 256, generator=g(8))).to(dt)
+        t[17] = 0  # zero row: eps clamp path
+        d, c = ops.cfrpn_head_tail(t.to(DEV), p["proposal_generator.rpn_head.anchor_deltas.weight"].view(4, 256).to(DEV),
+                                   p["proposal_generator.rpn_head.anchor_deltas.bias"].to(DEV),
+                                   p["proposal_generator.rpn_head.centerness.weight"].view(1, 256).to(DEV),
+                                   p["proposal_generator.rpn_head.centerness.bias"].to(DEV))
+        dr, cr = O.cfrpn_head_tail(t.float(), p)
+        assert_close(d, dr, rtol=1e-4, atol=1e-5, name="deltas")
+        assert_close(c, cr, rtol=1e-4, atol=1e-6, name="ctr")
+
+
+def _run_select(ops, shapes, strides, sizes, n, topk, image_sizes, seed, ties=False, poison=False):
+    gg = g(seed)
+    anchors = O.anchor_grid(shapes, strides, sizes)
+    ctr = [torch.rand(n, h * w, generator=gg) for h, w in shapes]
+    if ties:
+        ctr = [(c * 20).round() / 20 for c in ctr]  # many exact ties, incl. at the k-th value
+    deltas = [torch.randn(n, h * w, 4, generator=gg) * 1.5 for h, w in shapes]
+    if poison:
+        deltas[0][0, 3, 1] = float("nan")
+        ctr[0][0, 3] = 2.0
+        deltas[0][n - 1, 5, 2] = float("inf")
+        ctr[0][n - 1, 5] = 3.0
+        deltas[1][0, 0] = torch.tensor([-1.0, -1.0, -1.0, -1.0])  # collapses to a point -> empty
+        ctr[1][0, 0] = 4.0
+        deltas[0][0, 7, 0] = float("-inf")  # relu(-inf) = 0: stays valid
+        ctr[0][0, 7] = 5.0
+    props = [O.ltrb_apply_deltas(d.reshape(-1, 4), a.unsqueeze(0).expand(n, -1, -1).reshape(-1, 4)).view(n, -1, 4)
+             for d, a in zip(deltas, anchors)]
+    ref = O.find_top_rpn_proposals(props, ctr, image_sizes, topk)
+    lv = ops.make_rpn_levels(shapes, strides, n, 1)
+    cell = torch.tensor([[[-s / 2, -s / 2, s / 2, s / 2]] for s in sizes], dtype=torch.float32)
+    ctr_cat = torch.cat([c.reshape(-1) for c in ctr]).to(DEV)
+    del_cat = torch.cat([d.reshape(-1, 4) for d in deltas]).to(DEV)
+    hw = torch.tensor(image_sizes, dtype=torch.int32).to(DEV)
+    r = ops.rpn_select(lv, cell.to(DEV), ctr_cat, del_cat, n, hw, topk)
+    counts = r["counts"].cpu()
+    for i, (rb, rs, ri) in enumerate(ref):
+        c = int(counts[i])
+        assert c == len(rb), f"image {i}: count {c} vs {len(rb)}"
+        assert torch.equal(r["src_index"][i, :c].cpu().long(), ri), f"image {i}: selected anchor indices differ"
+        assert torch.equal(r["scores"][i, :c].cpu(), rs)
+        assert torch.equal(r["boxes"][i, :c].cpu(), rb), f"image {i}: decoded boxes not bit-exact"
+        assert bool((r["batch_idx"].view(n, -1)[i, :c].cpu() == i).all()) and bool((r["batch_idx"].view(n, -1)[i, c:].cpu() == -1).all())
+    return r, ref
+
+
+def test_rpn_select_small_with_ties_and_poison(ops):
+    shapes, strides, sizes = [(24, 40), (12, 20), (6, 10), (3, 5)], (4, 8, 16, 32), (32, 64, 128, 256)
+    r, _ = _run_select(ops, shapes, strides, sizes, 3, 100, [(96, 160), (90, 150), (96, 100)], 11, ties=True, poison=True)
+    assert int(r["status_flags"].cpu()[0]) != 0
+    r, _ = _run_select(ops, shapes, strides, sizes, 2, 2000, [(96, 160)] * 2, 12)  # k >= level size: take all
+    assert int(r["status_flags"].cpu()[0]) == 0
+
+
+def test_rpn_select_full_size(ops):
+    shapes = O.level_shapes(800, 1344)
+    r, ref = _run_select(ops, shapes, O.FPN_STRIDES, O.ANCHOR_SIZES, 2, 1000, [(800, 1333), (750, 1333)], 13, ties=True)
+    assert r["cap"] == 4273
+    _run_select(ops, shapes, O.FPN_STRIDES, O.ANCHOR_SIZES, 1, 2000, [(800, 1333)], 14)  # train-time k: cap 7323
+
+
+# ------------------------------------------------------------------------------------------------------
+def _roi_case(seed, n=2, c=256, hw=(64, 96)):
+    gg = g(seed)
+    h, w = hw
+    feats = [torch.randn(n, c, h // s, w // s, generator=gg) for s in (4, 8, 16, 32)]
+    m = 300
+    ctr = torch.rand(m, 2, generator=gg) * torch.tensor([w * 1.0, h * 1.0])
+    size = torch.exp(torch.rand(m, 2, generator=gg) * 6.0)  # 1 .. 400 px: all four levels, tiny and huge
+    boxes = torch.cat((ctr - size / 2, ctr + size / 2), dim=1)
+    boxes[0] = torch.tensor([10.0, 10.0, 10.0, 10.0])      # zero area
+    boxes[1] = torch.tensor([-50.0, -40.0, 30.0, 20.0])    # crosses the top-left border
+    boxes[2] = torch.tensor([0.0, 0.0, float(w), float(h)])  # whole image
+    boxes[3] = torch.tensor([w - 5.0, h - 5.0, w + 300.0, h + 300.0])  # mostly outside
+    bidx = torch.randint(0, n, (m,), generator=gg, dtype=torch.int32)
+    bidx[7] = -1
+    return feats, boxes, bidx
+
+
+@pytest.mark.parametrize("dt,odt", [(torch.float32, torch.float32), (torch.float16, torch.float32), (torch.float16, torch.float16),
+                                    (torch.bfloat16, torch.float32)])
+def test_roi_align_vs_oracle(ops, dt, odt):
+    feats, boxes, bidx = _roi_case(21)
+    fq = [f.to(dt) for f in feats]
+    out = ops.roi_align([nhwc(f).to(DEV) for f in fq], (0.25, 0.125, 0.0625, 0.03125), boxes.to(DEV), bidx.to(DEV), 7, odt)
+    out = out.cpu().float().permute(0, 3, 1, 2)  # (m,7,7,c) -> (m,c,7,7)
+    lv = O.assign_levels(boxes)
+    ref = torch.zeros_like(out)
+    for l, s in enumerate((0.25, 0.125, 0.0625, 0.03125)):
+        ids = torch.nonzero((lv == l) & (bidx >= 0)).squeeze(1)
+        rois = torch.cat((bidx[ids].float().unsqueeze(1), boxes[ids]), dim=1)
+        ref[ids] = CO.roi_align(fq[l].float(), rois, s)
+    assert float(out[7].abs().max()) == 0.0 and float(out[0].abs().max()) == 0.0
+    if odt == torch.float32:
+        assert_close(out, ref, rtol=1e-4, atol=1e-5, name="roi_align")
+    else:
+        assert_close(out, ref, rtol=2.0 ** -10, atol=2e-3, name="roi_align f16 out")
+
+
+def test_roi_align_wide_bins_take_the_sample_loop(ops):
+    # one coarse level only: a 600 px RoI at stride 4 has 21 px bins (> the 13 px LDS table) -> 4-tap fallback
+    gg = g(22)
+    f = torch.randn(1, 8, 160, 200, generator=gg)
+    boxes = torch.tensor([[20.0, 30.0, 620.0, 500.0], [100.0, 100.0, 140.0, 130.0]])
+    bidx = torch.zeros(2, dtype=torch.int32)
+    out = ops.roi_align([nhwc(f).to(DEV)], (0.25,), boxes.to(DEV), bidx.to(DEV), 7, torch.float32, min_level=2).cpu().permute(0, 3, 1, 2)
+    ref = CO.roi_align(f, torch.cat((bidx.float().unsqueeze(1), boxes), 1), 0.25)
+    assert_close(out, ref, rtol=1e-4, atol=1e-5, name="roi_align fallback")
+
+
+def test_roi_align_linear_ramp_is_exact(ops):
+    ys, xs = torch.meshgrid(torch.arange(50.0), torch.arange(84.0), indexing="ij")
+    f = (0.5 * xs - 0.25 * ys + 3.0).view(1, 1, 50, 84).expand(1, 4, 50, 84).contiguous()
+    boxes = torch.tensor([[100.0, 80.0, 400.0, 390.0]])
+    out = ops.roi_align([nhwc(f).to(DEV)], (1 / 16,), boxes.to(DEV), torch.zeros(1, dtype=torch.int32, device=DEV), 7, torch.float32,
+                        min_level=4).cpu()[0, :, :, 0]
+    x1, y1, x2, y2 = [(v / 16 - 0.5) for v in boxes[0].tolist()]
+    for ph in range(7):
+        for pw in range(7):
+            cx, cy = x1 + (pw + 0.5) * (x2 - x1) / 7, y1 + (ph + 0.5) * (y2 - y1) / 7
+            assert out[ph, pw].item() == pytest.approx(0.5 * cx - 0.25 * cy + 3.0, rel=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------------
+def test_box_predictor_tail(ops):
+    gg = g(31)
+    p = O.make_head_params(1)
+    m = 2000
+    x = F.relu(torch.randn(m, 1024, generator=gg))
+    xy = torch.rand(m, 2, generator=gg) * torch.tensor([1200.0, 700.0])
+    props = torch.cat((xy, xy + torch.rand(m, 2, generator=gg) * 300 + 1), dim=1)
+    ctr = torch.rand(m, generator=gg)
+    bidx = torch.randint(0, 2, (m,), generator=gg, dtype=torch.int32)
+    bidx[5] = -1
+    hw = torch.tensor([[800, 1333], [640, 1000]], dtype=torch.int32)
+    w = torch.cat((p["roi_heads.box_predictor.bbox_pred.weight"], p["roi_heads.box_predictor.iou_pred.weight"]))
+    b = torch.cat((p["roi_heads.box_predictor.bbox_pred.bias"], p["roi_heads.box_predictor.iou_pred.bias"]))
+    r = ops.box_predictor_tail(x.to(DEV), w.to(DEV), b.to(DEV), props.to(DEV), ctr.to(DEV), bidx.to(DEV), hw.to(DEV))
+    d, iou = O.box_predictor(x, p)
+    assert_close(r["pred_deltas"], torch.where(bidx.unsqueeze(1) >= 0, d, torch.zeros(1)), rtol=1e-4, atol=1e-5, name="deltas")
+    assert_close(r["pred_iou"], torch.where(bidx >= 0, iou[:, 0], torch.zeros(1)), rtol=1e-4, atol=1e-6, name="iou")
+    # downstream arithmetic checked on the kernel's own deltas/iou (identical inputs => tight tolerance)
+    dk, ik = r["pred_deltas"].cpu(), r["pred_iou"].cpu()
+    boxes = O.b2b_apply_deltas(dk, props)
+    score = O.objectness_score(ik, ctr)
+    for i in range(2):
+        sel = bidx == i
+        bc = O.box_clip(boxes[sel], tuple(hw[i].tolist()))
+        assert_close(r["boxes"].cpu()[sel], bc, rtol=1e-5, atol=1e-3, name="boxes")
+    assert_close(r["score"].cpu()[bidx >= 0], score[bidx >= 0], rtol=1e-6, atol=1e-7, name="score")
+    cand = (score > 0.05) & (bidx >= 0)
+    near = (score - 0.05).abs() < 1e-6
+    assert bool(((r["cand"].cpu() != 0) == cand)[~near].all())
+
+
+def _nms_inputs(seed, nseg, stride, lens, ncls):
+    rng = np.random.default_rng(seed)
+    xy = rng.uniform(0, 300, (nseg, stride, 2)).astype(np.float32)
+    wh = rng.uniform(10, 120, (nseg, stride, 2)).astype(np.float32)
+    boxes = np.concatenate((xy, xy + wh), 2)
+    scores = np.round(rng.uniform(0, 1, (nseg, stride)), 3).astype(np.float32)  # exact ties
+    cls = rng.integers(0, ncls, (nseg, stride)).astype(np.int32)
+    cand = (rng.uniform(0, 1, (nseg, stride)) > 0.2).astype(np.int32)
+    return boxes, scores, cls, cand, np.asarray(lens, dtype=np.int32)
+
+
+@pytest.mark.parametrize("stride,lens,ncls,thr,topk", [
+    (1000, [1000, 37, 0, 999], 5, 0.5, 50),
+    (1000, [1000, 500], 1, 0.5, 1000),       # topk never reached
+    (4273, [4273, 4000, 1], 1, 1.0, 1000),   # first-stage: pure stable sort + top-1000 (LDS sort, 8192 slots)
+    (20000, [20000, 12345], 20, 0.5, 50),    # worst-case known candidates: global-memory sort path
+    (64, [64, 1], 3, 0.3, 10),
+])
+def test_nms_topk_bit_exact(ops, stride, lens, ncls, thr, topk):
+    nseg = len(lens)
+    boxes, scores, cls, cand, seg_len = _nms_inputs(stride + len(lens), nseg, stride, lens, ncls)
+    keep, cnt = ops.nms_topk(torch.from_numpy(boxes).to(DEV), torch.from_numpy(scores).to(DEV), torch.from_numpy(cls).to(DEV),
+                             torch.from_numpy(cand).to(DEV), nseg, stride, torch.from_numpy(seg_len).to(DEV), thr, topk)
+    keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+    for s in range(nseg):
+        ids = np.nonzero(cand[s, : lens[s]])[0]
+        if thr >= 1.0:
+            k = ids[CO.argsort_desc(scores[s, ids])][:topk]
+        else:
+            k = ids[CO.batched_nms(boxes[s, ids], scores[s, ids], cls[s, ids].astype(np.int64), thr)][:topk]
+        assert cnt[s] == len(k), f"segment {s}: kept {cnt[s]} vs {len(k)}"
+        assert keep[s, : cnt[s]].tolist() == k.tolist(), f"segment {s}: kept index list differs"
+        assert (keep[s, cnt[s]:] == -1).all()
+
+
+def test_nms_no_class_no_cand(ops):
+    boxes, scores, _, _, seg_len = _nms_inputs(3, 2, 300, [300, 150], 1)
+    keep, cnt = ops.nms_topk(torch.from_numpy(boxes).to(DEV), torch.from_numpy(scores).to(DEV), None, None, 2, 300,
+                             torch.from_numpy(seg_len).to(DEV), 0.4, 25)
+    for s in range(2):
+        k = CO.nms(boxes[s, : seg_len[s]], scores[s, : seg_len[s]], 0.4)[:25]
+        assert keep[s, : int(cnt[s])].cpu().tolist() == k.tolist()
+
+
+def test_gather_and_l2norm(ops):
+    gg = g(41)
+    src = torch.randn(2 * 50, 1024, generator=gg)
+    keep = torch.tensor([[3, 49, 0, -1], [7, 7, 1, 2]], dtype=torch.int32)
+    cnt = torch.tensor([3, 2], dtype=torch.int32)
+    out = ops.gather_rows(src.to(DEV), 50, keep.to(DEV), cnt.to(DEV)).cpu()
+    assert torch.equal(out[0, :3], src[[3, 49, 0]]) and torch.equal(out[1, :2], src[[57, 57]])
+    assert float(out[0, 3].abs().max()) == 0 and float(out[1, 2:].abs().max()) == 0
+    x = torch.randn(20, 256, generator=gg)
+    x[3] = 0
+    assert_close(ops.l2_normalize_rows(x.to(DEV)), F.normalize(x), rtol=1e-6, atol=1e-7, name="l2norm")
+
+
+def test_pln_tail(ops):
+    gg = g(42)
+    p = O.make_head_params(2)
+    feats = F.relu(torch.randn(1500, 1024, generator=gg))
+    cls_ref, rec_ref, md_ref, emb = O.pln_inference(feats, p, 0.23, 80, 20)
+    protos = ops.l2_normalize_rows(p["roi_heads.dml.representatives"].to(DEV))
+    rv = torch.tensor([1000, 400], dtype=torch.int32)
+    emb_pad = torch.zeros(2000, 256)
+    emb_pad[:1000] = emb[:1000]
+    emb_pad[1000:1400] = emb[1000:1400]
+    pc, md = ops.pln_tail(emb_pad.to(DEV), protos, 20, 1, 0.23, 80, rows_valid=rv.to(DEV), seg_rows=1000)
+    pc, md = pc.cpu(), md.cpu()
+    valid = torch.cat((torch.arange(1000), torch.arange(1000, 1400)))
+    assert_close(md[valid], md_ref[:1400], rtol=1e-5, atol=1e-6, name="min_dist")
+    # classes must agree wherever the decision is not within rounding of a tie / the threshold
+    rep = F.normalize(p["roi_heads.dml.representatives"])
+    dist = 1.0 - F.normalize(emb[:1400]) @ rep.t()
+    top2 = dist.topk(2, dim=1, largest=False)[0]
+    safe = ((top2[:, 1] - top2[:, 0]) > 1e-5) & ((md_ref[:1400] - 0.23).abs() > 1e-5)
+    assert int(safe.sum()) > 1300
+    assert torch.equal(pc[valid][safe], cls_ref[:1400][safe])
+    assert bool((pc[1400:] == -1).all())
+    assert int((pc[valid] == 80).sum()) > 0 and int((pc[valid] != 80).sum()) > 0
+
+
+def test_pln_tail_known_answers(ops):
+    protos = torch.eye(20, 256)
+    f = torch.zeros(4, 256)
+    f[0, 7] = 5.0
+    f[1, 3] = 1.0
+    f[1, 4] = 1.0
+    f[2, 100] = 1.0
+    f[3, 5] = 1.0
+    f[3, 6] = 0.6
+    pc, md = ops.pln_tail(f.to(DEV), protos.to(DEV), 20, 1, 0.23, 80)
+    assert pc.cpu().tolist() == [7, 80, 80, 5]
+    pc2, _ = ops.pln_tail(f.to(DEV), protos.to(DEV), 20, 1, 0.5, 80)
+    assert pc2.cpu()[1].item() == 3  # tie between classes 3 and 4: lower index
+    cm = (torch.arange(20) * 3 + 1).to(torch.int64)
+    pc3, _ = ops.pln_tail(f.to(DEV), protos.to(DEV), 20, 1, 0.23, 1000, class_map=cm.to(DEV))
+    assert pc3.cpu().tolist() == [22, 1000, 1000, 16]
+
+
+def test_softmax_candidates_nms_assemble_vs_oracle(ops):
+    gg = g(43)
+    p = O.make_head_params(3)
+    n, seg = 2, 1000
+    cfg = dict(O.VOC_COCO_CFG)
+    results_ref, inputs = [], []
+    counts = [1000, 620]
+    det_boxes = torch.zeros(n, seg, 4)
+    det_scores = torch.zeros(n, seg)
+    pred_cls = torch.full((n, seg), -1, dtype=torch.int64)
+    logits = torch.zeros(n, seg, 21)
+    for i in range(n):
+        c = counts[i]
+        xy = torch.rand(c, 2, generator=gg) * torch.tensor([1000.0, 600.0])
+        b = torch.cat((xy, xy + torch.rand(c, 2, generator=gg) * 250 + 5), dim=1)
+        b = O.box_clip(b, (800, 1333))
+        s = torch.sort(torch.rand(c, generator=gg), descending=True)[0]
+        rec = torch.randn(c, 1024, generator=gg) * 2
+        cls = torch.where(torch.rand(c, generator=gg) > 0.4, torch.randint(0, 20, (c,), generator=gg), torch.tensor(80))
+        lg = F.linear(rec, p["roi_heads.softmaxcls.cls_score.weight"], p["roi_heads.softmaxcls.cls_score.bias"])
+        results_ref.append(O.softmax_classifier_inference(b, s, cls, rec, (800, 1333), p, cfg))
+        det_boxes[i, :c], det_scores[i, :c], pred_cls[i, :c], logits[i, :c] = b, s, cls, lg
+    cnt = torch.tensor(counts, dtype=torch.int32)
+    cands = ops.softmax_candidates(logits.view(-1, 21).to(DEV), 20, det_boxes.view(-1, 4).to(DEV), det_scores.view(-1).to(DEV),
+                                   pred_cls.view(-1).to(DEV), cnt.to(DEV), n, seg, 80, cfg["known_score_thresh"], cfg["unknown_score_thresh"])
+    kk, kc = ops.nms_topk(cands["k_boxes"], cands["k_scores"], cands["k_cls"], None, n, seg * 20, cands["k_count"], cfg["known_nms_thresh"],
+                          cfg["known_topk"])
+    uk, uc = ops.nms_topk(cands["u_boxes"], cands["u_scores"], None, None, n, seg, cands["u_count"], cfg["unknown_nms_thresh"],
+                          cfg["unknown_topk"])
+    ob, osc, ocl, on = ops.assemble_detections(cands, kk, kc, uk, uc, n, 80)
+    for i in range(n):
+        rb, rs, rc = results_ref[i]
+        c = int(on[i])
+        assert c == len(rb), f"image {i}: {c} detections vs {len(rb)}"
+        assert torch.equal(ocl[i, :c].cpu(), rc)
+        assert_close(osc[i, :c], rs, rtol=1e-5, atol=1e-7, name="scores")
+        assert torch.equal(ob[i, :c].cpu(), rb)
+        nu = int((rc == 80).sum())
+        assert bool((rc[:nu] == 80).all()) and bool((rc[nu:] != 80).all())  # [unknown..., known...]
