@@ -369,7 +369,11 @@ def test_gather_and_l2norm(ops):
 def test_pln_tail(ops):
     gg = g(42)
     p = O.make_head_params(2)
-    feats = F.relu(torch.randn(1500, 1024, generator=gg))
+    p["roi_heads.dml.encoder.weight"] = torch.eye(256, 1024)  # emb = feats[:, :256]: lets the test place rows near prototypes
+    feats = torch.randn(1500, 1024, generator=gg)
+    near = torch.arange(0, 1500, 2)
+    feats[near, :256] = p["roi_heads.dml.representatives"][near % 20] * 1.7 + torch.randn(len(near), 256, generator=gg) * \
+        torch.linspace(0.05, 1.2, len(near)).unsqueeze(1)
     cls_ref, rec_ref, md_ref, emb = O.pln_inference(feats, p, 0.23, 80, 20)
     protos = ops.l2_normalize_rows(p["roi_heads.dml.representatives"].to(DEV))
     rv = torch.tensor([1000, 400], dtype=torch.int32)
