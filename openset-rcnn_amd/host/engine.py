@@ -1,0 +1,223 @@
+"""Batched inference engine for the Openset R-CNN hot path on one MI355X.
+
+Everything the reference does in per-image / per-level Python loops with host syncs runs here as
+one stream of HIP launches over all N images with on-device counts; the only device->host transfer is the
+final (N, 100) detection block. Mirrors, stage by stage:
+
+  GeneralizedRCNN.inference [d2]                         -> OpensetRCNNEngine.forward
+    preprocess_image + ImageList.from_tensors [d2]       -> ops.preprocess
+    build_resnet_fpn_backbone [d2]                       -> _backbone (stem view conv, bottlenecks, FPN, p6)
+    ClsFreeRPN.forward (classification_free_rpn.py:493)  -> _rpn
+    OpensetROIHeads._forward_box (osrcnn_roi_heads.py:282) -> _roi_heads
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from .weights import R50_BLOCKS, pack_conv_weight, pack_fc1_weight, pack_stem_weight
+
+DEFAULT_CFG = dict(
+    pixel_mean=(103.53, 116.28, 123.675), pixel_std=(1.0, 1.0, 1.0), size_divisibility=32,
+    fpn_strides=(4, 8, 16, 32, 64), anchor_sizes=(32, 64, 128, 256, 512),
+    pre_nms_topk_test=1000, min_box_size=0.0,
+    pooler_resolution=7, pooler_scales=(0.25, 0.125, 0.0625, 0.03125), canonical_level=4, canonical_size=224,
+    bbox_reg_weights=(10.0, 10.0, 5.0, 5.0), mean_type="geometric",
+    obj_score_thresh=0.05, nms_thresh_test=1.0, detections_per_image=1000,
+    known_score_thresh=0.05, known_nms_thresh=0.5, known_topk=50,
+    unknown_score_thresh=0.0, unknown_nms_thresh=0.5, unknown_topk=50,
+    num_classes=81, num_known=20, reps_per_class=1, unknown_id=80, unk_thr=0.23,
+)
+
+
+class OpensetRCNNEngine:
+    def __init__(self, params: Dict[str, torch.Tensor], cfg: Optional[dict] = None, dtype: torch.dtype = torch.float16,
+                 device: str = "cuda", class_map: Optional[torch.Tensor] = None):
+        self.cfg = dict(DEFAULT_CFG)
+        if cfg:
+            self.cfg.update(cfg)
+        self.dtype = dtype
+        self.device = torch.device(device)
+        dev = self.device
+        w: Dict[str, torch.Tensor] = {}
+        for k, v in params.items():
+            if not k.endswith(".weight") or v.dim() != 4 or k.startswith("proposal_generator.rpn_head.anchor") or \
+                    k.startswith("proposal_generator.rpn_head.centerness"):
+                continue
+            pre = k[: -len(".weight")]
+            if pre == "backbone.bottom_up.stem.conv1":
+                w[pre + ".w"] = pack_stem_weight(v, dtype).to(dev)
+            else:
+                w[pre + ".w"] = pack_conv_weight(v, dtype).to(dev)
+            w[pre + ".b"] = params[pre + ".bias"].float().contiguous().to(dev)
+        c = self.cfg
+        self.fc1_w = pack_fc1_weight(params["roi_heads.box_head.fc1.weight"], 256, c["pooler_resolution"], dtype).to(dev)
+        self.fc1_b = params["roi_heads.box_head.fc1.bias"].float().to(dev)
+        self.fc2_w = params["roi_heads.box_head.fc2.weight"].to(dtype).contiguous().to(dev)
+        self.fc2_b = params["roi_heads.box_head.fc2.bias"].float().to(dev)
+        f32 = lambda k: params[k].float().contiguous().to(dev)  # noqa: E731
+        self.rpn_wd = f32("proposal_generator.rpn_head.anchor_deltas.weight").view(-1, 256)
+        self.rpn_bd = f32("proposal_generator.rpn_head.anchor_deltas.bias")
+        self.rpn_wc = f32("proposal_generator.rpn_head.centerness.weight").view(1, 256)
+        self.rpn_bc = f32("proposal_generator.rpn_head.centerness.bias")
+        self.pred_w = torch.cat((f32("roi_heads.box_predictor.bbox_pred.weight"), f32("roi_heads.box_predictor.iou_pred.weight"))).contiguous()
+        self.pred_b = torch.cat((f32("roi_heads.box_predictor.bbox_pred.bias"), f32("roi_heads.box_predictor.iou_pred.bias"))).contiguous()
+        self.enc_w, self.enc_b = f32("roi_heads.dml.encoder.weight"), f32("roi_heads.dml.encoder.bias")
+        self.dec_w, self.dec_b = f32("roi_heads.dml.decoder.weight"), f32("roi_heads.dml.decoder.bias")
+        self.protos = ops.l2_normalize_rows(f32("roi_heads.dml.representatives"))  # prototype_learning_network.py:199
+        self.cls_w, self.cls_b = f32("roi_heads.softmaxcls.cls_score.weight"), f32("roi_heads.softmaxcls.cls_score.bias")
+        self.class_map = None if class_map is None else class_map.to(torch.int64).to(dev)
+        self.w = w
+        sizes = c["anchor_sizes"]
+        self.cell_anchors = torch.tensor([[[-s / 2.0, -s / 2.0, s / 2.0, s / 2.0]] for s in sizes], dtype=torch.float32, device=dev)
+        self._lv_cache = {}
+        self.profile = None  # set to a list to collect (name, algorithmic flops, start event, end event) per MFMA launch
+
+    # ---- backbone -------------------------------------------------------------------------------------------
+    def _conv(self, x, name, stride=1, pad=0, relu=False, residual=None, res_mode=0, out=None, out_dtype=None):
+        w = self.w[name + ".w"]
+        if self.profile is None:
+            return ops.conv2d(x, w, self.w[name + ".b"], stride, pad, relu, residual, res_mode, out_dtype, out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = ops.conv2d(x, w, self.w[name + ".b"], stride, pad, relu, residual, res_mode, out_dtype, out)
+        e1.record()
+        rows = y.numel() // w.shape[0]
+        self.profile.append((name, 2.0 * rows * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3], e0, e1))
+        return y
+
+    def _linear(self, x, w, b, relu, out_dtype=None, name="fc"):
+        if self.profile is None:
+            return ops.linear(x, w, b, relu=relu, out_dtype=out_dtype)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = ops.linear(x, w, b, relu=relu, out_dtype=out_dtype)
+        e1.record()
+        self.profile.append((name, 2.0 * x.shape[0] * w.shape[0] * w.shape[1], e0, e1))
+        return y
+
+    def _backbone(self, images: torch.Tensor, hp: int, wp: int, keep: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+        c = self.cfg
+        xpad = ops.preprocess(images, hp, wp, c["pixel_mean"], c["pixel_std"], self.dtype)
+        if self.profile is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        x = ops.stem_conv(xpad, self.w["backbone.bottom_up.stem.conv1.w"], self.w["backbone.bottom_up.stem.conv1.b"], hp, wp, relu=True)
+        if self.profile is not None:
+            e1.record()
+            self.profile.append(("backbone.bottom_up.stem.conv1", 2.0 * x.numel() * 147, e0, e1))  # 7*7*3 real taps
+        if keep is not None:
+            keep["stem"] = x
+        x = ops.maxpool3x3s2(x)
+        feats = {}
+        for si, nb in enumerate(R50_BLOCKS):
+            for b in range(nb):
+                pre = f"backbone.bottom_up.res{si + 2}.{b}"
+                stride = 2 if (b == 0 and si > 0) else 1  # MSRA: stride in the first 1x1
+                sc = self._conv(x, pre + ".shortcut", stride) if b == 0 else x
+                o = self._conv(x, pre + ".conv1", stride, relu=True)
+                o = self._conv(o, pre + ".conv2", 1, 1, relu=True)
+                x = self._conv(o, pre + ".conv3", relu=True, residual=sc, res_mode=1)
+            feats[f"res{si + 2}"] = x
+        out = {}
+        prev = self._conv(feats["res5"], "backbone.fpn_lateral5")
+        out["p5"] = self._conv(prev, "backbone.fpn_output5", 1, 1)
+        for lvl in (4, 3, 2):
+            prev = self._conv(feats[f"res{lvl}"], f"backbone.fpn_lateral{lvl}", residual=prev, res_mode=2)
+            out[f"p{lvl}"] = self._conv(prev, f"backbone.fpn_output{lvl}", 1, 1)
+        out["p6"] = ops.subsample2(out["p5"])
+        if keep is not None:
+            keep.update(feats)
+        return out
+
+    # ---- CF-RPN ---------------------------------------------------------------------------------------------
+    def _levels(self, shapes, n):
+        key = (tuple(shapes), n)
+        if key not in self._lv_cache:
+            self._lv_cache[key] = ops.make_rpn_levels(shapes, self.cfg["fpn_strides"], n, 1)
+        return self._lv_cache[key]
+
+    def _rpn(self, feats: Dict[str, torch.Tensor], image_hw: torch.Tensor, keep: Optional[dict] = None):
+        fl = [feats[k] for k in ("p2", "p3", "p4", "p5", "p6")]
+        n = fl[0].shape[0]
+        shapes = [(f.shape[1], f.shape[2]) for f in fl]
+        rows = [n * h * w for h, w in shapes]
+        t_all = torch.empty((sum(rows), 256), dtype=self.dtype, device=self.device)
+        off = 0
+        for f, r in zip(fl, rows):
+            self._conv(f, "proposal_generator.rpn_head.conv", 1, 1, relu=True, out=t_all[off:off + r])
+            off += r
+        deltas, ctr = ops.cfrpn_head_tail(t_all, self.rpn_wd, self.rpn_bd, self.rpn_wc, self.rpn_bc)
+        sel = ops.rpn_select(self._levels(shapes, n), self.cell_anchors, ctr, deltas, n, image_hw, self.cfg["pre_nms_topk_test"],
+                             self.cfg["min_box_size"])
+        if keep is not None:
+            keep.update(rpn_t=t_all, rpn_deltas=deltas, rpn_ctr=ctr, rpn_shapes=shapes)
+        return sel
+
+    # ---- RoI heads ------------------------------------------------------------------------------------------
+    def _roi_heads(self, feats, sel, image_hw, keep: Optional[dict] = None):
+        c = self.cfg
+        n, cap = sel["boxes"].shape[0], sel["cap"]
+        boxes = sel["boxes"].view(-1, 4)
+        pooled = ops.roi_align([feats[k] for k in ("p2", "p3", "p4", "p5")], c["pooler_scales"], boxes, sel["batch_idx"],
+                               c["pooler_resolution"], self.dtype, c["canonical_level"], c["canonical_size"], 2)
+        m = pooled.shape[0]
+        h1 = self._linear(pooled.view(m, -1), self.fc1_w, self.fc1_b, True, name="roi_heads.box_head.fc1")
+        box_feats = self._linear(h1, self.fc2_w, self.fc2_b, True, torch.float32, name="roi_heads.box_head.fc2")
+        pt = ops.box_predictor_tail(box_feats, self.pred_w, self.pred_b, boxes, sel["scores"].view(-1), sel["batch_idx"], image_hw,
+                                    c["bbox_reg_weights"], 0 if c["mean_type"] == "geometric" else 1, c["obj_score_thresh"])
+        topk1 = c["detections_per_image"]
+        keep1, cnt1 = ops.nms_topk(pt["boxes"], pt["score"], None, pt["cand"], n, cap, sel["counts"], c["nms_thresh_test"], topk1)
+        det_boxes = ops.gather_rows(pt["boxes"], cap, keep1, cnt1)
+        det_scores = ops.gather_rows(pt["score"], cap, keep1, cnt1)
+        det_feats = ops.gather_rows(box_feats, cap, keep1, cnt1)
+        emb = ops.gemm_f32(det_feats.view(n * topk1, -1), self.enc_w, self.enc_b)
+        rec = ops.gemm_f32(emb, self.dec_w, self.dec_b)
+        pcls, mind = ops.pln_tail(emb, self.protos, c["num_known"], c["reps_per_class"], c["unk_thr"], c["unknown_id"], self.class_map,
+                                  cnt1, topk1)
+        logits = ops.gemm_f32(rec, self.cls_w, self.cls_b)
+        # class_map (GraspNet) remaps known ids at the very end; the known/unknown split uses the un-mapped unknown id
+        cands = ops.softmax_candidates(logits, c["num_known"], det_boxes.view(-1, 4), det_scores.view(-1), pcls, cnt1, n, topk1,
+                                       c["unknown_id"], c["known_score_thresh"], c["unknown_score_thresh"])
+        kk, kc = ops.nms_topk(cands["k_boxes"], cands["k_scores"], cands["k_cls"], None, n, topk1 * c["num_known"], cands["k_count"],
+                              c["known_nms_thresh"], c["known_topk"])
+        uk, uc = ops.nms_topk(cands["u_boxes"], cands["u_scores"], None, None, n, topk1, cands["u_count"], c["unknown_nms_thresh"],
+                              c["unknown_topk"])
+        ob, osc, ocl, on = ops.assemble_detections(cands, kk, kc, uk, uc, n, c["unknown_id"], self.class_map)
+        if keep is not None:
+            keep.update(pooled=pooled, h1=h1, box_feats=box_feats, pred=pt, keep1=keep1, cnt1=cnt1, det_boxes=det_boxes,
+                        det_scores=det_scores, det_feats=det_feats, emb=emb, rec=rec, pln_class=pcls, min_dist=mind, logits=logits,
+                        cands=cands, k_keep=kk, k_keep_count=kc, u_keep=uk, u_keep_count=uc)
+        return ob, osc, ocl, on
+
+    # ---- whole path -----------------------------------------------------------------------------------------
+    def forward(self, images: torch.Tensor, image_sizes: Optional[Sequence[Tuple[int, int]]] = None, keep: Optional[dict] = None):
+        """images: (n,3,h,w) uint8 or float32 BGR on the GPU (one common size; ragged batches are padded by the
+        caller). Returns padded (boxes (n,100,4), scores, classes int64, counts) on the GPU."""
+        n, _, h, w = images.shape
+        d = self.cfg["size_divisibility"]
+        hp, wp = (h + d - 1) // d * d, (w + d - 1) // d * d
+        if image_sizes is None:
+            image_sizes = [(h, w)] * n
+        image_hw = torch.tensor(image_sizes, dtype=torch.int32).to(self.device, non_blocking=True)
+        return self.forward_device(images, image_hw, hp, wp, keep)
+
+    def forward_device(self, images, image_hw, hp, wp, keep=None):
+        feats = self._backbone(images, hp, wp, keep)
+        sel = self._rpn(feats, image_hw, keep)
+        if keep is not None:
+            keep.update(feats=feats, sel=sel)
+        return self._roi_heads(feats, sel, image_hw, keep)
+
+    @staticmethod
+    def to_instances(result, n: int) -> List[dict]:
+        """One D2H copy; list of {'pred_boxes','scores','pred_classes'} per image (the fields the evaluators read,
+        pascal_voc_evaluation.py:58-61)."""
+        ob, osc, ocl, on = [t.cpu() for t in result]
+        out = []
+        for i in range(n):
+            c = int(on[i])
+            out.append(dict(pred_boxes=ob[i, :c], scores=osc[i, :c], pred_classes=ocl[i, :c]))
+        return out

@@ -1,0 +1,102 @@
+"""Parameter handling for the HIP path: detectron2-compatible state-dict names (checkpoint row),
+FrozenBatchNorm folding, and the one-time repacking of weights into the layouts the kernels read.
+
+No checkpoint is reachable offline, so ``random_params`` builds a seeded synthetic parameter set with the
+reference's parameter names and shapes (He-style init scaled so that activations stay inside fp16 range)."""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+
+R50_BLOCKS = (3, 4, 6, 3)
+R50_MID = (64, 128, 256, 512)
+
+
+def fold_frozen_bn(state: Dict[str, torch.Tensor], eps: float = 1e-5) -> Dict[str, torch.Tensor]:
+    """[d2] FrozenBatchNorm2d (y = x*w*rsqrt(var+eps) + (b - mean*w*rsqrt(var+eps))) folded into the preceding
+    bias-free conv: '<conv>.norm.{weight,bias,running_mean,running_var}' keys are consumed and '<conv>.bias' produced."""
+    out = dict(state)
+    for k in list(state.keys()):
+        if k.endswith(".norm.weight"):
+            pre = k[: -len(".norm.weight")]
+            w, b = state[pre + ".norm.weight"], state[pre + ".norm.bias"]
+            mean, var = state[pre + ".norm.running_mean"], state[pre + ".norm.running_var"]
+            scale = w * (var + eps).rsqrt()
+            out[pre + ".weight"] = state[pre + ".weight"] * scale.view(-1, 1, 1, 1)
+            out[pre + ".bias"] = b - mean * scale
+            for s in ("weight", "bias", "running_mean", "running_var"):
+                out.pop(pre + ".norm." + s, None)
+    return out
+
+
+def random_params(seed: int = 0, num_known: int = 20, fc_dim: int = 1024, emd: int = 256, res_gain: float = 0.5,
+                  spread: bool = True) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic parameters (already BN-folded) for R50-FPN + CF-RPN head + Openset RoI heads."""
+    g = torch.Generator().manual_seed(seed)
+    p: Dict[str, torch.Tensor] = {}
+
+    def conv(name, cout, cin, k, gain=1.0, bias_std=0.05):
+        std = gain * math.sqrt(2.0 / (cout * k * k))
+        p[name + ".weight"] = torch.randn(cout, cin, k, k, generator=g) * std
+        p[name + ".bias"] = torch.randn(cout, generator=g) * bias_std
+
+    conv("backbone.bottom_up.stem.conv1", 64, 3, 7, gain=0.02)
+    cin = 64
+    for si, (nb, mid) in enumerate(zip(R50_BLOCKS, R50_MID)):
+        cout = mid * 4
+        for b in range(nb):
+            pre = f"backbone.bottom_up.res{si + 2}.{b}"
+            if b == 0:
+                conv(pre + ".shortcut", cout, cin, 1, gain=0.7)
+            conv(pre + ".conv1", mid, cin, 1)
+            conv(pre + ".conv2", mid, mid, 3)
+            conv(pre + ".conv3", cout, mid, 1, gain=res_gain)
+            cin = cout
+    for lvl, c in zip((2, 3, 4, 5), (256, 512, 1024, 2048)):
+        conv(f"backbone.fpn_lateral{lvl}", 256, c, 1, gain=0.7)
+        conv(f"backbone.fpn_output{lvl}", 256, 256, 3, gain=0.7)
+
+    g2 = torch.Generator().manual_seed(seed + 1000)
+    m = 30.0 if spread else 1.0
+
+    def lin(name, o, i, std, bstd=0.0):
+        p[name + ".weight"] = torch.randn(o, i, generator=g2) * std
+        p[name + ".bias"] = torch.randn(o, generator=g2) * bstd if bstd else torch.zeros(o)
+
+    in_dim = 256 * 49
+    p["proposal_generator.rpn_head.conv.weight"] = torch.randn(256, 256, 3, 3, generator=g2) * 0.01 * (2 if spread else 1)
+    p["proposal_generator.rpn_head.conv.bias"] = torch.zeros(256)
+    p["proposal_generator.rpn_head.anchor_deltas.weight"] = torch.randn(4, 256, 1, 1, generator=g2) * 0.01 * m * 3
+    p["proposal_generator.rpn_head.anchor_deltas.bias"] = torch.full((4,), 0.5 if spread else 0.0)
+    p["proposal_generator.rpn_head.centerness.weight"] = torch.randn(1, 256, 1, 1, generator=g2) * 0.01 * m * 10
+    p["proposal_generator.rpn_head.centerness.bias"] = torch.zeros(1)
+    lin("roi_heads.box_head.fc1", fc_dim, in_dim, math.sqrt(2.0 / in_dim), 0.02)
+    lin("roi_heads.box_head.fc2", fc_dim, fc_dim, math.sqrt(2.0 / fc_dim), 0.02)
+    lin("roi_heads.box_predictor.bbox_pred", 4, fc_dim, 0.001 * m)
+    lin("roi_heads.box_predictor.iou_pred", 1, fc_dim, 0.01 * (m / 3))
+    lin("roi_heads.dml.encoder", emd, fc_dim, 0.01 * (m / 6))
+    lin("roi_heads.dml.decoder", fc_dim, emd, 0.01 * (m / 6))
+    p["roi_heads.dml.representatives"] = torch.randn(num_known, emd, generator=g2)
+    lin("roi_heads.softmaxcls.cls_score", num_known + 1, fc_dim, 0.01 * (m / 3))
+    return p
+
+
+def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """(cout,cin,kh,kw) -> (cout,kh,kw,cin): the GEMM K axis becomes contiguous per tap."""
+    return w.permute(0, 2, 3, 1).contiguous().to(dtype)
+
+
+def pack_stem_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """(64,3,7,7) -> stem view (64,7,1,32): K slice kh holds 8 taps x 4 channels, 8th tap / 4th channel zero."""
+    cout = w.shape[0]
+    v = torch.zeros(cout, 7, 8, 4, dtype=torch.float32)
+    v[:, :, :7, :3] = w.float().permute(0, 2, 3, 1)
+    return v.view(cout, 7, 1, 32).contiguous().to(dtype)
+
+
+def pack_fc1_weight(w: torch.Tensor, channels: int, pooled: int, dtype: torch.dtype) -> torch.Tensor:
+    """fc1 (out, c*p*p) with the reference's (c,ph,pw) flatten order -> (out, p*p*c) matching RoIAlign's (ph,pw,c) output."""
+    o = w.shape[0]
+    return w.view(o, channels, pooled, pooled).permute(0, 2, 3, 1).reshape(o, pooled * pooled * channels).contiguous().to(dtype)
