@@ -1,0 +1,183 @@
+"""End-to-end composition test of the inference engine on the GPU, checked stage by stage against the CPU oracle.
+
+fp16 storage between layers makes a whole-network comparison loose by construction, so each stage of
+the oracle is fed the ENGINE's own inputs to that stage: dense stages are then compared at the tolerance of one
+rounding of the stored result, and every index-producing stage (top-k selection, first-stage sort, PLN class,
+NMS keep lists, final detections) must match bit-exactly given identical inputs.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import c_binding as CO
+from oracle import osr_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def nchw(t):
+    return t.detach().cpu().float().permute(0, 3, 1, 2).contiguous()
+
+
+def rel_err(a, b):
+    a, b = a.detach().cpu().float(), b.detach().cpu().float()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-6))
+
+
+@pytest.fixture(scope="module")
+def run(osr):
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from openset_rcnn_amd.host.engine import OpensetRCNNEngine
+    from openset_rcnn_amd.host.weights import random_params
+    params = random_params(0)
+    eng = OpensetRCNNEngine(params, dtype=torch.float16, device=DEV)
+    g = torch.Generator().manual_seed(7)
+    images = torch.randint(0, 256, (2, 3, 250, 330), generator=g, dtype=torch.uint8)
+    sizes = [(250, 330), (240, 300)]  # second image: smaller valid area inside the same tensor
+    keep = {}
+    out = eng.forward(images.to(DEV), sizes, keep=keep)
+    torch.cuda.synchronize()
+    return dict(eng=eng, params=params, images=images, sizes=sizes, keep=keep, out=out)
+
+
+def q16(t):
+    return t.half().float()
+
+
+def test_backbone_wiring(run):
+    p = {k: (q16(v) if v.dim() == 4 else v) for k, v in run["params"].items()}
+    batch, _ = O.preprocess_images([im for im in run["images"]])
+    feats = O.resnet_fpn_forward(q16(batch), p, quant=q16)
+    for k in ("p2", "p3", "p4", "p5", "p6"):
+        e = nchw(run["keep"]["feats"][k])
+        assert e.shape == feats[k].shape
+        assert rel_err(e, feats[k]) < 3e-2, f"{k}: rel err {rel_err(e, feats[k])}"  # ~50 fp16-rounded layers deep
+    for k in ("res2", "res3", "res4", "res5"):
+        assert nchw(run["keep"][k]).shape[1] == {"res2": 256, "res3": 512, "res4": 1024, "res5": 2048}[k]
+
+
+def test_rpn_head_and_selection(run):
+    keep, p = run["keep"], run["params"]
+    feats = {k: nchw(v) for k, v in keep["feats"].items()}
+    n = 2
+    # dense part: oracle on the engine's pyramid (fp16 conv weights, fp32 everywhere else)
+    pq = dict(p)
+    pq["proposal_generator.rpn_head.conv.weight"] = q16(p["proposal_generator.rpn_head.conv.weight"])
+    ds, cs = [], []
+    for k in ("p2", "p3", "p4", "p5", "p6"):
+        d, c = O.cfrpn_head(feats[k], pq)
+        ds.append(d)
+        cs.append(c)
+    ds, cs = O.flatten_head_outputs(ds, cs)
+    d_ref = torch.cat([d.reshape(-1, 4) for d in ds])
+    c_ref = torch.cat([c.reshape(-1) for c in cs])
+    assert rel_err(keep["rpn_deltas"], d_ref) < 5e-3  # hidden state stored in fp16 before the normalise
+    assert float((keep["rpn_ctr"].cpu() - c_ref).abs().max()) < 2e-3
+    # index part: oracle selection on the engine's own deltas / centerness -> bit-exact
+    shapes = keep["rpn_shapes"]
+    anchors = O.anchor_grid(shapes)
+    ctr, dl, off = [], [], 0
+    for h, w in shapes:
+        ctr.append(keep["rpn_ctr"][off:off + n * h * w].cpu().view(n, h * w))
+        dl.append(keep["rpn_deltas"][off:off + n * h * w].cpu().view(n, h * w, 4))
+        off += n * h * w
+    props = [O.ltrb_apply_deltas(d.reshape(-1, 4), a.unsqueeze(0).expand(n, -1, -1).reshape(-1, 4)).view(n, -1, 4) for d, a in zip(dl, anchors)]
+    ref = O.find_top_rpn_proposals(props, ctr, run["sizes"], 1000)
+    sel = keep["sel"]
+    for i, (rb, rs, ri) in enumerate(ref):
+        c = int(sel["counts"][i])
+        assert c == len(rb)
+        assert torch.equal(sel["src_index"][i, :c].cpu().long(), ri)
+        assert torch.equal(sel["boxes"][i, :c].cpu(), rb)
+        assert torch.equal(sel["scores"][i, :c].cpu(), rs)
+
+
+def test_roi_heads_stagewise(run):
+    keep, p, eng = run["keep"], run["params"], run["eng"]
+    sel = keep["sel"]
+    n, cap = 2, sel["cap"]
+    counts = [int(c) for c in sel["counts"].cpu()]
+    feats = [nchw(keep["feats"][k]) for k in ("p2", "p3", "p4", "p5")]
+    boxes = [sel["boxes"][i, :counts[i]].cpu() for i in range(n)]
+    # RoIAlign (fp16 out) vs the C oracle on the engine's pyramid and proposals
+    pooled_ref = O.roi_pooler_ref(feats, boxes, roi_align_fn=CO.roi_align)
+    pooled = keep["pooled"].view(n, cap, 7, 7, 256)
+    pe = torch.cat([pooled[i, :counts[i]] for i in range(n)]).cpu().float().permute(0, 3, 1, 2)
+    assert float((pe - pooled_ref).abs().max()) < 2e-3 * max(1.0, float(pooled_ref.abs().max()))
+    assert float(pooled[0, counts[0]:].abs().max()) == 0.0  # padded rows are zero
+    # box head on the engine's pooled features (fp16 operands, fp32 accumulate)
+    pq = dict(p)
+    pq["roi_heads.box_head.fc1.weight"] = q16(p["roi_heads.box_head.fc1.weight"])
+    pq["roi_heads.box_head.fc2.weight"] = q16(p["roi_heads.box_head.fc2.weight"])
+    x = torch.flatten(pe, 1)
+    h1 = q16(F.relu(F.linear(x, pq["roi_heads.box_head.fc1.weight"], p["roi_heads.box_head.fc1.bias"])))
+    bf_ref = F.relu(F.linear(h1, pq["roi_heads.box_head.fc2.weight"], p["roi_heads.box_head.fc2.bias"]))
+    bf = keep["box_feats"].view(n, cap, -1)
+    bfe = torch.cat([bf[i, :counts[i]] for i in range(n)]).cpu()
+    assert rel_err(bfe, bf_ref) < 5e-3
+    # predictor + first-stage filtering on the engine's box features
+    d_ref, iou_ref = O.box_predictor(bfe, p)
+    pd = keep["pred"]["pred_deltas"].view(n, cap, 4)
+    assert rel_err(torch.cat([pd[i, :counts[i]] for i in range(n)]), d_ref) < 1e-4
+    score = keep["pred"]["score"].view(n, cap).cpu()
+    cand = keep["pred"]["cand"].view(n, cap).cpu()
+    keep1, cnt1 = keep["keep1"].cpu(), keep["cnt1"].cpu()
+    for i in range(n):
+        ids = torch.nonzero(cand[i, :counts[i]]).squeeze(1).numpy()
+        order = ids[CO.argsort_desc(score[i, ids].numpy())][:1000]
+        assert int(cnt1[i]) == len(order)
+        assert keep1[i, :len(order)].tolist() == order.tolist()  # first-stage "NMS" (thr 1.0) == stable sort + top-1000
+    # PLN on the engine's gathered features
+    det_feats = keep["det_feats"].cpu()
+    for i in range(n):
+        c = int(cnt1[i])
+        cls, rec, md, emb = O.pln_inference(det_feats[i, :c], p, eng.cfg["unk_thr"], 80, 20)
+        assert rel_err(keep["emb"].view(n, 1000, -1)[i, :c], emb) < 1e-4
+        assert rel_err(keep["rec"].view(n, 1000, -1)[i, :c], rec) < 1e-4
+        rep = F.normalize(p["roi_heads.dml.representatives"])
+        dist = 1.0 - F.normalize(emb) @ rep.t()
+        top2 = dist.topk(2, dim=1, largest=False)[0]
+        safe = ((top2[:, 1] - top2[:, 0]) > 1e-5) & ((md - eng.cfg["unk_thr"]).abs() > 1e-5)
+        assert torch.equal(keep["pln_class"].view(n, 1000)[i, :c].cpu()[safe], cls[safe])
+
+
+def test_final_detections_given_engine_logits(run):
+    """Softmax classifier + both NMS passes + assembly, oracle fed the engine's det boxes/scores/classes/logits."""
+    keep, eng = run["keep"], run["eng"]
+    n = 2
+    cnt1 = keep["cnt1"].cpu()
+    ob, osc, ocl, on = [t.cpu() for t in run["out"]]
+    cfg = dict(O.VOC_COCO_CFG)
+    for i in range(n):
+        c = int(cnt1[i])
+        b = keep["det_boxes"][i, :c].cpu()
+        s = keep["det_scores"][i, :c, 0].cpu()
+        cls = keep["pln_class"].view(n, 1000)[i, :c].cpu()
+        lg = keep["logits"].view(n, 1000, 21)[i, :c].cpu()
+        known = cls != 80
+        probs = F.softmax(lg[known], dim=-1)
+        kb, ks, kc = O.softmax_known_inference(b[known], probs, run["sizes"][i], cfg["known_score_thresh"], cfg["known_nms_thresh"], cfg["known_topk"])
+        if not bool(known.all()):
+            ub, us, uc = O.softmax_unknown_inference(b[~known], s[~known], run["sizes"][i], cfg["unknown_score_thresh"],
+                                                     cfg["unknown_nms_thresh"], cfg["unknown_topk"], 80)
+            rb, rs, rc = torch.cat((ub, kb)), torch.cat((us, ks)), torch.cat((uc, kc))
+        else:
+            rb, rs, rc = kb, ks, kc
+        m = int(on[i])
+        assert m == len(rb), f"image {i}: {m} detections vs oracle {len(rb)}"
+        assert torch.equal(ocl[i, :m], rc)
+        assert torch.equal(ob[i, :m], rb)
+        assert float((osc[i, :m] - rs).abs().max()) < 1e-6
+    insts = eng.to_instances(run["out"], n)
+    assert len(insts) == n and set(insts[0]) == {"pred_boxes", "scores", "pred_classes"}
+
+
+def test_engine_is_deterministic(run):
+    eng = run["eng"]
+    a = eng.forward(run["images"].to(DEV), run["sizes"])
+    b = eng.forward(run["images"].to(DEV), run["sizes"])
+    for x, y, z in zip(a, b, run["out"]):
+        assert torch.equal(x, y) and torch.equal(x, z)
