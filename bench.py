@@ -32,13 +32,30 @@ METRIC = "images/sec at 3x800x1333, R50-FPN, 1/2/4/8 MI355X; mAP_k vs ref"
 MFMA_PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def host_cores() -> int:
+    """CPUs this process may actually use: min(online CPUs, affinity mask, cgroup v2 cpu.max quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(params, batch: int, iters: int):
     """The oracle (a port: the reference itself cannot run here) timed on the host cores."""
+    cores = host_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)  # the C oracle's OpenMP runtime reads it when the library loads
     from oracle import c_binding as CO
     from oracle import osr_oracle as O
     g = torch.Generator().manual_seed(0)
     images = [torch.randint(0, 256, (3, 800, 1333), generator=g, dtype=torch.uint8) for _ in range(batch)]
-    cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     with torch.no_grad():
         O.detector_inference(images[:1], params, params, roi_align_fn=CO.roi_align)  # warm-up (1 image)

@@ -53,27 +53,33 @@ class OpensetRCNNEngine:
                 w[pre + ".w"] = pack_conv_weight(v, dtype).to(dev)
             w[pre + ".b"] = params[pre + ".bias"].float().contiguous().to(dev)
         c = self.cfg
+        f32 = lambda k: params[k].float().contiguous().to(dev)  # noqa: E731
+        self.has_backbone = "backbone.bottom_up.stem.conv1.weight" in params
+        self.has_rpn = "proposal_generator.rpn_head.conv.weight" in params
+        self.has_roi = "roi_heads.box_head.fc1.weight" in params
+        self.w = w
+        self.class_map = None if class_map is None else class_map.to(torch.int64).to(dev)
+        self._lv_cache = {}
+        self.profile = None  # set to a list to collect (name, algorithmic flops, start event, end event) per MFMA launch
+        if self.has_rpn:
+            self.rpn_wd = f32("proposal_generator.rpn_head.anchor_deltas.weight").view(-1, 256)
+            self.rpn_bd = f32("proposal_generator.rpn_head.anchor_deltas.bias")
+            self.rpn_wc = f32("proposal_generator.rpn_head.centerness.weight").view(1, 256)
+            self.rpn_bc = f32("proposal_generator.rpn_head.centerness.bias")
+            sizes = c["anchor_sizes"]
+            self.cell_anchors = torch.tensor([[[-s / 2.0, -s / 2.0, s / 2.0, s / 2.0]] for s in sizes], dtype=torch.float32, device=dev)
+        if not self.has_roi:
+            return
         self.fc1_w = pack_fc1_weight(params["roi_heads.box_head.fc1.weight"], 256, c["pooler_resolution"], dtype).to(dev)
         self.fc1_b = params["roi_heads.box_head.fc1.bias"].float().to(dev)
         self.fc2_w = params["roi_heads.box_head.fc2.weight"].to(dtype).contiguous().to(dev)
         self.fc2_b = params["roi_heads.box_head.fc2.bias"].float().to(dev)
-        f32 = lambda k: params[k].float().contiguous().to(dev)  # noqa: E731
-        self.rpn_wd = f32("proposal_generator.rpn_head.anchor_deltas.weight").view(-1, 256)
-        self.rpn_bd = f32("proposal_generator.rpn_head.anchor_deltas.bias")
-        self.rpn_wc = f32("proposal_generator.rpn_head.centerness.weight").view(1, 256)
-        self.rpn_bc = f32("proposal_generator.rpn_head.centerness.bias")
         self.pred_w = torch.cat((f32("roi_heads.box_predictor.bbox_pred.weight"), f32("roi_heads.box_predictor.iou_pred.weight"))).contiguous()
         self.pred_b = torch.cat((f32("roi_heads.box_predictor.bbox_pred.bias"), f32("roi_heads.box_predictor.iou_pred.bias"))).contiguous()
         self.enc_w, self.enc_b = f32("roi_heads.dml.encoder.weight"), f32("roi_heads.dml.encoder.bias")
         self.dec_w, self.dec_b = f32("roi_heads.dml.decoder.weight"), f32("roi_heads.dml.decoder.bias")
         self.protos = ops.l2_normalize_rows(f32("roi_heads.dml.representatives"))  # prototype_learning_network.py:199
         self.cls_w, self.cls_b = f32("roi_heads.softmaxcls.cls_score.weight"), f32("roi_heads.softmaxcls.cls_score.bias")
-        self.class_map = None if class_map is None else class_map.to(torch.int64).to(dev)
-        self.w = w
-        sizes = c["anchor_sizes"]
-        self.cell_anchors = torch.tensor([[[-s / 2.0, -s / 2.0, s / 2.0, s / 2.0]] for s in sizes], dtype=torch.float32, device=dev)
-        self._lv_cache = {}
-        self.profile = None  # set to a list to collect (name, algorithmic flops, start event, end event) per MFMA launch
 
     # ---- backbone -------------------------------------------------------------------------------------------
     def _conv(self, x, name, stride=1, pad=0, relu=False, residual=None, res_mode=0, out=None, out_dtype=None):
@@ -98,9 +104,10 @@ class OpensetRCNNEngine:
         self.profile.append((name, 2.0 * x.shape[0] * w.shape[0] * w.shape[1], e0, e1))
         return y
 
-    def _backbone(self, images: torch.Tensor, hp: int, wp: int, keep: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+    def _backbone(self, images: torch.Tensor, hp: int, wp: int, keep: Optional[dict] = None, normalized: bool = False) -> Dict[str, torch.Tensor]:
         c = self.cfg
-        xpad = ops.preprocess(images, hp, wp, c["pixel_mean"], c["pixel_std"], self.dtype)
+        mean, std = ((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)) if normalized else (c["pixel_mean"], c["pixel_std"])
+        xpad = ops.preprocess(images, hp, wp, mean, std, self.dtype)
         if self.profile is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

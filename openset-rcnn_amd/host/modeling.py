@@ -1,0 +1,496 @@
+"""Host-side mirror of the reference's plug-in surface: the detectron2-style registries and the
+registered names the yaml files select --
+
+    META_ARCHITECTURE "GeneralizedRCNN", BACKBONE.NAME "build_resnet_fpn_backbone",
+    PROPOSAL_GENERATOR.NAME "ClsFreeRPN"  (classification_free_rpn.py:165), RPN.HEAD_NAME "ClsFreeRPNHead" (:50),
+    ROI_HEADS.NAME "OpensetROIHeads" (osrcnn_roi_heads.py:26), ROI_BOX_HEAD.NAME "FastRCNNConvFCHead"
+
+-- with the same constructor configuration keys, forward signatures, output field names and state-dict key names.
+The modules own fp32 parameters under detectron2's names (checkpoint compatible); their inference forwards run on
+the HIP library through `OpensetRCNNEngine` (no eager path). Training forwards are not built this round and raise.
+Feature maps cross these signatures as logical (N,C,H,W) tensors in channels_last memory (= the kernels' NHWC)."""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import ops
+from .config import CfgNode
+from .engine import OpensetRCNNEngine
+from .structures import Boxes, ImageList, Instances, ShapeSpec
+from .weights import R50_BLOCKS, R50_MID, fold_frozen_bn
+
+
+class Registry:
+    def __init__(self, name: str):
+        self._name = name
+        self._map: Dict[str, object] = {}
+
+    def register(self, obj=None):
+        if obj is None:
+            def deco(o):
+                self._do(o.__name__, o)
+                return o
+            return deco
+        self._do(obj.__name__, obj)
+        return obj
+
+    def _do(self, name, obj):
+        assert name not in self._map, f"'{name}' already registered in '{self._name}'"
+        self._map[name] = obj
+
+    def get(self, name: str):
+        if name not in self._map:
+            raise KeyError(f"No object named '{name}' found in '{self._name}' registry (have: {sorted(self._map)})")
+        return self._map[name]
+
+    def __contains__(self, name):
+        return name in self._map
+
+
+META_ARCH_REGISTRY = Registry("META_ARCH")
+BACKBONE_REGISTRY = Registry("BACKBONE")
+PROPOSAL_GENERATOR_REGISTRY = Registry("PROPOSAL_GENERATOR")
+RPN_HEAD_REGISTRY = Registry("RPN_HEAD")
+ROI_HEADS_REGISTRY = Registry("ROI_HEADS")
+ROI_BOX_HEAD_REGISTRY = Registry("ROI_BOX_HEAD")
+
+_TRAIN_MSG = ("the training forward (targets, losses, backward) of the HIP path is the next scope row (DESIGN.md section 7); "
+              "this build implements inference only")
+
+
+def _to_nhwc(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """Logical NCHW -> contiguous NHWC view/copy of the kernel dtype (free when already channels_last + dtype)."""
+    return x.to(dtype).permute(0, 2, 3, 1).contiguous()
+
+
+class _EngineOwner(nn.Module):
+    """Lazily packs this module's parameters (under canonical names) into an OpensetRCNNEngine."""
+    _prefix = ""
+
+    def __init__(self):
+        super().__init__()
+        self._eng: Optional[OpensetRCNNEngine] = None
+        self._shared: Optional[OpensetRCNNEngine] = None
+        self._eng_cfg: dict = {}
+        self._class_map = None
+        self.kernel_dtype = torch.float16
+
+    def engine(self) -> OpensetRCNNEngine:
+        if self._shared is not None:
+            return self._shared
+        if self._eng is None:
+            sd = {self._prefix + k: v.detach() for k, v in self.state_dict().items()}
+            dev = next(iter(sd.values())).device
+            if dev.type != "cuda":
+                raise ops.OsrError("the model must be on the GPU (model.to('cuda')): the HIP path has no CPU fallback")
+            sd = fold_frozen_bn({k: v.cpu() for k, v in sd.items()})
+            self._eng = OpensetRCNNEngine(sd, self._eng_cfg, self.kernel_dtype, str(dev), self._class_map)
+        return self._eng
+
+    def refresh(self):
+        self._eng = None
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.refresh()
+        return r
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# backbone
+# ---------------------------------------------------------------------------------------------------------------
+class FrozenBatchNorm2d(nn.Module):
+    def __init__(self, c: int, eps: float = 1e-5):
+        super().__init__()
+        self.eps = eps
+        self.register_buffer("weight", torch.ones(c))
+        self.register_buffer("bias", torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c) - eps)
+
+
+class _ConvBN(nn.Module):
+    def __init__(self, cin, cout, k, gain=1.0):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(cout, cin, k, k) * gain * math.sqrt(2.0 / (cout * k * k)))
+        self.norm = FrozenBatchNorm2d(cout)
+
+
+class _ConvBias(nn.Module):
+    def __init__(self, cin, cout, k, gain=1.0):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(cout, cin, k, k) * gain * math.sqrt(2.0 / (cout * k * k)))
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+
+class _Bottleneck(nn.Module):
+    def __init__(self, cin, mid, cout, first):
+        super().__init__()
+        if first:
+            self.shortcut = _ConvBN(cin, cout, 1, 0.7)
+        self.conv1 = _ConvBN(cin, mid, 1)
+        self.conv2 = _ConvBN(mid, mid, 3)
+        self.conv3 = _ConvBN(mid, cout, 1, 0.5)
+
+
+class _Stem(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = _ConvBN(3, 64, 7, 0.02)
+
+
+class _BottomUp(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.stem = _Stem()
+        cin = 64
+        for si, (nb, mid) in enumerate(zip(R50_BLOCKS, R50_MID)):
+            blocks = []
+            for b in range(nb):
+                blocks.append(_Bottleneck(cin, mid, mid * 4, b == 0))
+                cin = mid * 4
+            setattr(self, f"res{si + 2}", nn.Sequential(*blocks))
+
+
+class ResNetFPN(_EngineOwner):
+    """[d2] build_resnet_fpn_backbone for R-50 (Base-RCNN-FPN.yaml:3-8): parameters under backbone.bottom_up.* /
+    backbone.fpn_{lateral,output}{2..5}.*; forward(x) takes the normalised, padded (N,3,H,W) fp32 batch."""
+    _prefix = "backbone."
+
+    def __init__(self, cfg: CfgNode):
+        super().__init__()
+        assert cfg.MODEL.RESNETS.DEPTH == 50, "only R-50 is on the hot path (VOC-COCO / GraspNet yaml: DEPTH 50)"
+        assert cfg.MODEL.RESNETS.STRIDE_IN_1X1 and cfg.MODEL.RESNETS.NORM == "FrozenBN"
+        self.bottom_up = _BottomUp()
+        for lvl, c in zip((2, 3, 4, 5), (256, 512, 1024, 2048)):
+            setattr(self, f"fpn_lateral{lvl}", _ConvBias(c, 256, 1, 0.7))
+            setattr(self, f"fpn_output{lvl}", _ConvBias(256, 256, 3, 0.7))
+        self._out_features = ["p2", "p3", "p4", "p5", "p6"]
+        self.size_divisibility = 32
+
+    def output_shape(self) -> Dict[str, ShapeSpec]:
+        return {f"p{l}": ShapeSpec(channels=256, stride=2 ** l) for l in range(2, 7)}
+
+    def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        n, _, h, w = x.shape
+        assert h % 32 == 0 and w % 32 == 0, "pad the batch to a multiple of 32 (ImageList.from_tensors(..., 32))"
+        feats = self.engine()._backbone(x.float().contiguous(), h, w, normalized=True)
+        return {k: v.permute(0, 3, 1, 2) for k, v in feats.items()}  # logical NCHW, channels_last memory
+
+
+@BACKBONE_REGISTRY.register()
+def build_resnet_fpn_backbone(cfg: CfgNode, input_shape=None):
+    return ResNetFPN(cfg)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CF-RPN
+# ---------------------------------------------------------------------------------------------------------------
+class _Conv3x3ReLU(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, 3, 3))
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+
+@RPN_HEAD_REGISTRY.register()
+class ClsFreeRPNHead(_EngineOwner):
+    """classification_free_rpn.py:50-162. forward(features) -> (list[(N,A*4,Hi,Wi)], list[(N,A,Hi,Wi)] sigmoid-ed)."""
+    _prefix = "proposal_generator.rpn_head."
+
+    def __init__(self, cfg: CfgNode = None, input_shape: List[ShapeSpec] = None, *, in_channels: int = 256, num_anchors: int = 1,
+                 box_dim: int = 4):
+        super().__init__()
+        if cfg is not None:
+            in_channels = input_shape[0].channels
+            assert len(set(s.channels for s in input_shape)) == 1, "Each level must have the same channel!"
+            assert list(cfg.MODEL.RPN.CONV_DIMS) == [-1], "only the single-conv head is on the hot path"
+            num_anchors = len(cfg.MODEL.ANCHOR_GENERATOR.ASPECT_RATIOS[0]) * len(cfg.MODEL.ANCHOR_GENERATOR.SIZES[0])
+        assert in_channels == 256 and num_anchors == 1 and box_dim == 4, "HIP CF-RPN head: 256 channels, A=1 (VOC-COCO/GraspNet yaml)"
+        self.conv = _Conv3x3ReLU(in_channels, in_channels)
+        self.anchor_deltas = nn.Conv2d(in_channels, num_anchors * box_dim, kernel_size=1)
+        self.centerness = nn.Conv2d(in_channels, num_anchors, kernel_size=1)
+        for m in (self.conv, self.anchor_deltas, self.centerness):  # classification_free_rpn.py:105-108
+            nn.init.normal_(m.weight, std=0.01)
+            nn.init.constant_(m.bias, 0)
+
+    def forward(self, features: List[torch.Tensor]):
+        eng = self.engine()
+        deltas, ctrs = [], []
+        for x in features:
+            n, _, h, w = x.shape
+            t = eng._conv(_to_nhwc(x, eng.dtype), "proposal_generator.rpn_head.conv", 1, 1, relu=True)
+            d, c = ops.cfrpn_head_tail(t.view(-1, t.shape[-1]), eng.rpn_wd, eng.rpn_bd, eng.rpn_wc, eng.rpn_bc)
+            deltas.append(d.view(n, h, w, 4).permute(0, 3, 1, 2))
+            ctrs.append(c.view(n, h, w, 1).permute(0, 3, 1, 2))
+        return deltas, ctrs
+
+
+@PROPOSAL_GENERATOR_REGISTRY.register()
+class ClsFreeRPN(nn.Module):
+    """classification_free_rpn.py:165-610. forward(images, features, gt_instances=None) ->
+    (list[Instances{proposal_boxes, objectness_logits}], losses dict)."""
+
+    def __init__(self, cfg: CfgNode, input_shape: Dict[str, ShapeSpec]):
+        super().__init__()
+        self.in_features = list(cfg.MODEL.RPN.IN_FEATURES)
+        shapes = [input_shape[f] for f in self.in_features]
+        self.rpn_head = RPN_HEAD_REGISTRY.get(cfg.MODEL.RPN.HEAD_NAME)(cfg, shapes)
+        self.strides = [s.stride for s in shapes]
+        self.anchor_sizes = [float(s[0]) for s in cfg.MODEL.ANCHOR_GENERATOR.SIZES]
+        assert len(self.anchor_sizes) == len(self.in_features)
+        self.pre_nms_topk = {True: cfg.MODEL.RPN.PRE_NMS_TOPK_TRAIN, False: cfg.MODEL.RPN.PRE_NMS_TOPK_TEST}
+        self.post_nms_topk = {True: cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN, False: cfg.MODEL.RPN.POST_NMS_TOPK_TEST}  # accepted, unused (F1)
+        self.nms_thresh = {True: cfg.MODEL.RPN.NMS_THRESH, False: cfg.MODEL.RPN.NMS_THRESH_TEST}                  # idem
+        self.min_box_size = float(cfg.MODEL.PROPOSAL_GENERATOR.MIN_SIZE)
+        self.loss_weight = {"loss_rpn_loc": cfg.MODEL.RPN.BBOX_REG_LOSS_WEIGHT * cfg.MODEL.RPN.LOSS_WEIGHT,
+                            "loss_rpn_ctr": cfg.MODEL.RPN.CTR_REG_LOSS_WEIGHT * cfg.MODEL.RPN.LOSS_WEIGHT}
+
+    def select(self, features: Dict[str, torch.Tensor], image_sizes: List[Tuple[int, int]]):
+        """Device-resident result of predict_proposals (padded arrays + counts), as the engine consumes it."""
+        feats = [features[f] for f in self.in_features]
+        deltas, ctrs = self.rpn_head(feats)
+        n = feats[0].shape[0]
+        shapes = [(f.shape[2], f.shape[3]) for f in feats]
+        # (N,4,H,W)/(N,1,H,W) views of NHWC memory -> level-major (N*H*W, 4) / (N*H*W)
+        d_cat = torch.cat([d.permute(0, 2, 3, 1).reshape(-1, 4) for d in deltas]).contiguous()
+        c_cat = torch.cat([c.permute(0, 2, 3, 1).reshape(-1) for c in ctrs]).contiguous()
+        dev = d_cat.device
+        lv = ops.make_rpn_levels(shapes, self.strides, n, 1)
+        cell = torch.tensor([[[-s / 2, -s / 2, s / 2, s / 2]] for s in self.anchor_sizes], dtype=torch.float32, device=dev)
+        hw = torch.tensor(image_sizes, dtype=torch.int32, device=dev)
+        return ops.rpn_select(lv, cell, c_cat, d_cat, n, hw, int(self.pre_nms_topk[self.training]), self.min_box_size), hw
+
+    def forward(self, images: ImageList, features: Dict[str, torch.Tensor], gt_instances: Optional[List[Instances]] = None):
+        if self.training:
+            assert gt_instances is not None, "RPN requires gt_instances in training!"
+            raise NotImplementedError(_TRAIN_MSG)
+        sel, _ = self.select(features, images.image_sizes)
+        counts = sel["counts"].cpu().tolist()  # the list-of-Instances API needs the lengths on the host
+        out = []
+        for i, size in enumerate(images.image_sizes):
+            r = Instances(size)
+            r.proposal_boxes = Boxes(sel["boxes"][i, : counts[i]])
+            r.objectness_logits = sel["scores"][i, : counts[i]]
+            out.append(r)
+        return out, {}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# RoI heads
+# ---------------------------------------------------------------------------------------------------------------
+@ROI_BOX_HEAD_REGISTRY.register()
+class FastRCNNConvFCHead(nn.Module):
+    """[d2] box head with NUM_FC=2 (Base-RCNN-FPN.yaml:24-27): fc1 (c*7*7 -> 1024), fc2 (1024 -> 1024), ReLU each."""
+
+    def __init__(self, cfg: CfgNode, input_shape: ShapeSpec):
+        super().__init__()
+        assert cfg.MODEL.ROI_BOX_HEAD.NUM_CONV == 0 and cfg.MODEL.ROI_BOX_HEAD.NUM_FC == 2
+        fc = cfg.MODEL.ROI_BOX_HEAD.FC_DIM
+        self.fc1 = nn.Linear(input_shape.channels * input_shape.height * input_shape.width, fc)
+        self.fc2 = nn.Linear(fc, fc)
+        self.output_shape = ShapeSpec(channels=fc)
+
+
+class OpensetFastRCNNOutputLayers(nn.Module):
+    """osrcnn_fast_rcnn.py:148-264: bbox_pred (class-agnostic 4) and iou_pred (1, sigmoid)."""
+
+    def __init__(self, cfg: CfgNode, input_shape: ShapeSpec):
+        super().__init__()
+        assert cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG, "the Openset yaml files use class-agnostic box regression"
+        self.bbox_pred = nn.Linear(input_shape.channels, 4)
+        self.iou_pred = nn.Linear(input_shape.channels, 1)
+        nn.init.normal_(self.bbox_pred.weight, std=0.001)
+        nn.init.normal_(self.iou_pred.weight, std=0.01)
+        nn.init.constant_(self.bbox_pred.bias, 0)
+        nn.init.constant_(self.iou_pred.bias, 0)
+
+
+class PLN(nn.Module):
+    """prototype_learning_network.py:17-97: encoder, decoder, `representatives` (num_known*reps, emd)."""
+
+    def __init__(self, cfg: CfgNode):
+        super().__init__()
+        fd, ed = cfg.MODEL.ROI_BOX_HEAD.FC_DIM, cfg.MODEL.PLN.EMD_DIM
+        assert cfg.MODEL.PLN.DISTANCE_TYPE == "COS", "the yaml files use the cosine distance"
+        self.encoder = nn.Linear(fd, ed)
+        self.decoder = nn.Linear(ed, fd)
+        for l in (self.encoder, self.decoder):
+            nn.init.normal_(l.weight, std=0.01)
+            nn.init.constant_(l.bias, 0)
+        self.representatives = nn.Parameter(torch.randn(cfg.MODEL.ROI_HEADS.NUM_KNOWN_CLASSES * cfg.MODEL.PLN.REPS_PER_CLASS, ed))
+
+
+class SoftMaxClassifier(nn.Module):
+    """softmax_classifier.py:170-245: cls_score (FC_DIM -> num_known+1)."""
+
+    def __init__(self, cfg: CfgNode):
+        super().__init__()
+        self.cls_score = nn.Linear(cfg.MODEL.ROI_BOX_HEAD.FC_DIM, cfg.MODEL.ROI_HEADS.NUM_KNOWN_CLASSES + 1)
+        nn.init.normal_(self.cls_score.weight, std=0.01)
+        nn.init.constant_(self.cls_score.bias, 0)
+
+
+def engine_cfg_from(cfg: CfgNode) -> dict:
+    """yaml keys -> engine hyper-parameters."""
+    rh, bh = cfg.MODEL.ROI_HEADS, cfg.MODEL.ROI_BOX_HEAD
+    return dict(
+        pixel_mean=tuple(cfg.MODEL.PIXEL_MEAN), pixel_std=tuple(cfg.MODEL.PIXEL_STD),
+        anchor_sizes=tuple(float(s[0]) for s in cfg.MODEL.ANCHOR_GENERATOR.SIZES),
+        pre_nms_topk_test=cfg.MODEL.RPN.PRE_NMS_TOPK_TEST, min_box_size=float(cfg.MODEL.PROPOSAL_GENERATOR.MIN_SIZE),
+        pooler_resolution=bh.POOLER_RESOLUTION, bbox_reg_weights=tuple(bh.BBOX_REG_WEIGHTS), mean_type=rh.MEAN_TYPE,
+        obj_score_thresh=rh.OBJ_SCORE_THRESH_TEST, nms_thresh_test=rh.NMS_THRESH_TEST, detections_per_image=cfg.TEST.DETECTIONS_PER_IMAGE,
+        known_score_thresh=rh.KNOWN_SCORE_THRESH, known_nms_thresh=rh.KNOWN_NMS_THRESH, known_topk=rh.KNOWN_TOPK,
+        unknown_score_thresh=rh.UNKNOWN_SCORE_THRESH, unknown_nms_thresh=rh.UNKNOWN_NMS_THRESH, unknown_topk=rh.UNKNOWN_TOPK,
+        num_classes=rh.NUM_CLASSES, num_known=rh.NUM_KNOWN_CLASSES, reps_per_class=cfg.MODEL.PLN.REPS_PER_CLASS,
+        # the reference hard-codes the unknown id: 80 with --opendet-benchmark, else 1000
+        unknown_id=80 if cfg.OPENDET_BENCHMARK else 1000, unk_thr=cfg.MODEL.PLN.UNK_THR,
+    )
+
+
+@ROI_HEADS_REGISTRY.register()
+class OpensetROIHeads(_EngineOwner):
+    """osrcnn_roi_heads.py:26-329. forward(images, features, proposals, targets=None) ->
+    (list[Instances{pred_boxes, scores, pred_classes}], {}) at inference."""
+    _prefix = "roi_heads."
+
+    def __init__(self, cfg: CfgNode, input_shape: Dict[str, ShapeSpec], class_id: Optional[torch.Tensor] = None):
+        super().__init__()
+        self.in_features = self.box_in_features = list(cfg.MODEL.ROI_HEADS.IN_FEATURES)
+        res = cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION
+        assert cfg.MODEL.ROI_BOX_HEAD.POOLER_TYPE == "ROIAlignV2" and cfg.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO == 0
+        self.pooler_scales = tuple(1.0 / input_shape[k].stride for k in self.in_features)
+        ch = input_shape[self.in_features[0]].channels
+        self.box_head = ROI_BOX_HEAD_REGISTRY.get(cfg.MODEL.ROI_BOX_HEAD.NAME)(cfg, ShapeSpec(channels=ch, height=res, width=res))
+        self.box_predictor = OpensetFastRCNNOutputLayers(cfg, self.box_head.output_shape)
+        self.dml = PLN(cfg)
+        self.softmaxcls = SoftMaxClassifier(cfg)
+        self.num_classes = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+        self._eng_cfg = engine_cfg_from(cfg)
+        self._eng_cfg["pooler_scales"] = self.pooler_scales
+        # GraspNet: sorted contiguous ids of the known categories (prototype_learning_network.py:80-95); VOC-COCO: identity
+        self._class_map = class_id
+
+    def forward_device(self, features: Dict[str, torch.Tensor], sel: dict, image_hw: torch.Tensor):
+        eng = self.engine()
+        feats = {k: _to_nhwc(features[k], eng.dtype) for k in self.in_features}
+        return eng._roi_heads(feats, sel, image_hw)
+
+    def forward(self, images: ImageList, features: Dict[str, torch.Tensor], proposals: List[Instances],
+                targets: Optional[List[Instances]] = None):
+        del images
+        if self.training:
+            assert targets, "'targets' argument is required during training"
+            raise NotImplementedError(_TRAIN_MSG)
+        n = len(proposals)
+        dev = proposals[0].proposal_boxes.tensor.device
+        counts = [len(p) for p in proposals]
+        cap = max(max(counts), 1)
+        boxes = torch.zeros((n, cap, 4), dtype=torch.float32, device=dev)
+        scores = torch.zeros((n, cap), dtype=torch.float32, device=dev)
+        bidx = torch.full((n, cap), -1, dtype=torch.int32, device=dev)
+        for i, p in enumerate(proposals):
+            boxes[i, : counts[i]] = p.proposal_boxes.tensor
+            scores[i, : counts[i]] = p.objectness_logits
+            bidx[i, : counts[i]] = i
+        sel = dict(boxes=boxes, scores=scores, batch_idx=bidx.view(-1), counts=torch.tensor(counts, dtype=torch.int32, device=dev), cap=cap)
+        hw = torch.tensor([p.image_size for p in proposals], dtype=torch.int32, device=dev)
+        res = OpensetRCNNEngine.to_instances(self.forward_device(features, sel, hw), n)
+        out = []
+        for r, p in zip(res, proposals):
+            inst = Instances(p.image_size)
+            inst.pred_boxes = Boxes(r["pred_boxes"])
+            inst.scores = r["scores"]
+            inst.pred_classes = r["pred_classes"]
+            out.append(inst)
+        return out, {}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# meta architecture
+# ---------------------------------------------------------------------------------------------------------------
+def detector_postprocess(results: Instances, output_height: int, output_width: int) -> Instances:
+    """[d2] rescale to the requested output resolution, clip, drop empty boxes."""
+    sx, sy = output_width / results.image_size[1], output_height / results.image_size[0]
+    out = Instances((output_height, output_width), **results.get_fields())
+    b = out.pred_boxes.clone()
+    b.scale(sx, sy)
+    b.clip(out.image_size)
+    out.pred_boxes = b
+    return out[b.nonempty()]
+
+
+@META_ARCH_REGISTRY.register()
+class GeneralizedRCNN(_EngineOwner):
+    """[d2] GeneralizedRCNN as the reference builds it (train.py:189): backbone + proposal_generator + roi_heads.
+    model(list[dict{image,height,width}]) -> list[{"instances": Instances}] in eval mode (train.py:96)."""
+    _prefix = ""
+
+    def __init__(self, cfg: CfgNode, class_id: Optional[torch.Tensor] = None):
+        super().__init__()
+        self.backbone = BACKBONE_REGISTRY.get(cfg.MODEL.BACKBONE.NAME)(cfg)
+        shapes = self.backbone.output_shape()
+        self.proposal_generator = PROPOSAL_GENERATOR_REGISTRY.get(cfg.MODEL.PROPOSAL_GENERATOR.NAME)(cfg, shapes)
+        self.roi_heads = ROI_HEADS_REGISTRY.get(cfg.MODEL.ROI_HEADS.NAME)(cfg, shapes, class_id)
+        self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1), False)
+        self._eng_cfg = engine_cfg_from(cfg)
+        self._class_map = class_id
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    def engine(self) -> OpensetRCNNEngine:
+        eng = super().engine()
+        for child in (self.backbone, self.proposal_generator.rpn_head, self.roi_heads):
+            child._shared = eng  # one packed copy of the weights for the whole model
+        return eng
+
+    def refresh(self):
+        super().refresh()
+        for child in (self.backbone, self.proposal_generator.rpn_head, self.roi_heads):
+            child._shared = None
+            child.refresh()
+
+    def preprocess_image(self, batched_inputs: List[dict]) -> ImageList:
+        images = [(x["image"].to(self.device).float() - self.pixel_mean) / self.pixel_std for x in batched_inputs]
+        return ImageList.from_tensors(images, self.backbone.size_divisibility)
+
+    def forward(self, batched_inputs: List[dict]):
+        if self.training:
+            raise NotImplementedError(_TRAIN_MSG)
+        return self.inference(batched_inputs)
+
+    @torch.no_grad()
+    def inference(self, batched_inputs: List[dict], do_postprocess: bool = True):
+        eng = self.engine()
+        imgs = [x["image"] for x in batched_inputs]
+        sizes = [(int(i.shape[-2]), int(i.shape[-1])) for i in imgs]
+        if len(set(sizes)) == 1 and len(set(i.dtype for i in imgs)) == 1 and imgs[0].dtype in (torch.uint8, torch.float32):
+            batch = torch.stack([i.to(self.device) for i in imgs])  # fused normalise+pad on the device
+            res = eng.forward(batch, sizes)
+        else:  # ragged batch: pad with the pixel mean so that the normalised padding is exactly zero
+            hm, wm = max(s[0] for s in sizes), max(s[1] for s in sizes)
+            batch = self.pixel_mean.to(self.device).float().expand(3, hm, wm).unsqueeze(0).repeat(len(imgs), 1, 1, 1)
+            for k, im in enumerate(imgs):
+                batch[k, :, : sizes[k][0], : sizes[k][1]] = im.to(self.device).float()
+            res = eng.forward(batch, sizes)
+        insts = OpensetRCNNEngine.to_instances(res, len(imgs))
+        out = []
+        for r, inp, size in zip(insts, batched_inputs, sizes):
+            inst = Instances(size, pred_boxes=Boxes(r["pred_boxes"]), scores=r["scores"], pred_classes=r["pred_classes"])
+            if do_postprocess:
+                inst = detector_postprocess(inst, inp.get("height", size[0]), inp.get("width", size[1]))
+            out.append({"instances": inst})
+        return out
+
+
+def build_model(cfg: CfgNode, class_id: Optional[torch.Tensor] = None) -> nn.Module:
+    """[d2] detectron2.modeling.build_model (train.py:189)."""
+    model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg, class_id)
+    return model.to(torch.device(cfg.MODEL.DEVICE))

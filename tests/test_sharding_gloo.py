@@ -1,0 +1,68 @@
+"""N>1 control path on CPU: 2 gloo ranks shard a global batch exactly like bench.py / the evaluator path does
+(no data-path collective; MAX-reduced timing; rank-0 gather), SURVEY.md 8e."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, global_n, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as ge
+    ge.load_package()
+    from openset_rcnn_amd.host import parallel as P
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = P.shard_range(global_n, rank, world)
+    # stand-in for the per-image engine output: one record per image of this rank's shard
+    mine = [{"image_id": i, "n_det": (i * 7) % 5} for i in range(lo, hi)]
+    P.barrier()
+    t = P.max_over_ranks(1.0 + rank)  # slowest rank defines the step time
+    gathered = P.gather_to_rank0(mine)
+    if rank == 0:
+        q.put((t, P.merge_sharded(gathered)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_gather():
+    world, global_n = 2, 33  # odd on purpose: ragged shards
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, global_n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    t, merged = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert t == 2.0
+    assert [m["image_id"] for m in merged] == list(range(global_n))  # every image exactly once, global order kept
+
+
+def test_shard_range_partitions():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as ge
+    ge.load_package()
+    from openset_rcnn_amd.host.parallel import shard_range
+    for n in (0, 1, 16, 33, 64, 127):
+        for w in (1, 2, 4, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
