@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-iters", type=int, default=1)
     ap.add_argument("--stages", action="store_true", help="also print a per-stage breakdown to stderr")
+    ap.add_argument("--layers", action="store_true", help="also print every MFMA launch (time, TFLOP/s, GB/s) to stderr")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,16 +136,20 @@ def main():
     torch.cuda.synchronize()
     prof = eng.profile
     eng.profile = None
-    mfma_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in prof)
-    mfma_flops = sum(f for _, f, _, _ in prof)
+    mfma_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1, _ in prof)
+    mfma_flops = sum(f for _, f, _, _, _ in prof)
     achieved = mfma_flops / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
     peak = MFMA_PEAK_TFLOPS[args.dtype]
     roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=None,
                     kernel="conv_igemm_kernel (implicit-GEMM conv + FC)", launches_per_step=len(prof),
                     flops_per_step=mfma_flops, kernel_ms_per_step=round(mfma_ms, 3))
+    if args.layers and rank == 0:
+        for name, f, e0, e1, nb in prof:
+            ms_ = e0.elapsed_time(e1)
+            print(f"  {name:48s} {ms_ * 1e3:8.1f} us {f / ms_ / 1e9:8.1f} TFLOP/s {nb / ms_ / 1e6:8.1f} GB/s", file=sys.stderr)
     if args.stages and rank == 0:
         agg = {}
-        for name, f, e0, e1 in prof:
+        for name, f, e0, e1, _ in prof:
             key = name.split(".")[1] if name.startswith("backbone.bottom_up") else name.split(".")[0] + "." + name.split(".")[1]
             key = name.split(".")[2] if name.startswith("backbone.bottom_up") else key
             a = agg.setdefault(key, [0.0, 0.0])

@@ -14,6 +14,7 @@
 // through a wave-private LDS slab so that bias + residual (+ FPN upsample-add) + ReLU + down-convert are applied
 // on 16-byte row segments and the store is coalesced along channels.
 #include "osr_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef f16_t f16x8 __attribute__((ext_vector_type(8)));
@@ -254,13 +255,22 @@ static osr_status conv_launch(const ConvArgs& a0, hipStream_t st) {
     return OSR_OK;
 }
 
+int osr_conv64_eligible(const osr_conv_params* p, long long in_bytes, long long w_bytes);
+osr_status osr_conv64_run(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* residual, void* out,
+                          long long in_bytes, long long w_bytes, hipStream_t st);
+
+static bool force_bk32() {
+    static const bool v = [] { const char* e = getenv("OSR_CONV_BK32"); return e && e[0] == '1'; }();
+    return v;
+}
+
 extern "C" osr_status osr_conv2d_fwd(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* residual,
                                      void* out, void* stream) {
     OSR_REQUIRE(p && in && weight && bias && out, OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: null pointer");
     OSR_REQUIRE(p->n >= 1 && p->hi >= 1 && p->wi >= 1 && p->ho >= 1 && p->wo >= 1, OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: bad spatial sizes");
     OSR_REQUIRE(p->cin >= 32 && p->cin % 32 == 0, OSR_ERR_UNSUPPORTED, "osr_conv2d_fwd: cin must be a multiple of 32, got %d", p->cin);
     OSR_REQUIRE(p->cout >= 8 && p->cout % 8 == 0, OSR_ERR_UNSUPPORTED, "osr_conv2d_fwd: cout must be a multiple of 8, got %d", p->cout);
-    OSR_REQUIRE(p->kh >= 1 && p->kw >= 1 && p->kh <= 7 && p->kw <= 7 && p->stride_h >= 1 && p->stride_w >= 1 && p->pad_h >= 0 && p->pad_w >= 0,
+    OSR_REQUIRE(p->kh >= 1 && p->kw >= 1 && p->kh <= 16 && p->kw <= 16 && p->stride_h >= 1 && p->stride_w >= 1 && p->pad_h >= 0 && p->pad_w >= 0,
                 OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: bad kernel geometry");
     OSR_REQUIRE(p->in_dtype == OSR_F16 || p->in_dtype == OSR_BF16, OSR_ERR_UNSUPPORTED, "osr_conv2d_fwd: in_dtype must be f16/bf16");
     OSR_REQUIRE(osr_dtype_ok(p->out_dtype), OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: bad out_dtype");
@@ -289,6 +299,13 @@ extern "C" osr_status osr_conv2d_fwd(const osr_conv_params* p, const void* in, c
     a.K = (int)K;
     a.tiles_m = a.tiles_n = 0;
     hipStream_t st = (hipStream_t)stream;
+    {
+        // extent of the input buffer implied by the strides (exact for contiguous NHWC, the stem view and FC rows)
+        const long long in_elems = p->in_stride_n > 0 ? (long long)p->n * p->in_stride_n
+                                                      : (long long)(p->hi - 1) * p->in_stride_h + (long long)(p->wi - 1) * p->in_stride_w + p->cin;
+        const long long in_bytes = in_elems * 2, w_bytes = (long long)p->cout * K * 2;
+        if (!force_bk32() && osr_conv64_eligible(p, in_bytes, w_bytes)) return osr_conv64_run(p, in, weight, bias, residual, out, in_bytes, w_bytes, st);
+    }
     if (p->in_dtype == OSR_F16) {
         if (p->out_dtype == OSR_F16) return conv_launch<f16_t, f16_t>(a, st);
         if (p->out_dtype == OSR_F32) return conv_launch<f16_t, float>(a, st);

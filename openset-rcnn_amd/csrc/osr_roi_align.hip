@@ -3,18 +3,23 @@
 // Replaces [d2] ROIPooler.forward + torchvision roi_align(aligned=True, sampling_ratio=0) at
 // /root/reference/openset_rcnn/modeling/roi_heads/osrcnn_roi_heads.py:108-113,306.
 //
-// Design (MI355X): one workgroup (7 compute waves + table build) per RoI, NHWC features so that the 256
-// channels of a pixel are one contiguous 512 B (fp16) line read by one wave-instruction (4 channels/lane).
-// The adaptive ceil(roi/7) x ceil(roi/7) sample grid of a bin is a tensor product and bilinear weights are
-// products, so  sum_samples bilinear(f) = sum_y sum_x wy[y]*wx[x]*f[y][x]  with per-axis weight tables: each
-// bin reads its (bin_h+~1.5)x(bin_w+~1.5) pixel footprint once instead of 4 taps per sample (about 1.8x fewer
-// line reads at the usual 14-28 px RoIs). The validity rule (y<-1||y>H||x<-1||x>W => sample contributes 0)
-// and the edge clamps are per-axis, hence preserved exactly; only the fp32 summation order differs from the
-// reference loop (documented tolerance 1e-4, measured ~1e-6). RoIs whose per-bin footprint exceeds the LDS
-// table (bins wider than 13 px) take the per-sample 4-tap loop.
+// Design (MI355X): one wave per RoI (4 per 256-thread workgroup, no workgroup barriers), NHWC features so that the
+// 256 channels of a pixel are one contiguous 512 B (fp16) line read by one wave-instruction (4 channels per lane).
+// The adaptive ceil(roi/7) x ceil(roi/7) sample grid of a bin is a tensor product and bilinear weights are products,
+// so  sum_samples bilinear(f) = sum_y sum_x wy[y]*wx[x]*f[y][x]  with per-axis weight tables (built by the wave in
+// its private LDS slice). Fast path ("column sums"): for each bin row the wave streams the footprint columns left to
+// right, forms colsum[x] = sum_y wy[y] f[y][x] from up to 6 row loads (all loads of a column group are issued before
+// any is used), and adds wx * colsum into a 3-bin sliding window of register accumulators; a bin is stored as soon
+// as the stream has passed it. Every footprint pixel of a bin row is read once instead of 4 taps per sample.
+// The validity rule (y<-1||y>H||x<-1||x>W => sample contributes 0) and the edge clamps are per-axis, hence preserved
+// exactly; only the fp32 summation order differs from the reference loop (tolerance 1e-4, measured ~1e-6) and the
+// final division by the sample count is a multiplication by its reciprocal. RoIs outside the fast path's
+// preconditions (bins narrower than a pixel, >6 rows per bin row, >64 footprint columns) take the per-bin separable
+// loop, and table overflow (bins wider than 13 px) the per-sample 4-tap loop.
 #include "osr_common.h"
 
 #define RA_MAXC 16  // table columns per bin
+#define RA_MAXX 64  // columns of the whole RoI footprint handled by the column-sum path
 
 struct RoiAlignArgs {
     const void* data[4];
@@ -63,6 +68,79 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const floa
     *reinterpret_cast<b4*>(p) = t;
 }
 
+template <class T> __device__ __forceinline__ void load8(const T* p, float v[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float v[8]) { load4<float>(p, v); load4<float>(p + 4, v + 4); }
+template <> __device__ __forceinline__ void load8<f16_t>(const f16_t* p, float v[8]) {
+    typedef f16_t h8 __attribute__((ext_vector_type(8)));
+    h8 t = *reinterpret_cast<const h8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float v[8]) {
+    uint4 t = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
+    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+}
+// packed 8-channel register image of one load (kept packed while the loads of a column group are in flight)
+typedef unsigned int ra_u32x4 __attribute__((ext_vector_type(4)));
+typedef float ra_f32x8 __attribute__((ext_vector_type(8)));
+template <class T> struct Raw8;
+template <> struct Raw8<float> {
+    ra_f32x8 r;
+    __device__ __forceinline__ void load(const float* p) { r = *reinterpret_cast<const ra_f32x8*>(p); }
+    __device__ __forceinline__ void get(float v[8]) const { _Pragma("unroll") for (int i = 0; i < 8; ++i) v[i] = r[i]; }
+};
+template <> struct Raw8<f16_t> {
+    typedef f16_t h8 __attribute__((ext_vector_type(8)));
+    h8 r;
+    __device__ __forceinline__ void load(const f16_t* p) { r = *reinterpret_cast<const h8*>(p); }
+    __device__ __forceinline__ void get(float v[8]) const { _Pragma("unroll") for (int i = 0; i < 8; ++i) v[i] = (float)r[i]; }
+};
+template <> struct Raw8<bf16_t> {
+    ra_u32x4 r;
+    __device__ __forceinline__ void load(const bf16_t* p) { r = *reinterpret_cast<const ra_u32x4*>(p); }
+    __device__ __forceinline__ void get(float v[8]) const {
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(r[i] << 16); v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+    }
+};
+// packed 4-channel register image of one 8-byte (fp16/bf16) or 16-byte (fp32) load
+template <class T> struct Raw4;
+template <> struct Raw4<float> {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 r;
+    __device__ __forceinline__ void load(const float* p) { r = *reinterpret_cast<const f4*>(p); }
+    __device__ __forceinline__ void get(float v[4]) const { _Pragma("unroll") for (int i = 0; i < 4; ++i) v[i] = r[i]; }
+};
+template <> struct Raw4<f16_t> {
+    typedef f16_t h4 __attribute__((ext_vector_type(4)));
+    h4 r;
+    __device__ __forceinline__ void load(const f16_t* p) { r = *reinterpret_cast<const h4*>(p); }
+    __device__ __forceinline__ void get(float v[4]) const { _Pragma("unroll") for (int i = 0; i < 4; ++i) v[i] = (float)r[i]; }
+};
+template <> struct Raw4<bf16_t> {
+    typedef bf16_t b4 __attribute__((ext_vector_type(4)));
+    b4 r;
+    __device__ __forceinline__ void load(const bf16_t* p) { r = *reinterpret_cast<const b4*>(p); }
+    __device__ __forceinline__ void get(float v[4]) const { _Pragma("unroll") for (int i = 0; i < 4; ++i) v[i] = (float)r[i]; }
+};
+template <class T> __device__ __forceinline__ void store8(T* p, const float v[8]) { store4<T>(p, v); store4<T>(p + 4, v + 4); }
+template <> __device__ __forceinline__ void store8<f16_t>(f16_t* p, const float v[8]) {
+    typedef f16_t h8 __attribute__((ext_vector_type(8)));
+    h8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (f16_t)v[i];
+    *reinterpret_cast<h8*>(p) = t;
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float v[8]) {
+    typedef bf16_t b8 __attribute__((ext_vector_type(8)));
+    b8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (bf16_t)v[i];
+    *reinterpret_cast<b8*>(p) = t;
+}
+
 // One sample coordinate of torchvision's pre_calc_for_bilinear_interpolate along one axis.
 // Returns false when the sample is outside [-1, size] (contributes nothing).
 __device__ __forceinline__ bool axis_sample(float start, int bin, float bin_size, int i, int grid, int size,
@@ -77,20 +155,37 @@ __device__ __forceinline__ bool axis_sample(float start, int bin, float bin_size
     return true;
 }
 
+__device__ __forceinline__ void ra_wave_sync() {
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
+    __builtin_amdgcn_wave_barrier();     // and the compiler keeps later LDS reads behind them
+}
+
+struct RaWaveLds {
+    float w[2][7][RA_MAXC];  // [axis: 0 = y, 1 = x][bin][column of the bin's footprint]
+    int lo[2][8], n[2][8];
+    int colb[RA_MAXX];       // per footprint column: first unfinished bin
+    float colw[3][RA_MAXX];  // weight of the column in bins colb, colb+1, colb+2
+};
+
+// One wave per RoI (4 RoIs per 256-thread workgroup, no workgroup barriers). The wave builds the per-axis weight
+// tables in its private LDS slice, then walks the 7 bin rows; per bin row it streams the footprint columns left to
+// right, both half-waves taking alternate feature rows, RA_G columns (= up to 3*RA_G 16-byte loads per lane) in
+// flight at a time, and keeps a 3-bin sliding window of accumulators in registers.
+#define RA_G 2
 template <class TI, class TO>
-__global__ __launch_bounds__(448) void roi_align_kernel(RoiAlignArgs a) {
-    const long long r = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+__global__ __launch_bounds__(256) void roi_align_kernel(RoiAlignArgs a) {
+    __shared__ RaWaveLds s_all[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long r = (long long)blockIdx.x * 4 + wid;
+    if (r >= a.m) return;
+    RaWaveLds& S = s_all[wid];
     const int P = a.pooled, C = a.c;
     TO* out = reinterpret_cast<TO*>(a.out) + (size_t)r * P * P * C;
 
-    __shared__ float s_w[2][7][RA_MAXC];  // [axis: 0=y,1=x][bin][col]
-    __shared__ int s_lo[2][7], s_n[2][7];
-    __shared__ int s_fallback;
-
     const int b = a.batch_idx[r];
     if (b < 0) {  // padding row: zeros
-        for (int i = tid * 4; i < P * P * C; i += blockDim.x * 4) {
+        for (int i = lane * 4; i < P * P * C; i += 64 * 4) {
             float z[4] = {0.f, 0.f, 0.f, 0.f};
             store4<TO>(out + i, z);
         }
@@ -102,7 +197,7 @@ __global__ __launch_bounds__(448) void roi_align_kernel(RoiAlignArgs a) {
     float lvf = floorf((float)a.canonical_level + log2f(sz / (float)a.canonical_size + 1e-8f));
     float lmin = (float)a.min_level, lmax = (float)(a.min_level + a.num_levels - 1);
     lvf = fminf(fmaxf(lvf, lmin), lmax);  // NaN (degenerate area) -> lmin via fmaxf
-    const int lv = (int)lvf - a.min_level;
+    const int lv = __builtin_amdgcn_readfirstlane((int)lvf - a.min_level);
     const int H = a.h[lv], W = a.w[lv];
     const float scale = a.scale[lv];
     const TI* feat = reinterpret_cast<const TI*>(a.data[lv]) + (size_t)b * H * W * C;
@@ -114,11 +209,11 @@ __global__ __launch_bounds__(448) void roi_align_kernel(RoiAlignArgs a) {
     const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
     const float count = (float)max(gh * gw, 1);
 
-    if (tid == 0) s_fallback = 0;
-    __syncthreads();
-    // ---- per-axis weight tables: thread (axis, bin, col) sums the samples that touch its column ----
-    if (tid < 2 * 7 * RA_MAXC && (tid / RA_MAXC) % 7 < P) {
-        const int axis = tid / (7 * RA_MAXC), bin = (tid / RA_MAXC) % 7, col = tid % RA_MAXC;
+    // ---- per-axis weight tables: entry (axis, bin, col) sums the samples that touch its column ----
+    bool overflow = false;
+    for (int e = lane; e < 2 * 7 * RA_MAXC; e += 64) {
+        const int axis = e / (7 * RA_MAXC), bin = (e / RA_MAXC) % 7, col = e % RA_MAXC;
+        if (bin >= P) continue;
         const float start = axis ? sw : sh, bs = axis ? bw : bh;
         const int grid = axis ? gw : gh, size = axis ? W : H;
         int first = -1, last = -1;
@@ -131,62 +226,161 @@ __global__ __launch_bounds__(448) void roi_align_kernel(RoiAlignArgs a) {
             if (lo - first == col) acc += wl;
             if (hi - first == col) acc += wh;
         }
-        s_w[axis][bin][col] = acc;
+        S.w[axis][bin][col] = acc;
         if (col == 0) {
-            s_lo[axis][bin] = first < 0 ? 0 : first;
-            int n = first < 0 ? 0 : last - first + 1;
-            s_n[axis][bin] = n;
-            if (n > RA_MAXC) s_fallback = 1;
+            const int n = first < 0 ? 0 : last - first + 1;
+            S.lo[axis][bin] = first < 0 ? 0 : first;
+            S.n[axis][bin] = n;
+            overflow |= n > RA_MAXC;
         }
     }
-    __syncthreads();
-    if (wid >= P) return;
-    const int ph = wid;
-    const bool fallback = s_fallback != 0;
+    const bool fallback = __any(overflow);
+    ra_wave_sync();
 
-    for (int c0 = lane * 4; c0 < C; c0 += 256) {
-        for (int pw = 0; pw < P; ++pw) {
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            if (!fallback) {
-                const int y0 = s_lo[0][ph], ny = s_n[0][ph], x0 = s_lo[1][pw], nx = s_n[1][pw];
-                for (int j = 0; j < ny; ++j) {
-                    const float wy = s_w[0][ph][j];
-                    const TI* row = feat + ((size_t)(y0 + j) * W + x0) * C + c0;
-                    for (int i = 0; i < nx; ++i) {
-                        float v[4];
-                        load4<TI>(row + (size_t)i * C, v);
-                        const float wgt = wy * s_w[1][pw][i];
-                        acc[0] += wgt * v[0]; acc[1] += wgt * v[1]; acc[2] += wgt * v[2]; acc[3] += wgt * v[3];
-                    }
-                }
-            } else {
-                for (int iy = 0; iy < gh; ++iy) {
-                    int yl, yh; float hy, ly;
-                    if (!axis_sample(sh, ph, bh, iy, gh, H, &yl, &yh, &hy, &ly)) continue;
-                    for (int ix = 0; ix < gw; ++ix) {
-                        int xl, xh; float hx, lx;
-                        if (!axis_sample(sw, pw, bw, ix, gw, W, &xl, &xh, &hx, &lx)) continue;
-                        float v1[4], v2[4], v3[4], v4[4];
-                        load4<TI>(feat + ((size_t)yl * W + xl) * C + c0, v1);
-                        load4<TI>(feat + ((size_t)yl * W + xh) * C + c0, v2);
-                        load4<TI>(feat + ((size_t)yh * W + xl) * C + c0, v3);
-                        load4<TI>(feat + ((size_t)yh * W + xh) * C + c0, v4);
-                        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+    // ---- column-sum fast path precondition (checked by lanes 0..P-1, one bin each) ----
+    bool bad = fallback;
+    int xs_l = 0x7fffffff, xe_l = 0;
+    if (lane < P) {
+        const int lo = S.lo[1][lane], n = S.n[1][lane];
+        if (n > 0) { xs_l = lo; xe_l = lo + n; }
+        if (lane + 1 < P && n > 0 && S.n[1][lane + 1] > 0 && S.lo[1][lane + 1] < lo) bad = true;
+        if (lane + 3 < P && n > 0 && S.n[1][lane + 3] > 0 && S.lo[1][lane + 3] < lo + n) bad = true;
+        if (lane + 1 < P && lane > 0 && n == 0 && S.n[1][lane - 1] > 0 && S.n[1][lane + 1] > 0) bad = true;  // hole: not expected
+        if (S.n[0][lane] > 6) bad = true;
+    }
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) acc[k] += w1 * v1[k] + w2 * v2[k] + w3 * v3[k] + w4 * v4[k];
-                    }
-                }
+    for (int d = 1; d < 8; d <<= 1) {
+        xs_l = min(xs_l, __shfl_xor(xs_l, d, 64));
+        xe_l = max(xe_l, __shfl_xor(xe_l, d, 64));
+    }
+    int xs = __builtin_amdgcn_readfirstlane(xs_l), xe = __builtin_amdgcn_readfirstlane(xe_l);
+    if (xs == 0x7fffffff) xs = 0;
+    const int ncol = xe - xs;
+    const bool win_ok = !__any(bad) && ncol <= RA_MAXX;
+
+    if (win_ok) {
+        if (lane < ncol) {  // per-column table
+            const int x = xs + lane;
+            int cb = 0;
+            while (cb < P && (S.n[1][cb] == 0 || x >= S.lo[1][cb] + S.n[1][cb])) ++cb;
+            S.colb[lane] = cb;
+#pragma unroll
+            for (int t2 = 0; t2 < 3; ++t2) {
+                const int bb = cb + t2;
+                float wv = 0.f;
+                if (bb < P) { const int i = x - S.lo[1][bb]; if (i >= 0 && i < S.n[1][bb]) wv = S.w[1][bb][i]; }
+                S.colw[t2][lane] = wv;
             }
+        }
+        ra_wave_sync();
+        const float inv_count = 1.0f / count;
+        const size_t rowstride = (size_t)W * C;
+        for (int ph = 0; ph < P; ++ph) {
+            const int y0 = __builtin_amdgcn_readfirstlane(S.lo[0][ph]), ny = __builtin_amdgcn_readfirstlane(S.n[0][ph]);
+            float wy[6];  // wave-uniform row weights (live in scalar registers)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] = acc[k] / count;
-            store4<TO>(out + (size_t)(ph * P + pw) * C + c0, acc);
+            for (int j = 0; j < 6; ++j) wy[j] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(j < ny ? S.w[0][ph][j] : 0.f)));
+            for (int cb0 = 0; cb0 < C; cb0 += 256) {
+                const int c0 = cb0 + lane * 4;
+                const bool cok = c0 < C;
+                const TI* rp = feat + ((size_t)y0 * W + xs) * C + (cok ? c0 : 0);
+                float a0[4], a1[4], a2[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { a0[k] = 0.f; a1[k] = 0.f; a2[k] = 0.f; }
+                int bcur = 0;
+#define RA_FLUSH()                                                                                        \
+                {                                                                                         \
+                    float tot[4];                                                                         \
+                    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                       \
+                        tot[k] = a0[k] * inv_count;                                                       \
+                        a0[k] = a1[k]; a1[k] = a2[k]; a2[k] = 0.f;                                        \
+                    }                                                                                     \
+                    if (cok) store4<TO>(out + (size_t)(ph * P + bcur) * C + c0, tot);                     \
+                    ++bcur;                                                                               \
+                }
+                for (int xg = 0; xg < ncol; xg += RA_G) {
+                    // issue every load of this column group before using any (memory-level parallelism)
+                    Raw4<TI> v[RA_G][6];
+#pragma unroll
+                    for (int g2 = 0; g2 < RA_G; ++g2) {
+                        const TI* cp = rp + (size_t)(xg + g2 < ncol ? xg + g2 : ncol - 1) * C;  // tail columns re-read the last one
+#pragma unroll
+                        for (int j = 0; j < 6; ++j)
+                            if (j < ny) v[g2][j].load(cp + j * rowstride);
+                    }
+#pragma unroll
+                    for (int g2 = 0; g2 < RA_G; ++g2) {
+                        if (xg + g2 < ncol) {
+                            const int x = xg + g2;
+                            const int cbx = __builtin_amdgcn_readfirstlane(S.colb[x]);
+                            while (bcur < cbx) RA_FLUSH();
+                            float cs[4] = {0.f, 0.f, 0.f, 0.f}, f[4];
+#pragma unroll
+                            for (int j = 0; j < 6; ++j)
+                                if (j < ny) { v[g2][j].get(f); _Pragma("unroll") for (int k = 0; k < 4; ++k) cs[k] = __builtin_fmaf(wy[j], f[k], cs[k]); }
+                            const float w0 = S.colw[0][x], w1 = S.colw[1][x], w2 = S.colw[2][x];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                a0[k] = __builtin_fmaf(w0, cs[k], a0[k]);
+                                a1[k] = __builtin_fmaf(w1, cs[k], a1[k]);
+                                a2[k] = __builtin_fmaf(w2, cs[k], a2[k]);
+                            }
+                        }
+                    }
+                }
+                while (bcur < P) RA_FLUSH();
+#undef RA_FLUSH
+            }
+        }
+        return;
+    }
+
+    // ---- general paths: per-bin separable footprint, or (table overflow) the per-sample 4-tap loop ----
+    for (int ph = 0; ph < P; ++ph) {
+        for (int c0 = lane * 4; c0 < C; c0 += 256) {
+            for (int pw = 0; pw < P; ++pw) {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                if (!fallback) {
+                    const int y0 = S.lo[0][ph], ny = S.n[0][ph], x0 = S.lo[1][pw], nx = S.n[1][pw];
+                    for (int j = 0; j < ny; ++j) {
+                        const float wy = S.w[0][ph][j];
+                        const TI* row = feat + ((size_t)(y0 + j) * W + x0) * C + c0;
+                        for (int i = 0; i < nx; ++i) {
+                            float v[4];
+                            load4<TI>(row + (size_t)i * C, v);
+                            const float wgt = wy * S.w[1][pw][i];
+                            acc[0] += wgt * v[0]; acc[1] += wgt * v[1]; acc[2] += wgt * v[2]; acc[3] += wgt * v[3];
+                        }
+                    }
+                } else {
+                    for (int iy = 0; iy < gh; ++iy) {
+                        int yl, yh; float hy, ly;
+                        if (!axis_sample(sh, ph, bh, iy, gh, H, &yl, &yh, &hy, &ly)) continue;
+                        for (int ix = 0; ix < gw; ++ix) {
+                            int xl, xh; float hx, lx;
+                            if (!axis_sample(sw, pw, bw, ix, gw, W, &xl, &xh, &hx, &lx)) continue;
+                            float v1[4], v2[4], v3[4], v4[4];
+                            load4<TI>(feat + ((size_t)yl * W + xl) * C + c0, v1);
+                            load4<TI>(feat + ((size_t)yl * W + xh) * C + c0, v2);
+                            load4<TI>(feat + ((size_t)yh * W + xl) * C + c0, v3);
+                            load4<TI>(feat + ((size_t)yh * W + xh) * C + c0, v4);
+                            const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) acc[k] += w1 * v1[k] + w2 * v2[k] + w3 * v3[k] + w4 * v4[k];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] = acc[k] / count;
+                store4<TO>(out + (size_t)(ph * P + pw) * C + c0, acc);
+            }
         }
     }
 }
 
 template <class TI>
 static osr_status launch_out(const RoiAlignArgs& a, int out_dtype, hipStream_t st) {
-    dim3 grid((unsigned)a.m), block(448);
+    dim3 grid((unsigned)((a.m + 3) / 4)), block(256);
     switch (out_dtype) {
         case OSR_F32: hipLaunchKernelGGL((roi_align_kernel<TI, float>), grid, block, 0, st, a); break;
         case OSR_F16: hipLaunchKernelGGL((roi_align_kernel<TI, f16_t>), grid, block, 0, st, a); break;

@@ -91,7 +91,9 @@ class OpensetRCNNEngine:
         y = ops.conv2d(x, w, self.w[name + ".b"], stride, pad, relu, residual, res_mode, out_dtype, out)
         e1.record()
         rows = y.numel() // w.shape[0]
-        self.profile.append((name, 2.0 * rows * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3], e0, e1))
+        nbytes = x.numel() * x.element_size() + w.numel() * w.element_size() + y.numel() * y.element_size() + \
+            (residual.numel() * residual.element_size() if residual is not None else 0)
+        self.profile.append((name, 2.0 * rows * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3], e0, e1, nbytes))
         return y
 
     def _linear(self, x, w, b, relu, out_dtype=None, name="fc"):
@@ -101,7 +103,8 @@ class OpensetRCNNEngine:
         e0.record()
         y = ops.linear(x, w, b, relu=relu, out_dtype=out_dtype)
         e1.record()
-        self.profile.append((name, 2.0 * x.shape[0] * w.shape[0] * w.shape[1], e0, e1))
+        nbytes = x.numel() * x.element_size() + w.numel() * w.element_size() + y.numel() * y.element_size()
+        self.profile.append((name, 2.0 * x.shape[0] * w.shape[0] * w.shape[1], e0, e1, nbytes))
         return y
 
     def _backbone(self, images: torch.Tensor, hp: int, wp: int, keep: Optional[dict] = None, normalized: bool = False) -> Dict[str, torch.Tensor]:
@@ -114,7 +117,8 @@ class OpensetRCNNEngine:
         x = ops.stem_conv(xpad, self.w["backbone.bottom_up.stem.conv1.w"], self.w["backbone.bottom_up.stem.conv1.b"], hp, wp, relu=True)
         if self.profile is not None:
             e1.record()
-            self.profile.append(("backbone.bottom_up.stem.conv1", 2.0 * x.numel() * 147, e0, e1))  # 7*7*3 real taps
+            self.profile.append(("backbone.bottom_up.stem.conv1", 2.0 * x.numel() * 147, e0, e1,
+                                 xpad.numel() * 2 + x.numel() * 2))  # 7*7*3 real taps
         if keep is not None:
             keep["stem"] = x
         x = ops.maxpool3x3s2(x)

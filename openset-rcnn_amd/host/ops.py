@@ -95,18 +95,20 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, stride: in
 
 def stem_conv(xpad: torch.Tensor, w_view: torch.Tensor, bias: torch.Tensor, hp: int, wp: int, relu: bool = True) -> torch.Tensor:
     """7x7/s2/p3 stem on the pre-padded NHWC4 image (see preprocess): a (kh=7, kw=1, cin=32) implicit GEMM whose
-    'pixels' are 4-element groups, 8 of which (7 taps + a zero-weight one) form one K slice."""
+    'pixels' are 4-element groups, 8 of which (7 taps + a zero-weight one) form one K slice. With the 8-row weight
+    view (pack_stem_weight) K = 256 and the BK=64 kernel takes it; the 8th row reads the halo with zero weights."""
     lib = _lib.load()
     _need(xpad, name="xpad"); _need(w_view, xpad.dtype, "w_view"); _need(bias, torch.float32, "bias")
     n, hd, wd, c4 = xpad.shape
     assert c4 == 4 and hd == hp + 6 and wd == stem_padded_width(wp)
     cout = w_view.shape[0]
-    assert tuple(w_view.shape[1:]) == (7, 1, 32)
+    assert tuple(w_view.shape[1:]) in ((7, 1, 32), (8, 1, 32))
+    kh = w_view.shape[1]
     ho, wo = hp // 2, wp // 2
     out = torch.empty((n, ho, wo, cout), dtype=xpad.dtype, device=xpad.device)
     p = ConvParams()
     p.n, p.hi, p.wi, p.cin, p.ho, p.wo, p.cout = n, hd, wd, 32, ho, wo, cout
-    p.kh, p.kw, p.stride_h, p.stride_w, p.pad_h, p.pad_w = 7, 1, 2, 2, 0, 0
+    p.kh, p.kw, p.stride_h, p.stride_w, p.pad_h, p.pad_w = kh, 1, 2, 2, 0, 0
     p.in_stride_n, p.in_stride_h, p.in_stride_w = hd * wd * 4, wd * 4, 4
     p.out_stride_n, p.out_stride_h, p.out_stride_w = ho * wo * cout, wo * cout, cout
     p.relu, p.res_mode, p.pad_mode = int(relu), 0, 1

@@ -89,11 +89,12 @@ def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 
 def pack_stem_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    """(64,3,7,7) -> stem view (64,7,1,32): K slice kh holds 8 taps x 4 channels, 8th tap / 4th channel zero."""
+    """(64,3,7,7) -> stem view (64,8,1,32): K slice kh holds 8 taps x 4 channels of one image row; the 8th tap,
+    the 4th channel and the whole 8th row are zero (the row pads K to a multiple of 64 for the BK=64 kernel)."""
     cout = w.shape[0]
-    v = torch.zeros(cout, 7, 8, 4, dtype=torch.float32)
-    v[:, :, :7, :3] = w.float().permute(0, 2, 3, 1)
-    return v.view(cout, 7, 1, 32).contiguous().to(dtype)
+    v = torch.zeros(cout, 8, 8, 4, dtype=torch.float32)
+    v[:, :7, :7, :3] = w.float().permute(0, 2, 3, 1)
+    return v.view(cout, 8, 1, 32).contiguous().to(dtype)
 
 
 def pack_fc1_weight(w: torch.Tensor, channels: int, pooled: int, dtype: torch.dtype) -> torch.Tensor:

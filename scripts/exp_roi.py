@@ -1,0 +1,45 @@
+"""Experiment driver (not part of the product): time osr_roi_align_fwd alone on the bench's real proposals."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+pkg = ge.load_package(); pkg._lib.load()
+from openset_rcnn_amd.host.engine import OpensetRCNNEngine
+from openset_rcnn_amd.host.weights import random_params
+from openset_rcnn_amd.host import ops
+eng = OpensetRCNNEngine(random_params(0), device="cuda:0")
+g = torch.Generator().manual_seed(1234)
+images = torch.randint(0, 256, (16, 3, 800, 1333), generator=g, dtype=torch.uint8).cuda()
+hw = torch.tensor([(800, 1333)] * 16, dtype=torch.int32, device="cuda")
+keep = {}
+eng.forward_device(images, hw, 800, 1344, keep)
+feats, sel = keep["feats"], keep["sel"]
+b = sel["boxes"].view(-1, 4)
+wh = (b[:, 2:] - b[:, :2])
+print("boxes w/h mean", wh.mean(0).tolist(), "max", wh.max(0)[0].tolist(), "counts", sel["counts"].tolist()[:4])
+fl = [feats[k] for k in ("p2", "p3", "p4", "p5")]
+def run():
+    return ops.roi_align(fl, (0.25, 0.125, 0.0625, 0.03125), b, sel["batch_idx"], 7, torch.float16)
+for _ in range(3): run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): run()
+e1.record(); torch.cuda.synchronize()
+print("OSR_ROI_DEBUG=%s roi_align %.3f ms" % (os.environ.get("OSR_ROI_DEBUG", "0"), e0.elapsed_time(e1) / 10))
+# locality experiment: all RoIs read image 0's pyramid / a tiny region
+bi0 = torch.where(sel["batch_idx"] >= 0, torch.zeros_like(sel["batch_idx"]), sel["batch_idx"])
+def run0():
+    return ops.roi_align(fl, (0.25, 0.125, 0.0625, 0.03125), b, bi0, 7, torch.float16)
+for _ in range(3): run0()
+torch.cuda.synchronize(); e0.record()
+for _ in range(10): run0()
+e1.record(); torch.cuda.synchronize()
+print("all RoIs on image 0: %.3f ms" % (e0.elapsed_time(e1) / 10))
+bs = (b * 0.1).contiguous()  # all boxes squeezed into a 133x80 px corner: everything L2 resident
+def run1():
+    return ops.roi_align(fl, (0.25, 0.125, 0.0625, 0.03125), bs, bi0, 7, torch.float16)
+for _ in range(3): run1()
+torch.cuda.synchronize(); e0.record()
+for _ in range(10): run1()
+e1.record(); torch.cuda.synchronize()
+print("tiny boxes (1/10 size) on image 0: %.3f ms" % (e0.elapsed_time(e1) / 10))

@@ -116,6 +116,10 @@ def test_stem_conv_matches_7x7(ops):
     assert out.shape == ref.shape
     eps = 2.0 ** -10
     assert_close(out, ref, rtol=eps, atol=eps * float(ref.abs().max()) * 0.01 + 1e-5, name="stem")
+    # the product packing: 8-row view (K = 256) -> BK=64 direct-to-LDS kernel, two taps per K slice
+    from openset_rcnn_amd.host.weights import pack_stem_weight
+    out8 = ops.stem_conv(xpad, pack_stem_weight(w7, torch.float16).to(DEV), b.to(DEV), hp, wp, relu=True).cpu().float().permute(0, 3, 1, 2)
+    assert_close(out8, ref, rtol=eps, atol=eps * float(ref.abs().max()) * 0.01 + 1e-5, name="stem bk64")
 
 
 def test_linear_large_k(ops):
