@@ -103,6 +103,15 @@ osr_status osr_cfrpn_head_tail(const void* t, int32_t t_dtype, int64_t rows, int
                                const float* b_delta, const float* w_ctr, const float* b_ctr, float* deltas,
                                float* ctr, void* stream);
 
+/* The whole ClsFreeRPNHead.forward for one pyramid level in ONE launch (classification_free_rpn.py:157-161):
+ * 3x3 conv + bias + ReLU on MFMA, then -- without the hidden state ever leaving the chip -- the channel
+ * L2-normalise, both 1x1 convs and the sigmoid. p describes the 3x3 convolution (cout must be 256, cin %% 64 == 0,
+ * no residual; p->relu/out_* are ignored). w_tail: (5, 256) fp32, rows 0-3 = anchor_deltas, row 4 = centerness;
+ * b_tail: (5). deltas/ctr are indexed by pixel (n*ho + oh)*wo + ow. Returns OSR_ERR_UNSUPPORTED outside that
+ * envelope: run osr_conv2d_fwd + osr_cfrpn_head_tail instead. */
+osr_status osr_cfrpn_head_fwd(const osr_conv_params* p, const void* in, const void* weight, const float* bias,
+                              const float* w_tail, const float* b_tail, float* deltas, float* ctr, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Proposal selection: ClsFreeRPN.predict_proposals -> _decode_proposals (classification_free_rpn.py:558-610)
  * + find_top_rpn_proposals (find_top_proposals.py:60-127) for all images and levels in two launches.

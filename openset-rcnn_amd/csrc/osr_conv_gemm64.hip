@@ -11,6 +11,7 @@
 //  * workgroup -> tile mapping is XCD-aware (blocks b and b+8 share an XCD/L2): each XCD walks a contiguous run of
 //    tiles with the N tiles of one M tile adjacent, so the gathered A rows are fetched into one L2 once.
 #include "osr_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef f16_t f16x8 __attribute__((ext_vector_type(8)));
@@ -38,6 +39,13 @@ struct Conv64Args {
     int tiles_m, tiles_n;
     unsigned in_bytes, w_bytes;  // buffer sizes for the bounds check (< 2 GiB)
     int stem;              // 1: cin == 32 view, two taps per K slice
+    int two_stage;         // 1: double-buffered staging (K-heavy layers); 0: one staging buffer, more workgroups per CU
+    // fused CF-RPN tail (EPI == 1): 1x1 weights [5][256] (rows 0-3 ltrb deltas, row 4 centerness), biases, outputs
+    const float* tail_w;
+    const float* tail_b;
+    float* tail_deltas;
+    float* tail_ctr;
+    int tail_lds_off;      // byte offset of the tail weights in LDS
 };
 
 #define OOB_OFF 0x80000000u
@@ -62,16 +70,15 @@ template <> __device__ __forceinline__ void store8_64<bf16_t>(bf16_t* p, const f
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <class TI, class TO, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm64_kernel(Conv64Args a) {
+template <class TI, class TO, int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256, 2) void conv_igemm64_kernel(Conv64Args a) {  // >= 2 waves per SIMD: VGPR + AGPR <= 256
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert(WM * WN == 4, "4 waves");
     constexpr int A_PIECES = BM / 8 / 4, B_PIECES = BN / 8 / 4;  // 1-KiB LDS-DMA pieces per wave per K step
     constexpr int STAGE = (BM + BN) * 128;
-    constexpr int EPI_LD = TN * 32 + 4;
-    constexpr int EPI_BYTES = 4 * 32 * EPI_LD * 4;
-    constexpr int LDS_BYTES = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    static_assert(TN % 2 == 0, "epilogue works on pairs of 32-column tiles");
+    constexpr int EPI_LD = 64 + 4;  // floats per staged row: one pair of N tiles at a time
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // max(stages * STAGE, EPI_BYTES), see conv64_launch
 
     typedef typename Frag64<TI>::type frag_t;
     const osr_conv_params& p = a.p;
@@ -161,11 +168,58 @@ __global__ __launch_bounds__(256) void conv_igemm64_kernel(Conv64Args a) {
     const int swz = ((lane & 31) >> 1) & 7;
     const int nk = a.K / 64;
     C64_ISSUE(0);
+
+    // ---- epilogue operands that do not depend on the accumulators are fetched now, under the K loop:
+    //      this lane's bias values and (128x128 / 128x64 tiles) its residual segments, one 16-byte load per staged row ----
+    constexpr int RPP = 8, NPASS = 4;               // 8 lanes x 8 channels cover the 64 staged columns; 8 rows per pass
+    constexpr int TNP = TN / 2;                     // pairs of N tiles
+    constexpr bool PRE_RES = (TN == 2) && (EPI == 0);
+    const int cseg = (lane & 7) * 8;
+    const TI* __restrict__ res = reinterpret_cast<const TI*>(a.res);
+    float bias8[TNP][8];
+    frag_t rres[PRE_RES ? TM : 1][PRE_RES ? NPASS : 1];
+    if constexpr (EPI == 0) {
+#pragma unroll
+        for (int jp = 0; jp < TNP; ++jp) {
+            const int co = n0 + (wc * TN + jp * 2) * 32 + cseg;
+            const bool co_ok = co < p.cout;
+            const float4 b0 = co_ok ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 b1 = co_ok ? *reinterpret_cast<const float4*>(a.bias + co + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bias8[jp][0] = b0.x; bias8[jp][1] = b0.y; bias8[jp][2] = b0.z; bias8[jp][3] = b0.w;
+            bias8[jp][4] = b1.x; bias8[jp][5] = b1.y; bias8[jp][6] = b1.z; bias8[jp][7] = b1.w;
+        }
+        if constexpr (PRE_RES) {
+            if (p.res_mode != 0) {
+                const int co = n0 + wc * TN * 32 + cseg;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int pass = 0; pass < NPASS; ++pass) {
+                        const long long m = m0 + (wr * TM + i) * 32 + pass * RPP + (lane >> 3);
+                        const bool ok = m < a.M && co < p.cout;
+                        const long long mm = ok ? m : 0;
+                        const int nimg = (int)(mm / howo), rem = (int)(mm - (long long)nimg * howo);
+                        const int oh = rem / p.wo, ow = rem - oh * p.wo;
+                        const int rh = p.res_mode == 2 ? (oh >> 1) : oh, rw = p.res_mode == 2 ? (ow >> 1) : ow;
+                        const long long off = ok ? (long long)nimg * p.res_stride_n + (long long)rh * p.res_stride_h + (long long)rw * p.res_stride_w + co : 0ll;
+                        rres[i][pass] = *reinterpret_cast<const frag_t*>(res + off);
+                    }
+            }
+        }
+    }
+    float tbias[EPI == 1 ? TN : 1];
+    if constexpr (EPI == 1) {
+        // tail weights -> LDS (behind the staging / t-tile region); per-lane conv bias of its TN output columns
+        float* s_tw = reinterpret_cast<float*>(lds + a.tail_lds_off);
+        for (int i = tid; i < 5 * 256; i += 256) s_tw[i] = a.tail_w[i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) tbias[j] = a.bias[(wc * TN + j) * 32 + (lane & 31)];
+    }
     for (int ks = 0; ks < nk; ++ks) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // tile ks landed for every wave; every wave is done reading the other stage
-        if (ks + 1 < nk) { C64_ADVANCE(); C64_ISSUE((ks + 1) & 1); }
-        const unsigned char* sa = lds + (ks & 1) * STAGE;
+        if (a.two_stage && ks + 1 < nk) { C64_ADVANCE(); C64_ISSUE((ks + 1) & 1); }
+        const unsigned char* sa = lds + (a.two_stage ? (ks & 1) : 0) * STAGE;
         const unsigned char* sb = sa + BM * 128;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -180,72 +234,174 @@ __global__ __launch_bounds__(256) void conv_igemm64_kernel(Conv64Args a) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = Frag64<TI>::mfma(fa[i], fb[j], acc[i][j]);
         }
+        if (!a.two_stage && ks + 1 < nk) {
+            __syncthreads();  // every wave has read the single staging buffer: refill it
+            C64_ADVANCE();
+            C64_ISSUE(0);
+        }
     }
     __syncthreads();  // all waves done with the staging buffers before the epilogue reuses them
 
-    // ---- epilogue (same scheme as the BK=32 kernel): wave-private fp32 slab -> 8 channels per lane ----
+    if constexpr (EPI == 1) {
+        // ---- fused CF-RPN tail (classification_free_rpn.py:159-161): t = relu(conv + bias) is parked in LDS in the
+        // storage dtype (exactly what the unfused path writes to HBM), then two threads per pixel compute
+        // ||t||^2 and the five 1x1 dot products, normalise, add the 1x1 biases and apply the sigmoid. ----
+        constexpr int LDT = 256 + 8;  // elements per t row (528 B: 16-B aligned, conflict-free chunk walk)
+        TI* s_t = reinterpret_cast<TI*>(lds);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int col = (wc * TN + j) * 32 + (lane & 31);
+                    s_t[row * LDT + col] = (TI)fmaxf(acc[i][j][r] + tbias[j], 0.f);
+                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // a few accumulators at a time: keeps the VGPR budget of the K loop
+                }
+        __syncthreads();
+        const float* s_tw = reinterpret_cast<const float*>(lds + a.tail_lds_off);
+        const int row = tid >> 1, hf = tid & 1;
+        float ss = 0.f, d[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int k = 0; k < 16; ++k) {
+            const int ch = (2 * k + hf) * 8;  // the two threads of a pixel take alternate 16-byte chunks
+            const frag_t tv = *reinterpret_cast<const frag_t*>(s_t + row * LDT + ch);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = (float)tv[e];
+                ss = __builtin_fmaf(v, v, ss);
+#pragma unroll
+                for (int q = 0; q < 5; ++q) d[q] = __builtin_fmaf(v, s_tw[q * 256 + ch + e], d[q]);
+            }
+        }
+        ss += __shfl_xor(ss, 1, 64);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) d[q] += __shfl_xor(d[q], 1, 64);
+        const long long m = m0 + row;
+        if (hf == 0 && m < a.M) {
+            const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+            *reinterpret_cast<float4*>(a.tail_deltas + m * 4) = make_float4(d[0] * inv + a.tail_b[0], d[1] * inv + a.tail_b[1],
+                                                                            d[2] * inv + a.tail_b[2], d[3] * inv + a.tail_b[3]);
+            a.tail_ctr[m] = 1.0f / (1.0f + expf(-(d[4] * inv + a.tail_b[4])));
+        }
+        return;
+    }
+
+    // ---- epilogue: wave-private fp32 slab (32 rows x 64 columns, one pair of N tiles at a time) -> 8 channels per lane:
+    //      bias + residual / FPN 2x upsample-add + ReLU + convert on 16-byte row segments, coalesced along channels ----
     float* slab = reinterpret_cast<float*>(lds) + wid * 32 * EPI_LD;
     TO* __restrict__ out = reinterpret_cast<TO*>(a.out);
-    const TI* __restrict__ res = reinterpret_cast<const TI*>(a.res);
-    constexpr int LPR = TN * 4, RPP = 64 / LPR;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int jp = 0; jp < TNP; ++jp) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                slab[row * EPI_LD + j * 32 + (lane & 31)] = acc[i][j][r];
-            }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        const int cseg = (lane % LPR) * 8;
-        const int co = n0 + wc * TN * 32 + cseg;
+            for (int j2 = 0; j2 < 2; ++j2)
 #pragma unroll
-        for (int pass = 0; pass < 32 / RPP; ++pass) {
-            const int row = pass * RPP + lane / LPR;
-            const long long m = m0 + (wr * TM + i) * 32 + row;
-            if (m < a.M && co < p.cout) {
-                const float4 v0 = *reinterpret_cast<const float4*>(slab + row * EPI_LD + cseg);
-                const float4 v1 = *reinterpret_cast<const float4*>(slab + row * EPI_LD + cseg + 4);
-                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co);
-                const float4 b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
-                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-                v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-                const int nimg = (int)(m / howo), rem = (int)(m - (long long)nimg * howo);
-                const int oh = rem / p.wo, ow = rem - oh * p.wo;
-                if (p.res_mode != 0) {
-                    const int rh = p.res_mode == 2 ? (oh >> 1) : oh, rw = p.res_mode == 2 ? (ow >> 1) : ow;
-                    const frag_t rv = *reinterpret_cast<const frag_t*>(res + (long long)nimg * p.res_stride_n + (long long)rh * p.res_stride_h +
-                                                                        (long long)rw * p.res_stride_w + co);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    slab[row * EPI_LD + j2 * 32 + (lane & 31)] = acc[i][jp * 2 + j2][r];
                 }
-                if (p.relu) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            const int co = n0 + (wc * TN + jp * 2) * 32 + cseg;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int row = pass * RPP + (lane >> 3);
+                const long long m = m0 + (wr * TM + i) * 32 + row;
+                if (m < a.M && co < p.cout) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(slab + row * EPI_LD + cseg);
+                    const float4 v1 = *reinterpret_cast<const float4*>(slab + row * EPI_LD + cseg + 4);
+                    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bias8[jp][e];
+                    const int nimg = (int)(m / howo), rem = (int)(m - (long long)nimg * howo);
+                    const int oh = rem / p.wo, ow = rem - oh * p.wo;
+                    if (p.res_mode != 0) {
+                        if constexpr (PRE_RES) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += (float)rres[i][pass][e];
+                        } else {
+                            const int rh = p.res_mode == 2 ? (oh >> 1) : oh, rw = p.res_mode == 2 ? (ow >> 1) : ow;
+                            const frag_t rv = *reinterpret_cast<const frag_t*>(res + (long long)nimg * p.res_stride_n + (long long)rh * p.res_stride_h +
+                                                                                (long long)rw * p.res_stride_w + co);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                        }
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    store8_64<TO>(out + (long long)nimg * p.out_stride_n + (long long)oh * p.out_stride_h + (long long)ow * p.out_stride_w + co, v);
                 }
-                store8_64<TO>(out + (long long)nimg * p.out_stride_n + (long long)oh * p.out_stride_h + (long long)ow * p.out_stride_w + co, v);
             }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
     }
+}
+
+static size_t conv64_lds_bytes(int bm, int bn, int two_stage) {
+    const size_t stage = (size_t)(bm + bn) * 128, epi = (size_t)4 * 32 * 68 * 4;
+    const size_t stages = two_stage ? 2 * stage : stage;
+    return stages > epi ? stages : epi;
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+static int one_stage_max_nk() { static const int v = env_int("OSR_CONV_1STAGE_MAXNK", 40); return v; }
+static int wide_n_min_m() { static const int v = env_int("OSR_CONV_WIDE_MIN_M", 200000); return v; }
+
+template <class K>
+static void allow_big_lds(K kernel) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 template <class TI, class TO>
 static osr_status conv64_launch(Conv64Args& a, hipStream_t st) {
+    const int nk = a.K / 64;
+    // Few K steps: the layer is bound by memory latency and its epilogue traffic, so trade the second staging buffer
+    // for more resident workgroups per CU. Many K steps: double buffer.
+    a.two_stage = nk > one_stage_max_nk() ? 1 : 0;
+    a.tail_lds_off = 0;
+    a.tiles_m = (int)((a.M + 127) / 128);
     if (a.p.cout <= 64) {
-        a.tiles_m = (int)((a.M + 127) / 128);
         a.tiles_n = (a.p.cout + 63) / 64;
-        hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 128, 64, 4, 1>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 128, 64, 4, 1, 0>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(256),
+                           conv64_lds_bytes(128, 64, a.two_stage), st, a);
+    } else if (a.p.cout == 256 && a.p.res_mode == 0 && nk >= 8 && !a.two_stage && a.M >= wide_n_min_m()) {
+        // 128 x 256 tiles for the big 256-channel layers (FPN output convs): the gathered activation rows are fetched once
+        a.tiles_n = a.p.cout / 256;
+        static thread_local bool attr = false;
+        if (!attr) { allow_big_lds(conv_igemm64_kernel<TI, TO, 128, 256, 2, 2, 0>); attr = true; }
+        hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 128, 256, 2, 2, 0>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(256),
+                           conv64_lds_bytes(128, 256, a.two_stage), st, a);
     } else {
-        a.tiles_m = (int)((a.M + 127) / 128);
         a.tiles_n = (a.p.cout + 127) / 128;
-        hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 128, 128, 2, 2>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 128, 128, 2, 2, 0>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(256),
+                           conv64_lds_bytes(128, 128, a.two_stage), st, a);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { osr_set_error("osr_conv2d_fwd(bk64): launch failed: %s", hipGetErrorString(e)); return OSR_ERR_LAUNCH; }
+    return OSR_OK;
+}
+
+template <class TI>
+static osr_status cfrpn_fused_launch(Conv64Args& a, hipStream_t st) {
+    a.two_stage = 0;
+    a.tiles_m = (int)((a.M + 127) / 128);
+    a.tiles_n = 1;
+    const size_t t_bytes = (size_t)128 * (256 + 8) * 2, stage = (size_t)(128 + 256) * 128;
+    a.tail_lds_off = (int)(t_bytes > stage ? t_bytes : stage);
+    const size_t lds = (size_t)a.tail_lds_off + 5 * 256 * 4;
+    static thread_local bool attr = false;
+    if (!attr) { allow_big_lds(conv_igemm64_kernel<TI, TI, 128, 256, 2, 2, 1>); attr = true; }
+    hipLaunchKernelGGL((conv_igemm64_kernel<TI, TI, 128, 256, 2, 2, 1>), dim3((unsigned)a.tiles_m), dim3(256), lds, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { osr_set_error("osr_cfrpn_head_fwd: launch failed: %s", hipGetErrorString(e)); return OSR_ERR_LAUNCH; }
     return OSR_OK;
 }
 
@@ -266,6 +422,7 @@ osr_status osr_conv64_run(const osr_conv_params* p, const void* in, const void* 
     a.in_bytes = (unsigned)in_bytes; a.w_bytes = (unsigned)w_bytes;
     a.stem = (p->pad_mode == 1 && p->cin == 32) ? 1 : 0;
     a.tiles_m = a.tiles_n = 0;
+    a.tail_w = a.tail_b = nullptr; a.tail_deltas = a.tail_ctr = nullptr;
     if (p->in_dtype == OSR_F16) {
         if (p->out_dtype == OSR_F16) return conv64_launch<f16_t, f16_t>(a, st);
         if (p->out_dtype == OSR_F32) return conv64_launch<f16_t, float>(a, st);
@@ -275,4 +432,34 @@ osr_status osr_conv64_run(const osr_conv_params* p, const void* in, const void* 
     }
     osr_set_error("osr_conv2d_fwd: out_dtype must equal in_dtype or be f32");
     return OSR_ERR_UNSUPPORTED;
+}
+
+// Whole ClsFreeRPNHead.forward for one level (3x3 conv + ReLU + channel L2-normalise + two 1x1 convs + sigmoid) in one
+// launch; deltas/ctr are written at pixel index n*ho*wo + oh*wo + ow. Returns OSR_ERR_UNSUPPORTED when the shape is
+// outside the fused kernel's envelope (the caller then runs osr_conv2d_fwd + osr_cfrpn_head_tail).
+extern "C" osr_status osr_cfrpn_head_fwd(const osr_conv_params* p, const void* in, const void* weight, const float* bias,
+                                         const float* w_tail, const float* b_tail, float* deltas, float* ctr, void* stream) {
+    OSR_REQUIRE(p && in && weight && bias && w_tail && b_tail && deltas && ctr, OSR_ERR_INVALID_ARG, "osr_cfrpn_head_fwd: null pointer");
+    OSR_REQUIRE(p->cout == 256 && p->cin % 64 == 0 && p->pad_mode == 0 && p->res_mode == 0, OSR_ERR_UNSUPPORTED,
+                "osr_cfrpn_head_fwd: fused path needs cout == 256, cin %% 64 == 0, no residual");
+    OSR_REQUIRE(p->in_dtype == OSR_F16 || p->in_dtype == OSR_BF16, OSR_ERR_UNSUPPORTED, "osr_cfrpn_head_fwd: in_dtype must be f16/bf16");
+    OSR_REQUIRE(p->n >= 1 && p->hi >= 1 && p->wi >= 1 && p->kh >= 1 && p->kw >= 1 && p->kh <= 16 && p->kw <= 16 && p->stride_h >= 1 && p->stride_w >= 1 &&
+                    p->pad_h >= 0 && p->pad_w >= 0, OSR_ERR_INVALID_ARG, "osr_cfrpn_head_fwd: bad geometry");
+    OSR_REQUIRE((p->hi + 2 * p->pad_h - p->kh) / p->stride_h + 1 == p->ho && (p->wi + 2 * p->pad_w - p->kw) / p->stride_w + 1 == p->wo,
+                OSR_ERR_INVALID_ARG, "osr_cfrpn_head_fwd: ho/wo inconsistent with hi/wi/kernel/stride/pad");
+    OSR_REQUIRE(p->in_stride_w % 8 == 0 && p->in_stride_h % 8 == 0 && p->in_stride_n % 8 == 0 && p->in_stride_n > 0, OSR_ERR_INVALID_ARG,
+                "osr_cfrpn_head_fwd: input strides must be multiples of 8 elements");
+    OSR_REQUIRE((((uintptr_t)in | (uintptr_t)weight | (uintptr_t)bias | (uintptr_t)deltas) & 15) == 0, OSR_ERR_INVALID_ARG,
+                "osr_cfrpn_head_fwd: pointers must be 16-byte aligned");
+    const long long in_bytes = (long long)p->n * p->in_stride_n * 2, w_bytes = (long long)p->cout * p->kh * p->kw * p->cin * 2;
+    OSR_REQUIRE(osr_conv64_eligible(p, in_bytes, w_bytes), OSR_ERR_UNSUPPORTED, "osr_cfrpn_head_fwd: tensor too large for 32-bit buffer offsets");
+    Conv64Args a;
+    a.p = *p; a.in = in; a.w = weight; a.bias = bias; a.res = nullptr; a.out = nullptr;
+    a.M = (long long)p->n * p->ho * p->wo;
+    a.K = p->kh * p->kw * p->cin;
+    a.in_bytes = (unsigned)in_bytes; a.w_bytes = (unsigned)w_bytes;
+    a.stem = 0;
+    a.tail_w = w_tail; a.tail_b = b_tail; a.tail_deltas = deltas; a.tail_ctr = ctr;
+    hipStream_t st = (hipStream_t)stream;
+    return p->in_dtype == OSR_F16 ? cfrpn_fused_launch<f16_t>(a, st) : cfrpn_fused_launch<bf16_t>(a, st);
 }

@@ -66,6 +66,9 @@ class OpensetRCNNEngine:
             self.rpn_bd = f32("proposal_generator.rpn_head.anchor_deltas.bias")
             self.rpn_wc = f32("proposal_generator.rpn_head.centerness.weight").view(1, 256)
             self.rpn_bc = f32("proposal_generator.rpn_head.centerness.bias")
+            self.rpn_wtail = torch.cat((self.rpn_wd, self.rpn_wc)).contiguous()
+            self.rpn_btail = torch.cat((self.rpn_bd, self.rpn_bc)).contiguous()
+            self.fuse_rpn_head = True
             sizes = c["anchor_sizes"]
             self.cell_anchors = torch.tensor([[[-s / 2.0, -s / 2.0, s / 2.0, s / 2.0]] for s in sizes], dtype=torch.float32, device=dev)
         if not self.has_roi:
@@ -143,6 +146,18 @@ class OpensetRCNNEngine:
             keep.update(feats)
         return out
 
+    def _rpn_level_fused(self, f, deltas, ctr):
+        w, b = self.w["proposal_generator.rpn_head.conv.w"], self.w["proposal_generator.rpn_head.conv.b"]
+        if self.profile is None:
+            return ops.cfrpn_head_fused(f, w, b, self.rpn_wtail, self.rpn_btail, deltas, ctr)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.cfrpn_head_fused(f, w, b, self.rpn_wtail, self.rpn_btail, deltas, ctr)
+        e1.record()
+        rows = deltas.shape[0]
+        self.profile.append(("proposal_generator.rpn_head.conv+tail", 2.0 * rows * 256 * (2304 + 5), e0, e1,
+                             f.numel() * 2 + w.numel() * 2 + rows * 20))
+
     # ---- CF-RPN ---------------------------------------------------------------------------------------------
     def _levels(self, shapes, n):
         key = (tuple(shapes), n)
@@ -155,12 +170,22 @@ class OpensetRCNNEngine:
         n = fl[0].shape[0]
         shapes = [(f.shape[1], f.shape[2]) for f in fl]
         rows = [n * h * w for h, w in shapes]
-        t_all = torch.empty((sum(rows), 256), dtype=self.dtype, device=self.device)
-        off = 0
-        for f, r in zip(fl, rows):
-            self._conv(f, "proposal_generator.rpn_head.conv", 1, 1, relu=True, out=t_all[off:off + r])
-            off += r
-        deltas, ctr = ops.cfrpn_head_tail(t_all, self.rpn_wd, self.rpn_bd, self.rpn_wc, self.rpn_bc)
+        if self.fuse_rpn_head:
+            # one launch per level: 3x3 conv + ReLU + normalise + both 1x1 + sigmoid, hidden state never leaves the chip
+            deltas = torch.empty((sum(rows), 4), dtype=torch.float32, device=self.device)
+            ctr = torch.empty((sum(rows),), dtype=torch.float32, device=self.device)
+            t_all = None
+            off = 0
+            for f, r in zip(fl, rows):
+                self._rpn_level_fused(f, deltas[off:off + r], ctr[off:off + r])
+                off += r
+        else:
+            t_all = torch.empty((sum(rows), 256), dtype=self.dtype, device=self.device)
+            off = 0
+            for f, r in zip(fl, rows):
+                self._conv(f, "proposal_generator.rpn_head.conv", 1, 1, relu=True, out=t_all[off:off + r])
+                off += r
+            deltas, ctr = ops.cfrpn_head_tail(t_all, self.rpn_wd, self.rpn_bd, self.rpn_wc, self.rpn_bc)
         sel = ops.rpn_select(self._levels(shapes, n), self.cell_anchors, ctr, deltas, n, image_hw, self.cfg["pre_nms_topk_test"],
                              self.cfg["min_box_size"])
         if keep is not None:

@@ -223,8 +223,8 @@ class ClsFreeRPNHead(_EngineOwner):
         deltas, ctrs = [], []
         for x in features:
             n, _, h, w = x.shape
-            t = eng._conv(_to_nhwc(x, eng.dtype), "proposal_generator.rpn_head.conv", 1, 1, relu=True)
-            d, c = ops.cfrpn_head_tail(t.view(-1, t.shape[-1]), eng.rpn_wd, eng.rpn_bd, eng.rpn_wc, eng.rpn_bc)
+            d, c = ops.cfrpn_head_fused(_to_nhwc(x, eng.dtype), eng.w["proposal_generator.rpn_head.conv.w"],
+                                        eng.w["proposal_generator.rpn_head.conv.b"], eng.rpn_wtail, eng.rpn_btail)
             deltas.append(d.view(n, h, w, 4).permute(0, 3, 1, 2))
             ctrs.append(c.view(n, h, w, 1).permute(0, 3, 1, 2))
         return deltas, ctrs

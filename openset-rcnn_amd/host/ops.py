@@ -169,6 +169,32 @@ def cfrpn_head_tail(t: torch.Tensor, w_delta, b_delta, w_ctr, b_ctr) -> Tuple[to
     return deltas, ctr
 
 
+def cfrpn_head_fused(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, w_tail: torch.Tensor, b_tail: torch.Tensor,
+                     deltas_out: Optional[torch.Tensor] = None, ctr_out: Optional[torch.Tensor] = None):
+    """ClsFreeRPNHead.forward for one level in one launch. x (n,h,w,256) f16/bf16, weight (256,3,3,256) packed,
+    w_tail (5,256) fp32 [deltas rows 0-3, centerness row 4], b_tail (5). Returns deltas (n*h*w, 4), ctr (n*h*w)."""
+    lib = _lib.load()
+    _need(x, name="x"); _need(weight, x.dtype, "weight"); _need(bias, torch.float32, "bias")
+    _need(w_tail, torch.float32, "w_tail"); _need(b_tail, torch.float32, "b_tail")
+    n, hi, wi, cin = x.shape
+    cout, kh, kw, _ = weight.shape
+    pad = kh // 2
+    rows = n * hi * wi
+    deltas = deltas_out if deltas_out is not None else torch.empty((rows, 4), dtype=torch.float32, device=x.device)
+    ctr = ctr_out if ctr_out is not None else torch.empty((rows,), dtype=torch.float32, device=x.device)
+    _need(deltas, torch.float32, "deltas"); _need(ctr, torch.float32, "ctr")
+    assert deltas.numel() == rows * 4 and ctr.numel() == rows
+    p = ConvParams()
+    p.n, p.hi, p.wi, p.cin, p.ho, p.wo, p.cout = n, hi, wi, cin, hi, wi, cout
+    p.kh, p.kw, p.stride_h, p.stride_w, p.pad_h, p.pad_w = kh, kw, 1, 1, pad, pad
+    p.in_stride_n, p.in_stride_h, p.in_stride_w = hi * wi * cin, wi * cin, cin
+    p.relu, p.res_mode, p.pad_mode = 1, 0, 0
+    p.in_dtype = p.out_dtype = _DT[x.dtype]
+    check(lib.osr_cfrpn_head_fwd(C.byref(p), _p(x), _p(weight), _p(bias), _p(w_tail), _p(b_tail), _p(deltas), _p(ctr), _stream()),
+          "osr_cfrpn_head_fwd")
+    return deltas, ctr
+
+
 def make_rpn_levels(shapes: Sequence[Tuple[int, int]], strides: Sequence[int], n: int, num_anchors: int = 1) -> RpnLevels:
     lv = RpnLevels()
     lv.num_levels, lv.num_anchors = len(shapes), num_anchors

@@ -456,3 +456,26 @@ def test_softmax_candidates_nms_assemble_vs_oracle(ops):
         assert torch.equal(ob[i, :c].cpu(), rb)
         nu = int((rc == 80).sum())
         assert bool((rc[:nu] == 80).all()) and bool((rc[nu:] != 80).all())  # [unknown..., known...]
+
+
+def test_cfrpn_head_fused_matches_two_step_and_oracle(ops):
+    """Fused ClsFreeRPNHead level (one launch) == conv + tail (two launches) == oracle on fp16-rounded operands."""
+    gg = g(51)
+    p = O.make_head_params(4)
+    x = (torch.randn(2, 256, 21, 29, generator=gg)).half()
+    w = p["proposal_generator.rpn_head.conv.weight"].half()
+    b = torch.randn(256, generator=gg) * 0.1
+    wt = torch.cat((p["proposal_generator.rpn_head.anchor_deltas.weight"].view(4, 256), p["proposal_generator.rpn_head.centerness.weight"].view(1, 256)))
+    bt = torch.cat((p["proposal_generator.rpn_head.anchor_deltas.bias"], p["proposal_generator.rpn_head.centerness.bias"]))
+    xd, wd = nhwc(x).to(DEV), w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    d_f, c_f = ops.cfrpn_head_fused(xd, wd, b.to(DEV), wt.to(DEV), bt.to(DEV))
+    t = ops.conv2d(xd, wd, b.to(DEV), 1, 1, relu=True)
+    d_u, c_u = ops.cfrpn_head_tail(t.view(-1, 256), wt[:4].contiguous().to(DEV), bt[:4].contiguous().to(DEV), wt[4:].contiguous().to(DEV),
+                                   bt[4:].contiguous().to(DEV))
+    assert_close(d_f, d_u, rtol=1e-4, atol=1e-5, name="fused vs two-step deltas")
+    assert_close(c_f, c_u, rtol=1e-4, atol=1e-6, name="fused vs two-step ctr")
+    tq = F.relu(F.conv2d(x.float(), w.float(), b, padding=1)).half().float()  # hidden state rounded to the storage dtype
+    pq = dict(p)
+    dr, cr = O.cfrpn_head_tail(tq.permute(0, 2, 3, 1).reshape(-1, 256), pq)
+    assert_close(d_f, dr, rtol=2e-3, atol=2e-3, name="fused vs oracle deltas")  # 1 fp16 ulp flips of t before the normalise
+    assert_close(c_f, cr, rtol=2e-3, atol=1e-3, name="fused vs oracle ctr")
