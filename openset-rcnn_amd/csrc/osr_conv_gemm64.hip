@@ -71,10 +71,11 @@ template <> __device__ __forceinline__ void store8_64<bf16_t>(bf16_t* p, const f
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 template <class TI, class TO, int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_igemm64_kernel(Conv64Args a) {  // >= 2 waves per SIMD: VGPR + AGPR <= 256
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Args a) {  // >= 2 waves per SIMD: VGPR + AGPR <= 256
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    static_assert(WM * WN == 4, "4 waves");
-    constexpr int A_PIECES = BM / 8 / 4, B_PIECES = BN / 8 / 4;  // 1-KiB LDS-DMA pieces per wave per K step
+    constexpr int NW = WM * WN, NT = NW * 64;  // waves / threads per workgroup (4 or 8 waves)
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    constexpr int A_PIECES = BM / 8 / NW, B_PIECES = BN / 8 / NW;  // 1-KiB LDS-DMA pieces per wave per K step
     constexpr int STAGE = (BM + BN) * 128;
     static_assert(TN % 2 == 0, "epilogue works on pairs of 32-column tiles");
     constexpr int EPI_LD = 64 + 4;  // floats per staged row: one pair of N tiles at a time
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm64_kernel(Conv64Args a) {  /
     //      this lane's bias values and (128x128 / 128x64 tiles) its residual segments, one 16-byte load per staged row ----
     constexpr int RPP = 8, NPASS = 4;               // 8 lanes x 8 channels cover the 64 staged columns; 8 rows per pass
     constexpr int TNP = TN / 2;                     // pairs of N tiles
-    constexpr bool PRE_RES = (TN == 2) && (EPI == 0);
+    constexpr bool PRE_RES = (TN == 2) && (TM <= 2) && (EPI == 0);
     const int cseg = (lane & 7) * 8;
     const TI* __restrict__ res = reinterpret_cast<const TI*>(a.res);
     float bias8[TNP][8];
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm64_kernel(Conv64Args a) {  /
     if constexpr (EPI == 1) {
         // tail weights -> LDS (behind the staging / t-tile region); per-lane conv bias of its TN output columns
         float* s_tw = reinterpret_cast<float*>(lds + a.tail_lds_off);
-        for (int i = tid; i < 5 * 256; i += 256) s_tw[i] = a.tail_w[i];
+        for (int i = tid; i < 5 * 256; i += NT) s_tw[i] = a.tail_w[i];
 #pragma unroll
         for (int j = 0; j < TN; ++j) tbias[j] = a.bias[(wc * TN + j) * 32 + (lane & 31)];
     }
@@ -221,19 +222,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm64_kernel(Conv64Args a) {  /
         if (a.two_stage && ks + 1 < nk) { C64_ADVANCE(); C64_ISSUE((ks + 1) & 1); }
         const unsigned char* sa = lds + (a.two_stage ? (ks & 1) : 0) * STAGE;
         const unsigned char* sb = sa + BM * 128;
+        // fragment reads are software-pipelined one 16-wide K slice ahead of the MFMAs that consume them
+        frag_t fa[2][TM], fb[2][TN];
+#define C64_LOAD_FRAGS(set, kk_)                                                                                                    \
+        {                                                                                                                           \
+            const int sl_ = (((kk_) * 2 + (lane >> 5)) ^ swz) * 16;                                                                 \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                          \
+                fa[set][i] = *reinterpret_cast<const frag_t*>(sa + ((wr * TM + i) * 32 + (lane & 31)) * 128 + sl_);                 \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                          \
+                fb[set][j] = *reinterpret_cast<const frag_t*>(sb + ((wc * TN + j) * 32 + (lane & 31)) * 128 + sl_);                 \
+        }
+        C64_LOAD_FRAGS(0, 0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const int sl = ((kk * 2 + (lane >> 5)) ^ swz) * 16;
-            frag_t fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const frag_t*>(sa + ((wr * TM + i) * 32 + (lane & 31)) * 128 + sl);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const frag_t*>(sb + ((wc * TN + j) * 32 + (lane & 31)) * 128 + sl);
+            if (kk < 3) C64_LOAD_FRAGS((kk + 1) & 1, kk + 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = Frag64<TI>::mfma(fa[i], fb[j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = Frag64<TI>::mfma(fa[kk & 1][i], fb[kk & 1][j], acc[i][j]);
         }
+#undef C64_LOAD_FRAGS
         if (!a.two_stage && ks + 1 < nk) {
             __syncthreads();  // every wave has read the single staging buffer: refill it
             C64_ADVANCE();
@@ -261,6 +269,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm64_kernel(Conv64Args a) {  /
                 }
         __syncthreads();
         const float* s_tw = reinterpret_cast<const float*>(lds + a.tail_lds_off);
+        static_assert(EPI == 0 || NT == 2 * BM, "two threads per pixel");
         const int row = tid >> 1, hf = tid & 1;
         float ss = 0.f, d[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -342,8 +351,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm64_kernel(Conv64Args a) {  /
     }
 }
 
-static size_t conv64_lds_bytes(int bm, int bn, int two_stage) {
-    const size_t stage = (size_t)(bm + bn) * 128, epi = (size_t)4 * 32 * 68 * 4;
+static size_t conv64_lds_bytes(int bm, int bn, int two_stage, int nw = 4) {
+    const size_t stage = (size_t)(bm + bn) * 128, epi = (size_t)nw * 32 * 68 * 4;
     const size_t stages = two_stage ? 2 * stage : stage;
     return stages > epi ? stages : epi;
 }
@@ -353,6 +362,8 @@ static int env_int(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 static int one_stage_max_nk() { static const int v = env_int("OSR_CONV_1STAGE_MAXNK", 40); return v; }
+static int big_tile_min_nk() { static const int v = env_int("OSR_CONV_BIG_MIN_NK", 8); return v; }
+static int big_tile_min_tiles() { static const int v = env_int("OSR_CONV_BIG_MIN_TILES", 768); return v; }
 static int wide_n_min_m() { static const int v = env_int("OSR_CONV_WIDE_MIN_M", 200000); return v; }
 
 template <class K>
@@ -368,7 +379,17 @@ static osr_status conv64_launch(Conv64Args& a, hipStream_t st) {
     a.two_stage = nk > one_stage_max_nk() ? 1 : 0;
     a.tail_lds_off = 0;
     a.tiles_m = (int)((a.M + 127) / 128);
-    if (a.p.cout <= 64) {
+    if (a.p.cout % 256 == 0 && a.p.res_mode == 0 && nk >= big_tile_min_nk() && (a.M + 255) / 256 * (a.p.cout / 256) >= big_tile_min_tiles()) {
+        // 256 x 256 tiles, 8 waves, double buffer (128 KB LDS, one workgroup per CU): 175 FLOP per staged byte, needed
+        // because the L2 -> LDS fill rate (~70 GB/s per CU), not the matrix pipe, bounds the 128 x 128 tiles
+        a.two_stage = 1;
+        a.tiles_m = (int)((a.M + 255) / 256);
+        a.tiles_n = a.p.cout / 256;
+        static thread_local bool attr = false;
+        if (!attr) { allow_big_lds(conv_igemm64_kernel<TI, TO, 256, 256, 2, 4, 0>); attr = true; }
+        hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 256, 256, 2, 4, 0>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(512),
+                           conv64_lds_bytes(256, 256, 1, 8), st, a);
+    } else if (a.p.cout <= 64) {
         a.tiles_n = (a.p.cout + 63) / 64;
         hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 128, 64, 4, 1, 0>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(256),
                            conv64_lds_bytes(128, 64, a.two_stage), st, a);
@@ -391,9 +412,22 @@ static osr_status conv64_launch(Conv64Args& a, hipStream_t st) {
 
 template <class TI>
 static osr_status cfrpn_fused_launch(Conv64Args& a, hipStream_t st) {
+    a.tiles_n = 1;
+    if ((a.M + 255) / 256 >= big_tile_min_tiles() && a.K / 64 >= big_tile_min_nk()) {
+        a.two_stage = 1;
+        a.tiles_m = (int)((a.M + 255) / 256);
+        const size_t t_bytes = (size_t)256 * (256 + 8) * 2, stages = (size_t)2 * (256 + 256) * 128;
+        a.tail_lds_off = (int)(t_bytes > stages ? t_bytes : stages);
+        const size_t lds = (size_t)a.tail_lds_off + 5 * 256 * 4;
+        static thread_local bool attr8 = false;
+        if (!attr8) { allow_big_lds(conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1>); attr8 = true; }
+        hipLaunchKernelGGL((conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1>), dim3((unsigned)a.tiles_m), dim3(512), lds, st, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { osr_set_error("osr_cfrpn_head_fwd: launch failed: %s", hipGetErrorString(e)); return OSR_ERR_LAUNCH; }
+        return OSR_OK;
+    }
     a.two_stage = 0;
     a.tiles_m = (int)((a.M + 127) / 128);
-    a.tiles_n = 1;
     const size_t t_bytes = (size_t)128 * (256 + 8) * 2, stage = (size_t)(128 + 256) * 128;
     a.tail_lds_off = (int)(t_bytes > stage ? t_bytes : stage);
     const size_t lds = (size_t)a.tail_lds_off + 5 * 256 * 4;
