@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-iters", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=2, help="micro-batch streams inside one GPU (1 = single stream)")
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage breakdown to stderr")
     ap.add_argument("--layers", action="store_true", help="also print every MFMA launch (time, TFLOP/s, GB/s) to stderr")
     args = ap.parse_args()
@@ -108,7 +110,16 @@ def main():
     image_hw = torch.tensor([(800, 1333)] * args.batch, dtype=torch.int32, device=eng.device)
 
     def step():
+        if args.streams > 1:
+            return eng.forward_device_streams(images, image_hw, 800, 1344, args.streams)
         return eng.forward_device(images, image_hw, 800, 1344)
+
+    if args.graph:
+        graph, gout = eng.capture(images, image_hw, 800, 1344, args.streams)
+
+        def step():  # noqa: F811  one hipGraph launch replays the whole pass
+            graph.replay()
+            return gout
 
     for _ in range(args.warmup):
         out = step()
@@ -132,7 +143,7 @@ def main():
 
     # ---- roofline of the dominant kernel family, measured live with HIP events on the launch stream ----
     eng.profile = []
-    step()
+    eng.forward_device(images, image_hw, 800, 1344)  # attribution pass: one stream, so each launch can be bracketed
     torch.cuda.synchronize()
     prof = eng.profile
     eng.profile = None
@@ -168,7 +179,8 @@ def main():
             "config": {"workload": "VOC-COCO openset_rcnn_R50_FPN_128k.yaml, inference-only, 3x800x1333 uint8 BGR -> padded 800x1344, "
                                    "1000 proposals/level (4273/img), 1000 dets/img, 50+50 final",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world} (images sharded, no collective)",
-                       "weights": "random-init (seed 0), FrozenBN folded", "detections_last_step": n_det},
+                       "weights": "random-init (seed 0), FrozenBN folded", "detections_last_step": n_det,
+                       "micro_batch_streams": args.streams, "hipgraph": bool(args.graph)},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -364,6 +364,7 @@ static int env_int(const char* name, int dflt) {
 static int one_stage_max_nk() { static const int v = env_int("OSR_CONV_1STAGE_MAXNK", 40); return v; }
 static int big_tile_min_nk() { static const int v = env_int("OSR_CONV_BIG_MIN_NK", 8); return v; }
 static int big_tile_min_tiles() { static const int v = env_int("OSR_CONV_BIG_MIN_TILES", 768); return v; }
+static int small_grid_blocks() { static const int v = env_int("OSR_CONV_SMALL_GRID", 768); return v; }
 static int wide_n_min_m() { static const int v = env_int("OSR_CONV_WIDE_MIN_M", 200000); return v; }
 
 template <class K>
@@ -379,6 +380,12 @@ static osr_status conv64_launch(Conv64Args& a, hipStream_t st) {
     a.two_stage = nk > one_stage_max_nk() ? 1 : 0;
     a.tail_lds_off = 0;
     a.tiles_m = (int)((a.M + 127) / 128);
+    {
+        // a grid too small to put 3-4 workgroups on every CU cannot hide the staging latency by occupancy:
+        // overlap it inside the workgroup instead (double buffer)
+        const long long nblk = (long long)a.tiles_m * ((a.p.cout + 127) / 128);
+        if (nk >= 2 && nblk < small_grid_blocks()) a.two_stage = 1;
+    }
     if (a.p.cout % 256 == 0 && a.p.res_mode == 0 && nk >= big_tile_min_nk() && (a.M + 255) / 256 * (a.p.cout / 256) >= big_tile_min_tiles()) {
         // 256 x 256 tiles, 8 waves, double buffer (128 KB LDS, one workgroup per CU): 175 FLOP per staged byte, needed
         // because the L2 -> LDS fill rate (~70 GB/s per CU), not the matrix pipe, bounds the 128 x 128 tiles

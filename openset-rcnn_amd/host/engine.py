@@ -60,6 +60,7 @@ class OpensetRCNNEngine:
         self.w = w
         self.class_map = None if class_map is None else class_map.to(torch.int64).to(dev)
         self._lv_cache = {}
+        self._streams = []
         self.profile = None  # set to a list to collect (name, algorithmic flops, start event, end event) per MFMA launch
         if self.has_rpn:
             self.rpn_wd = f32("proposal_generator.rpn_head.anchor_deltas.weight").view(-1, 256)
@@ -246,6 +247,56 @@ class OpensetRCNNEngine:
         if keep is not None:
             keep.update(feats=feats, sel=sel)
         return self._roi_heads(feats, sel, image_hw, keep)
+
+    def forward_device_streams(self, images, image_hw, hp, wp, nstreams: int = 4):
+        """Same result as forward_device, with the batch split into `nstreams` contiguous micro-batches that run the
+        whole path concurrently on separate HIP streams. Images are independent, so this is data parallelism inside
+        one GPU: while one micro-batch's kernel drains its last, sparsely occupied wave of workgroups, the other
+        streams' kernels fill the idle CUs (the layers of res4/res5/FPN have too few tiles to cover 256 CUs evenly)."""
+        n = images.shape[0]
+        ns = max(1, min(nstreams, n))
+        if ns == 1:
+            return self.forward_device(images, image_hw, hp, wp)
+        while len(self._streams) < ns:
+            self._streams.append(torch.cuda.Stream(device=self.device))
+        cur = torch.cuda.current_stream(self.device)
+        start = torch.cuda.Event()
+        start.record(cur)
+        outs = []
+        base, extra = divmod(n, ns)
+        lo = 0
+        for i in range(ns):
+            hi = lo + base + (1 if i < extra else 0)
+            st = self._streams[i]
+            st.wait_event(start)
+            with torch.cuda.stream(st):
+                o = self.forward_device(images[lo:hi], image_hw[lo:hi], hp, wp)
+                done = torch.cuda.Event()
+                done.record(st)
+            if not torch.cuda.is_current_stream_capturing():
+                for t in o:
+                    t.record_stream(cur)
+            cur.wait_event(done)
+            outs.append(o)
+            lo = hi
+        return tuple(torch.cat([o[k] for o in outs]) for k in range(4))
+
+    def capture(self, images, image_hw, hp, wp, nstreams: int = 1):
+        """Capture one whole pass (all micro-batch streams, ~110 launches each) into a hipGraph. Returns (graph, outputs):
+        `graph.replay()` re-runs the pass on the same input buffers and refreshes `outputs` in place. The path has no
+        host syncs, no host-side shape decisions and fixed-capacity outputs, so it is capturable as is; replay removes
+        the per-launch host cost, which otherwise bounds the step once several streams are in play."""
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):  # warm-up outside capture: lazy one-time work (func attributes, allocator pools)
+                self.forward_device_streams(images, image_hw, hp, wp, nstreams)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.forward_device_streams(images, image_hw, hp, wp, nstreams)
+        return graph, out
 
     @staticmethod
     def to_instances(result, n: int) -> List[dict]:

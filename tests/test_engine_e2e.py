@@ -181,3 +181,35 @@ def test_engine_is_deterministic(run):
     b = eng.forward(run["images"].to(DEV), run["sizes"])
     for x, y, z in zip(a, b, run["out"]):
         assert torch.equal(x, y) and torch.equal(x, z)
+
+
+def test_micro_batch_streams_give_the_same_detections(run):
+    """Splitting the batch over HIP streams is pure intra-GPU data parallelism: per-image results do not change."""
+    eng = run["eng"]
+    imgs = torch.cat([run["images"], run["images"].flip(0)]).to(DEV)  # 4 images
+    hw = torch.tensor(run["sizes"] + run["sizes"][::-1], dtype=torch.int32, device=DEV)
+    a = eng.forward_device(imgs, hw, 256, 352)
+    b = eng.forward_device_streams(imgs, hw, 256, 352, nstreams=2)
+    c = eng.forward_device_streams(imgs, hw, 256, 352, nstreams=4)
+    torch.cuda.synchronize()
+    for x, y, z in zip(a, b, c):
+        assert torch.equal(x, y) and torch.equal(x, z)
+
+
+def test_hipgraph_replay_matches_eager(run):
+    eng = run["eng"]
+    imgs = torch.cat([run["images"], run["images"].flip(0)]).to(DEV)
+    hw = torch.tensor(run["sizes"] + run["sizes"][::-1], dtype=torch.int32, device=DEV)
+    eager = [t.clone() for t in eng.forward_device(imgs, hw, 256, 352)]
+    graph, out = eng.capture(imgs, hw, 256, 352, nstreams=2)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    for x, y in zip(eager, out):
+        assert torch.equal(x, y)
+    imgs.copy_(imgs.flip(0))  # new content in the captured input buffer -> replay follows it
+    graph.replay()
+    torch.cuda.synchronize()
+    ref = eng.forward_device(imgs, hw, 256, 352)
+    for x, y in zip(ref, out):
+        assert torch.equal(x, y)
