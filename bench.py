@@ -151,7 +151,17 @@ def main():
     mfma_flops = sum(f for _, f, _, _, _ in prof)
     achieved = mfma_flops / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
     peak = MFMA_PEAK_TFLOPS[args.dtype]
-    roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=None,
+    # HBM-side traffic of the same kernel family: PMC counters cannot be read from inside the process, so the value is
+    # the one collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x2 per the gfx950
+    # guide) on this very command and committed under profiles/; null when that file is absent.
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
+    if os.path.exists(tfile):
+        with open(tfile) as fh:
+            traffic = {"GB_per_step": json.load(fh).get("conv_family_GB_per_step"), "source": "profiles/r01_c_pmc_traffic.json"}
+    algo_bytes = sum(nb for _, _, _, _, nb in prof)
+    roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic,
+                    algorithmic_GB_per_step=round(algo_bytes / 1e9, 2),
                     kernel="conv_igemm_kernel (implicit-GEMM conv + FC)", launches_per_step=len(prof),
                     flops_per_step=mfma_flops, kernel_ms_per_step=round(mfma_ms, 3))
     if args.layers and rank == 0:
