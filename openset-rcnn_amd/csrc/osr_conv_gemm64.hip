@@ -14,6 +14,10 @@
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef C64_M16
+#define C64_M16 1  // 1: v_mfma_f32_16x16x32 (four per 32x32 macro tile and 32-wide K step), 0: v_mfma_f32_32x32x16
+#endif
 typedef f16_t f16x8 __attribute__((ext_vector_type(8)));
 typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -21,10 +25,12 @@ template <class T> struct Frag64;
 template <> struct Frag64<f16_t> {
     typedef f16x8 type;
     static __device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 template <> struct Frag64<bf16_t> {
     typedef bf16x8 type;
     static __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 
 struct Conv64Args {
@@ -158,6 +164,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
         else { c0 += 64; if (c0 >= p.cin) { c0 = 0; if (++kw >= p.kw) { kw = 0; ++kh; } } } \
     }
 
+    // Accumulators of the wave's TM x TN macro tiles of 32 x 32. ACC(i,j,r) r=0..15 addresses them uniformly:
+    //   32x32x16 MFMA: one f32x16, element r at row (r&3)+8(r>>2)+4(lane>>5), column lane&31;
+    //   16x16x32 MFMA: four f32x4 sub-tiles [si][sj], element q at row si*16+(lane>>4)*4+q, column sj*16+(lane&15).
+#if C64_M16
+    f32x4 acc[TM][TN][2][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][(r >> 3) & 1][(r >> 2) & 1][r & 3] = 0.f;
+#define C64_ACC(i, j, r) acc[i][j][((r) >> 3) & 1][((r) >> 2) & 1][(r) & 3]
+#define C64_ROW(r) ((((r) >> 3) & 1) * 16 + (lane >> 4) * 4 + ((r) & 3))
+#define C64_COL(r) ((((r) >> 2) & 1) * 16 + (lane & 15))
+#else
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -165,8 +186,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#define C64_ACC(i, j, r) acc[i][j][r]
+#define C64_ROW(r) (((r) & 3) + 8 * ((r) >> 2) + 4 * (lane >> 5))
+#define C64_COL(r) (lane & 31)
+#endif
 
-    const int swz = ((lane & 31) >> 1) & 7;
+    [[maybe_unused]] const int swz = ((lane & 31) >> 1) & 7;
     const int nk = a.K / 64;
     C64_ISSUE(0);
 
@@ -208,13 +233,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
             }
         }
     }
-    float tbias[EPI == 1 ? TN : 1];
+    float tbias[EPI == 1 ? TN : 1][2];  // per-lane conv bias of its output columns ([.][1] only differs for 16x16 sub-tiles)
     if constexpr (EPI == 1) {
         // tail weights -> LDS (behind the staging / t-tile region); per-lane conv bias of its TN output columns
         float* s_tw = reinterpret_cast<float*>(lds + a.tail_lds_off);
         for (int i = tid; i < 5 * 256; i += NT) s_tw[i] = a.tail_w[i];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) tbias[j] = a.bias[(wc * TN + j) * 32 + (lane & 31)];
+        for (int j = 0; j < TN; ++j) {
+            tbias[j][0] = a.bias[(wc * TN + j) * 32 + C64_COL(0)];
+            tbias[j][1] = a.bias[(wc * TN + j) * 32 + C64_COL(4)];
+        }
     }
     for (int ks = 0; ks < nk; ++ks) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -223,6 +251,37 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
         const unsigned char* sa = lds + (a.two_stage ? (ks & 1) : 0) * STAGE;
         const unsigned char* sb = sa + BM * 128;
         // fragment reads are software-pipelined one 16-wide K slice ahead of the MFMAs that consume them
+#if C64_M16
+        // 16x16x32: a fragment = 16 rows x 32 K; lane l holds row l&15, K chunk (l>>4) of the 32-wide step.
+        // [set][tile][row half] ; two 32-wide K steps per 64-wide slice, pipelined one step ahead.
+        frag_t fa[2][TM][2], fb[2][TN][2];
+#define C64_LOAD_FRAGS(set, k32_)                                                                                                   \
+        {                                                                                                                           \
+            _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                                                      \
+                const int rr_ = hf * 16 + (lane & 15);                                                                              \
+                const int sl_ = (((k32_) * 4 + (lane >> 4)) ^ ((rr_ >> 1) & 7)) * 16;                                               \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                      \
+                    fa[set][i][hf] = *reinterpret_cast<const frag_t*>(sa + ((wr * TM + i) * 32 + rr_) * 128 + sl_);                 \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                      \
+                    fb[set][j][hf] = *reinterpret_cast<const frag_t*>(sb + ((wc * TN + j) * 32 + rr_) * 128 + sl_);                 \
+            }                                                                                                                       \
+        }
+        C64_LOAD_FRAGS(0, 0);
+#pragma unroll
+        for (int k32 = 0; k32 < 2; ++k32) {
+            if (k32 < 1) C64_LOAD_FRAGS(1, 1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int si = 0; si < 2; ++si)
+#pragma unroll
+                        for (int sj = 0; sj < 2; ++sj)
+                            acc[i][j][si][sj] = Frag64<TI>::mfma16(fa[k32][i][si], fb[k32][j][sj], acc[i][j][si][sj]);
+        }
+#undef C64_LOAD_FRAGS
+#else
         frag_t fa[2][TM], fb[2][TN];
 #define C64_LOAD_FRAGS(set, kk_)                                                                                                    \
         {                                                                                                                           \
@@ -242,6 +301,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
                 for (int j = 0; j < TN; ++j) acc[i][j] = Frag64<TI>::mfma(fa[kk & 1][i], fb[kk & 1][j], acc[i][j]);
         }
 #undef C64_LOAD_FRAGS
+#endif
         if (!a.two_stage && ks + 1 < nk) {
             __syncthreads();  // every wave has read the single staging buffer: refill it
             C64_ADVANCE();
@@ -262,9 +322,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const int col = (wc * TN + j) * 32 + (lane & 31);
-                    s_t[row * LDT + col] = (TI)fmaxf(acc[i][j][r] + tbias[j], 0.f);
+                    const int row = (wr * TM + i) * 32 + C64_ROW(r);
+                    const int col = (wc * TN + j) * 32 + C64_COL(r);
+                    s_t[row * LDT + col] = (TI)fmaxf(C64_ACC(i, j, r) + tbias[j][(r >> 2) & 1], 0.f);
                     if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // a few accumulators at a time: keeps the VGPR budget of the K loop
                 }
         __syncthreads();
@@ -309,8 +369,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
             for (int j2 = 0; j2 < 2; ++j2)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    slab[row * EPI_LD + j2 * 32 + (lane & 31)] = acc[i][jp * 2 + j2][r];
+                    slab[C64_ROW(r) * EPI_LD + j2 * 32 + C64_COL(r)] = C64_ACC(i, jp * 2 + j2, r);
                 }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
