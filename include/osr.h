@@ -234,6 +234,96 @@ osr_status osr_assemble_detections(const float* k_boxes, const float* k_scores, 
                                    int64_t unknown_id, const int64_t* class_map, float* out_boxes, float* out_scores,
                                    int64_t* out_classes, int32_t* out_count, void* stream);
 
+/* =========================================================================================================
+ * Training step, forward half: targets and losses. Gradients are not
+ * produced by this library yet; every function below is a forward kernel whose outputs equal the reference's
+ * forward values. Random subsampling takes caller-supplied uniform keys: the k smallest keys of a class are
+ * kept (ties: lower index) -- the role torch.randperm plays in [d2] subsample_labels -- so that runs are
+ * reproducible and the selected lists are comparable bit for bit.
+ * ========================================================================================================= */
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Anchor <-> GT matching: ClsFreeRPN.label_and_sample_anchors up to the subsampling
+ * (classification_free_rpn.py:359-371): pairwise IoU (GT x anchors), argmax over GT (first maximum),
+ * Matcher(reg thresholds, labels [0,-1,1], allow_low_quality_matches) and the same for the objectness
+ * thresholds. Anchors are generated in-kernel from the level table (image-major list of R = sum h*w*a).
+ * gt_boxes: (n, gmax, 4) padded, gt_count (n). Images without GT get label 0 everywhere and matched_idx 0.
+ * Outputs: matched_idx (n,R) int32, matched_iou (n,R), labels_reg / labels_obj (n,R) int8 in {-1,0,1}.
+ * workspace: n*gmax*4 bytes.
+ * --------------------------------------------------------------------------------------------------------- */
+osr_status osr_rpn_match_anchors(const osr_rpn_levels* levels, const float* cell_anchors, int32_t n,
+                                 const float* gt_boxes, const int32_t* gt_count, int32_t gmax, float reg_lo,
+                                 float reg_hi, float obj_lo, float obj_hi, int32_t* matched_idx, float* matched_iou,
+                                 int8_t* labels_reg, int8_t* labels_obj, void* workspace, int64_t workspace_bytes,
+                                 void* stream);
+
+/* [d2] subsample_labels + ClsFreeRPN._subsample_labels (classification_free_rpn.py:299-316), in place: keep
+ * min(int(num_samples*positive_fraction), #pos) positives and min(num_samples - kept_pos, #neg) negatives with
+ * the smallest keys, everything else becomes -1. labels, keys: (n, r). num_samples <= 512. */
+osr_status osr_subsample_labels(int8_t* labels, const float* keys, int32_t n, int64_t r, int32_t num_samples,
+                                float positive_fraction, int32_t* num_pos_out, int32_t* num_neg_out, void* stream);
+
+/* Matched GT box per anchor and the centerness target (classification_free_rpn.py:386-402): ltrb deltas of the
+ * anchor against its matched GT, zero unless the anchor centre lies inside, sqrt(min(l,r)/max(l,r) *
+ * min(t,b)/max(t,b)), zero where the (subsampled) objectness label is 0. matched_boxes (n,R,4), ctr_target (n,R). */
+osr_status osr_rpn_anchor_targets(const osr_rpn_levels* levels, const float* cell_anchors, int32_t n,
+                                  const float* gt_boxes, const int32_t* gt_count, int32_t gmax,
+                                  const int32_t* matched_idx, const int8_t* labels_obj, float* matched_boxes,
+                                  float* ctr_target, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * ClsFreeRPN.losses, BBOX_REG_LOSS_TYPE "iou" (classification_free_rpn.py:446-490, box_regression_w_iou.py:49-61).
+ * pred_deltas / pred_ctr: the level-major buffers osr_cfrpn_head_tail writes (levels->offset). Targets are
+ * image-major (n, R). out6 = {loss_rpn_loc, loss_rpn_ctr, num_pos, num_neg, obj_num_pos, obj_num_neg}; both
+ * losses are divided by batch_size_per_image * n and multiplied by their weight. workspace: 6 KiB.
+ * --------------------------------------------------------------------------------------------------------- */
+osr_status osr_rpn_losses_fwd(const osr_rpn_levels* levels, const float* cell_anchors, int32_t n,
+                              const float* pred_deltas, const float* pred_ctr, const int8_t* labels_reg,
+                              const int8_t* labels_obj, const float* matched_boxes, const float* ctr_target,
+                              float loc_weight, float ctr_weight, int32_t batch_size_per_image, float* out6,
+                              void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * OpensetROIHeads.label_and_sample_proposals (osrcnn_roi_heads.py:177-216): append the GT boxes to the
+ * proposals ([d2] add_ground_truth_to_proposals, logit log((1-1e-10)/1e-10)), IoU against GT,
+ * Matcher([iou_thr],[0,1]), class = GT class or num_classes (background), matched IoU, then keep batch_size
+ * candidates, at most int(batch_size*positive_fraction) foreground. Candidates of image i are
+ * [proposals 0..prop_count[i]), GT 0..gt_count[i])]; keys is (n, pcap+gmax): the key of proposal j is keys[i][j],
+ * the key of GT g is keys[i][pcap+g], whatever the counts are.
+ * Output rows per image: foreground by ascending key, then background by ascending key, padded to batch_size
+ * (class -1, src -1). out_counts: (n,3) = {rows, foreground, background}. batch_size <= 512.
+ * --------------------------------------------------------------------------------------------------------- */
+int64_t osr_roi_match_sample_workspace_bytes(int32_t n, int64_t pcap, int32_t gmax);
+osr_status osr_roi_match_and_sample(const float* prop_boxes, const float* prop_logits, const int32_t* prop_count,
+                                    int64_t pcap, const float* gt_boxes, const int64_t* gt_classes,
+                                    const int32_t* gt_count, int32_t gmax, int32_t n, const float* keys,
+                                    int32_t num_classes, int32_t batch_size, float positive_fraction, float iou_thr,
+                                    float* out_boxes, float* out_logits, int64_t* out_classes, float* out_ious,
+                                    float* out_gt_boxes, int32_t* out_src, int32_t* out_counts, void* workspace,
+                                    int64_t workspace_bytes, void* stream);
+
+/* OpensetFastRCNNOutputLayers.losses (osrcnn_fast_rcnn.py:312-370): L1 between the predicted deltas and
+ * Box2BoxTransform(reg_weights).get_deltas(proposal, gt), and L1 between the predicted and the matched IoU,
+ * over rows with 0 <= class < num_classes; both divided by m. out2 = {loss_box_reg, loss_iou}. workspace 2 KiB. */
+osr_status osr_roi_box_losses_fwd(const float* pred_deltas, const float* pred_iou, const float* proposal_boxes,
+                                  const float* gt_boxes, const int64_t* gt_classes, const float* gt_iou, int64_t m,
+                                  int32_t num_classes, const float reg_weights[4], float box_weight, float iou_weight,
+                                  float* out2, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* PLN.loss, COS distance, one prototype per class (prototype_learning_network.py:133-187): rows with a known
+ * class and IoU > iou_thr contribute relu(d_own - alpha) + relu(beta - min d_other); the prototypes contribute
+ * sum_k relu(alpha + beta - min_{j!=k} d(p_k,p_j)); total * loss_weight / m. emb: (m,d) un-normalised encoder
+ * output; protos_normed (num_known, d). workspace 3 KiB. */
+osr_status osr_pln_loss_fwd(const float* emb, int64_t m, int32_t d, const float* protos_normed, int32_t num_known,
+                            const int64_t* gt_classes, const float* ious, float iou_thr, float alpha, float beta,
+                            float loss_weight, float* out1, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* SoftMaxClassifier.loss (softmax_classifier.py:266-285): id_map (known c -> c, num_classes -> num_known, any
+ * other class is ignored), mean cross entropy over num_known+1 logits, times loss_weight. workspace 2 KiB. */
+osr_status osr_softmax_ce_loss_fwd(const float* logits, int64_t m, int32_t num_known, const int64_t* gt_classes,
+                                   int32_t num_classes, float loss_weight, float* out1, void* workspace,
+                                   int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,7 @@ SOURCES = {
     "osr_rpn.hip": ["-ffp-contract=off"],
     "osr_roi_align.hip": ["-ffp-contract=off"],
     "osr_det_tail.hip": ["-ffp-contract=off"],
+    "osr_train_fwd.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

@@ -1,0 +1,657 @@
+// Training-side targets and losses (forward) for gfx950 -- include/osr.h "train step, forward half".
+//
+// Reference call sites (/root/reference/openset_rcnn/modeling/):
+//   proposal_generator/classification_free_rpn.py:320-411 label_and_sample_anchors, :414-491 losses
+//   box_regression_w_iou.py:49-61 ("iou" box loss)            roi_heads/osrcnn_roi_heads.py:137-230
+//   roi_heads/osrcnn_fast_rcnn.py:266-370                      roi_heads/prototype_learning_network.py:117-187
+//   roi_heads/softmax_classifier.py:266-285
+// and the [d2] primitives used there: pairwise_iou, Matcher, subsample_labels, Box2BoxTransform[Linear].get_deltas,
+// add_ground_truth_to_proposals. Random sampling takes caller-supplied uniform keys (k smallest keys per class,
+// ties to the lower index) instead of torch.randperm: same distribution, reproducible.
+// Every reduction is two-stage (per-workgroup partials in fixed order, then one workgroup), so losses are bitwise
+// reproducible run to run. Compile with -ffp-contract=off (labels / sampled index lists must be bit-exact).
+#include "osr_common.h"
+
+struct TrLevels {
+    int num_levels, num_anchors;
+    int h[OSR_MAX_LEVELS], w[OSR_MAX_LEVELS], stride[OSR_MAX_LEVELS];
+    long long pred_off[OSR_MAX_LEVELS];  // element offset of level l in the level-major prediction buffers
+    int aoff[OSR_MAX_LEVELS + 1];        // prefix of h*w*a: index base inside an image's concatenated anchor list
+    int R;
+};
+
+static bool tr_fill(const osr_rpn_levels* in, TrLevels* o) {
+    if (!in || in->num_levels < 1 || in->num_levels > OSR_MAX_LEVELS || in->num_anchors < 1) return false;
+    o->num_levels = in->num_levels; o->num_anchors = in->num_anchors;
+    long long a = 0;
+    for (int l = 0; l < in->num_levels; ++l) {
+        if (in->h[l] < 1 || in->w[l] < 1 || in->stride[l] < 1) return false;
+        o->h[l] = in->h[l]; o->w[l] = in->w[l]; o->stride[l] = in->stride[l]; o->pred_off[l] = in->offset[l];
+        o->aoff[l] = (int)a;
+        a += (long long)in->h[l] * in->w[l] * in->num_anchors;
+        if (a > (1ll << 30)) return false;
+    }
+    o->aoff[in->num_levels] = (int)a;
+    o->R = (int)a;
+    return true;
+}
+
+__device__ __forceinline__ float4 tr_anchor(const TrLevels& lv, const float* __restrict__ cell, int r, int* level, int* cell_idx) {
+    int l = 0;
+    while (l + 1 < lv.num_levels && r >= lv.aoff[l + 1]) ++l;
+    const int idx = r - lv.aoff[l], A = lv.num_anchors, a = idx % A, c = idx / A;
+    const float sx = (float)(c % lv.w[l]) * (float)lv.stride[l], sy = (float)(c / lv.w[l]) * (float)lv.stride[l];
+    const float* ca = cell + ((long long)l * A + a) * 4;
+    *level = l; *cell_idx = idx;
+    return make_float4(sx + ca[0], sy + ca[1], sx + ca[2], sy + ca[3]);
+}
+
+// [d2] pairwise_iou element: inter / (a1 + a2 - inter) when inter > 0, else 0 (a1 = GT area, a2 = box area)
+__device__ __forceinline__ float tr_iou(const float4 g, const float4 b) {
+    const float a1 = (g.z - g.x) * (g.w - g.y), a2 = (b.z - b.x) * (b.w - b.y);
+    const float w = fmaxf(fminf(g.z, b.z) - fmaxf(g.x, b.x), 0.f), h = fmaxf(fminf(g.w, b.w) - fmaxf(g.y, b.y), 0.f);
+    const float inter = w * h;
+    return inter > 0.f ? inter / (a1 + a2 - inter) : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// anchor <-> GT matching (both Matchers share the IoU matrix and its argmax)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rpn_match_pass1(TrLevels lv, const float* __restrict__ cell, const float* __restrict__ gt,
+                                                       const int* __restrict__ gt_count, int gmax, int* __restrict__ matched_idx,
+                                                       float* __restrict__ matched_iou, unsigned int* __restrict__ gtmax) {
+    const int img = blockIdx.y, r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= lv.R) return;
+    int l, ci;
+    const float4 b = tr_anchor(lv, cell, r, &l, &ci);
+    const int G = min(gt_count[img], gmax);
+    float best = 0.f;
+    int bi = 0;
+    for (int g = 0; g < G; ++g) {
+        const float4 gb = *reinterpret_cast<const float4*>(gt + ((long long)img * gmax + g) * 4);
+        const float v = tr_iou(gb, b);
+        if (g == 0 || v > best) { best = v; bi = g; }  // first maximum wins
+        atomicMax(gtmax + (long long)img * gmax + g, __float_as_uint(v));  // IoU >= 0: uint order == float order
+    }
+    matched_idx[(long long)img * lv.R + r] = bi;
+    matched_iou[(long long)img * lv.R + r] = best;
+}
+
+__device__ __forceinline__ signed char tr_label(float v, float lo, float hi) { return v < lo ? 0 : (v < hi ? -1 : 1); }
+
+__global__ __launch_bounds__(256) void rpn_match_pass2(TrLevels lv, const float* __restrict__ cell, const float* __restrict__ gt,
+                                                       const int* __restrict__ gt_count, int gmax, const float* __restrict__ matched_iou,
+                                                       const unsigned int* __restrict__ gtmax, float reg_lo, float reg_hi, float obj_lo,
+                                                       float obj_hi, int low_quality, signed char* __restrict__ labels_reg,
+                                                       signed char* __restrict__ labels_obj) {
+    const int img = blockIdx.y, r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= lv.R) return;
+    const int G = min(gt_count[img], gmax);
+    const long long o = (long long)img * lv.R + r;
+    if (G == 0) { labels_reg[o] = 0; labels_obj[o] = 0; return; }  // [d2] Matcher on an empty matrix: everything background
+    const float v = matched_iou[o];
+    signed char lr = tr_label(v, reg_lo, reg_hi), lo_ = tr_label(v, obj_lo, obj_hi);
+    if (low_quality) {
+        int l, ci;
+        const float4 b = tr_anchor(lv, cell, r, &l, &ci);
+        bool lq = false;
+        for (int g = 0; g < G; ++g) {
+            const float4 gb = *reinterpret_cast<const float4*>(gt + ((long long)img * gmax + g) * 4);
+            lq |= __float_as_uint(tr_iou(gb, b)) == gtmax[(long long)img * gmax + g];  // quality == best_of_gt (incl. the 0 == 0 quirk)
+        }
+        if (lq) { lr = 1; lo_ = 1; }
+    }
+    labels_reg[o] = lr;
+    labels_obj[o] = lo_;
+}
+
+extern "C" osr_status osr_rpn_match_anchors(const osr_rpn_levels* lvl, const float* cell_anchors, int32_t n, const float* gt_boxes,
+                                            const int32_t* gt_count, int32_t gmax, float reg_lo, float reg_hi, float obj_lo, float obj_hi,
+                                            int32_t* matched_idx, float* matched_iou, int8_t* labels_reg, int8_t* labels_obj,
+                                            void* workspace, int64_t workspace_bytes, void* stream) {
+    TrLevels lv;
+    OSR_REQUIRE(tr_fill(lvl, &lv), OSR_ERR_INVALID_ARG, "osr_rpn_match_anchors: bad level table");
+    OSR_REQUIRE(cell_anchors && gt_boxes && gt_count && matched_idx && matched_iou && labels_reg && labels_obj && workspace, OSR_ERR_INVALID_ARG,
+                "osr_rpn_match_anchors: null pointer");
+    OSR_REQUIRE(n >= 1 && n <= 65535 && gmax >= 1, OSR_ERR_INVALID_ARG, "osr_rpn_match_anchors: bad n / gmax");
+    OSR_REQUIRE(workspace_bytes >= (int64_t)n * gmax * 4, OSR_ERR_WORKSPACE, "osr_rpn_match_anchors: workspace needs n*gmax*4 bytes");
+    OSR_REQUIRE(((uintptr_t)gt_boxes & 15) == 0, OSR_ERR_INVALID_ARG, "osr_rpn_match_anchors: gt_boxes must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, (size_t)n * gmax * 4, st) != hipSuccess) { osr_set_error("osr_rpn_match_anchors: memset failed"); return OSR_ERR_LAUNCH; }
+    dim3 grid((lv.R + 255) / 256, n);
+    hipLaunchKernelGGL(rpn_match_pass1, grid, dim3(256), 0, st, lv, cell_anchors, gt_boxes, gt_count, gmax, matched_idx, matched_iou, (unsigned int*)workspace);
+    OSR_CHECK_LAUNCH("osr_rpn_match_anchors(pass1)");
+    hipLaunchKernelGGL(rpn_match_pass2, grid, dim3(256), 0, st, lv, cell_anchors, gt_boxes, gt_count, gmax, matched_iou, (const unsigned int*)workspace,
+                       reg_lo, reg_hi, obj_lo, obj_hi, 1, (signed char*)labels_reg, (signed char*)labels_obj);
+    OSR_CHECK_LAUNCH("osr_rpn_match_anchors(pass2)");
+    return OSR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// block-wide "k smallest keys among members" (ties: lower index), result sorted ascending by (key, index)
+// ------------------------------------------------------------------------------------------------------
+#define TR_THREADS 1024
+#define TR_MAXK 512
+
+__device__ __forceinline__ void tr_bitonic_desc(unsigned long long* buf, int n) {
+    for (int k = 2; k <= n; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = buf[i], b = buf[ixj];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) { buf[i] = b; buf[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+// member(i) -> bool, keyf(i) -> float. Selects min(k, #members) entries; s_sel[j] low 32 bits = 0xffffffff - index, in
+// ascending (key, index) order. Returns the number selected (uniform). Must be called by the whole block.
+template <class MemberF, class KeyF>
+__device__ int tr_select_smallest(MemberF member, KeyF keyf, int cnt, int k, unsigned long long* s_sel,
+                                  int* s_hist, int* s_scan, unsigned int* s_bc) {
+    const int tid = threadIdx.x;
+    // members
+    int c = 0;
+    for (int i = tid; i < cnt; i += blockDim.x) c += member(i) ? 1 : 0;
+    int m;
+    osr_block_excl_scan(c, s_scan, &m);
+    if (k > m) k = m;
+    if (k > TR_MAXK) k = TR_MAXK;
+    if (k <= 0) return 0;
+    // inverted monotone key: the k smallest floats are the k largest v
+    unsigned int prefix = 0, mask = 0;
+    int remaining = k;
+    const bool all = m <= k;
+    if (!all) {
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            for (int i = tid; i < 256; i += blockDim.x) s_hist[i] = 0;
+            __syncthreads();
+            for (int i = tid; i < cnt; i += blockDim.x)
+                if (member(i)) {
+                    const unsigned int v = ~osr_float_key(keyf(i));
+                    if ((v & mask) == prefix) atomicAdd(&s_hist[(v >> shift) & 255], 1);
+                }
+            __syncthreads();
+            if (tid == 0) {
+                int acc = 0, d = 255;
+                for (; d > 0; --d) {
+                    if (acc + s_hist[d] >= remaining) break;
+                    acc += s_hist[d];
+                }
+                s_bc[0] = prefix | ((unsigned int)d << shift);
+                s_bc[1] = (unsigned int)(remaining - acc);
+            }
+            __syncthreads();
+            prefix = s_bc[0];
+            remaining = (int)s_bc[1];
+            mask |= 255u << shift;
+            __syncthreads();
+        }
+    }
+    const unsigned int T = prefix;
+    int ngt_total = 0;
+    if (!all) {
+        int g = 0;
+        for (int i = tid; i < cnt; i += blockDim.x) g += (member(i) && ~osr_float_key(keyf(i)) > T) ? 1 : 0;
+        osr_block_excl_scan(g, s_scan, &ngt_total);
+    }
+    int base_gt = 0, base_eq = 0;
+    for (int i0 = 0; i0 < cnt; i0 += blockDim.x) {
+        const int i = i0 + tid;
+        unsigned int v = 0;
+        int gt = 0, eq = 0;
+        if (i < cnt && member(i)) {
+            v = ~osr_float_key(keyf(i));
+            if (all) gt = 1; else { gt = v > T; eq = v == T; }
+        }
+        int tot;
+        const int packed = osr_block_excl_scan(gt | (eq << 16), s_scan, &tot);
+        const int pg = base_gt + (packed & 0xffff), pe = base_eq + (packed >> 16);
+        const unsigned long long comp = ((unsigned long long)v << 32) | (unsigned int)(0xffffffffu - (unsigned int)i);
+        if (gt && pg < TR_MAXK) s_sel[pg] = comp;
+        if (eq && pe < remaining && ngt_total + pe < TR_MAXK) s_sel[ngt_total + pe] = comp;
+        base_gt += tot & 0xffff;
+        base_eq += tot >> 16;
+    }
+    int kp = 1;
+    while (kp < k) kp <<= 1;
+    for (int i = k + tid; i < kp; i += blockDim.x) s_sel[i] = 0ull;
+    __syncthreads();
+    tr_bitonic_desc(s_sel, kp);  // v descending == key ascending; index ascending inside ties
+    return k;
+}
+
+// [d2] subsample_labels + ClsFreeRPN._subsample_labels (classification_free_rpn.py:299-316): grid (image, which)
+__global__ __launch_bounds__(TR_THREADS) void subsample_kernel(signed char* __restrict__ labels, const float* __restrict__ keys, long long R,
+                                                               int num_samples, float pos_fraction, int* __restrict__ num_pos_out,
+                                                               int* __restrict__ num_neg_out) {
+    __shared__ unsigned long long s_sel[TR_MAXK];
+    __shared__ int s_pos[TR_MAXK], s_neg[TR_MAXK];
+    __shared__ int s_hist[256], s_scan[32];
+    __shared__ unsigned int s_bc[2];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    signed char* lab = labels + (long long)img * R;
+    const float* ky = keys + (long long)img * R;
+    const int cnt = (int)R;
+    const int want_pos = (int)((float)num_samples * pos_fraction);
+    const int np = tr_select_smallest([&](int i) { return lab[i] == 1; }, [&](int i) { return ky[i]; }, cnt, want_pos, s_sel, s_hist, s_scan, s_bc);
+    for (int j = tid; j < np; j += blockDim.x) s_pos[j] = (int)(0xffffffffu - (unsigned int)(s_sel[j] & 0xffffffffull));
+    __syncthreads();
+    const int nn = tr_select_smallest([&](int i) { return lab[i] == 0; }, [&](int i) { return ky[i]; }, cnt, num_samples - np, s_sel, s_hist, s_scan, s_bc);
+    for (int j = tid; j < nn; j += blockDim.x) s_neg[j] = (int)(0xffffffffu - (unsigned int)(s_sel[j] & 0xffffffffull));
+    __syncthreads();
+    for (int i = tid; i < cnt; i += blockDim.x) lab[i] = -1;  // label.fill_(-1)
+    __syncthreads();
+    for (int j = tid; j < np; j += blockDim.x) lab[s_pos[j]] = 1;  // scatter_(pos_idx, 1)
+    for (int j = tid; j < nn; j += blockDim.x) lab[s_neg[j]] = 0;  // scatter_(neg_idx, 0)
+    if (tid == 0) { num_pos_out[img] = np; num_neg_out[img] = nn; }
+}
+
+extern "C" osr_status osr_subsample_labels(int8_t* labels, const float* keys, int32_t n, int64_t r, int32_t num_samples, float positive_fraction,
+                                           int32_t* num_pos_out, int32_t* num_neg_out, void* stream) {
+    OSR_REQUIRE(labels && keys && num_pos_out && num_neg_out, OSR_ERR_INVALID_ARG, "osr_subsample_labels: null pointer");
+    OSR_REQUIRE(n >= 1 && r >= 1 && r < (1ll << 30), OSR_ERR_INVALID_ARG, "osr_subsample_labels: bad sizes");
+    OSR_REQUIRE(num_samples >= 1 && num_samples <= TR_MAXK && positive_fraction >= 0.f && positive_fraction <= 1.f, OSR_ERR_UNSUPPORTED,
+                "osr_subsample_labels: num_samples must be in 1..%d", TR_MAXK);
+    hipLaunchKernelGGL(subsample_kernel, dim3(n), dim3(TR_THREADS), 0, (hipStream_t)stream, (signed char*)labels, keys, (long long)r, num_samples,
+                       positive_fraction, num_pos_out, num_neg_out);
+    OSR_CHECK_LAUNCH("osr_subsample_labels");
+    return OSR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// matched GT boxes + centerness targets (classification_free_rpn.py:386-402)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rpn_targets_kernel(TrLevels lv, const float* __restrict__ cell, const float* __restrict__ gt,
+                                                          const int* __restrict__ gt_count, int gmax, const int* __restrict__ matched_idx,
+                                                          const signed char* __restrict__ labels_obj, float* __restrict__ matched_boxes,
+                                                          float* __restrict__ ctr_target) {
+    const int img = blockIdx.y, r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= lv.R) return;
+    const long long o = (long long)img * lv.R + r;
+    const int G = min(gt_count[img], gmax);
+    if (G == 0) {
+        *reinterpret_cast<float4*>(matched_boxes + o * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        ctr_target[o] = 0.f;
+        return;
+    }
+    int l, ci;
+    const float4 a = tr_anchor(lv, cell, r, &l, &ci);
+    const float4 g = *reinterpret_cast<const float4*>(gt + ((long long)img * gmax + matched_idx[o]) * 4);
+    *reinterpret_cast<float4*>(matched_boxes + o * 4) = g;
+    // [d2] Box2BoxTransformLinear(normalize_by_size=True).get_deltas, reordered to l, r, t, b
+    const float cx = 0.5f * (a.x + a.z), cy = 0.5f * (a.y + a.w), sw = a.z - a.x, sh = a.w - a.y;
+    float dl = (cx - g.x) / sw, dt = (cy - g.y) / sh, dr = (g.z - cx) / sw, db = (g.w - cy) / sh;
+    if (!(dl >= 0.f && dr >= 0.f && dt >= 0.f && db >= 0.f)) { dl = 0.f; dr = 0.f; dt = 0.f; db = 0.f; }
+    float c = sqrtf((fminf(dl, dr) / (fmaxf(dl, dr) + 1e-12f)) * (fminf(dt, db) / (fmaxf(dt, db) + 1e-12f)));
+    if (labels_obj[o] == 0) c = 0.f;
+    ctr_target[o] = c;
+}
+
+extern "C" osr_status osr_rpn_anchor_targets(const osr_rpn_levels* lvl, const float* cell_anchors, int32_t n, const float* gt_boxes,
+                                             const int32_t* gt_count, int32_t gmax, const int32_t* matched_idx, const int8_t* labels_obj,
+                                             float* matched_boxes, float* ctr_target, void* stream) {
+    TrLevels lv;
+    OSR_REQUIRE(tr_fill(lvl, &lv), OSR_ERR_INVALID_ARG, "osr_rpn_anchor_targets: bad level table");
+    OSR_REQUIRE(cell_anchors && gt_boxes && gt_count && matched_idx && labels_obj && matched_boxes && ctr_target, OSR_ERR_INVALID_ARG,
+                "osr_rpn_anchor_targets: null pointer");
+    OSR_REQUIRE(n >= 1 && n <= 65535 && gmax >= 1, OSR_ERR_INVALID_ARG, "osr_rpn_anchor_targets: bad n / gmax");
+    OSR_REQUIRE((((uintptr_t)gt_boxes | (uintptr_t)matched_boxes) & 15) == 0, OSR_ERR_INVALID_ARG, "osr_rpn_anchor_targets: box arrays must be 16-byte aligned");
+    hipLaunchKernelGGL(rpn_targets_kernel, dim3((lv.R + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, lv, cell_anchors, gt_boxes, gt_count, gmax,
+                       matched_idx, (const signed char*)labels_obj, matched_boxes, ctr_target);
+    OSR_CHECK_LAUNCH("osr_rpn_anchor_targets");
+    return OSR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// deterministic two-stage reductions
+// ------------------------------------------------------------------------------------------------------
+#define RED_BLOCKS 256
+#define RED_MAXV 8
+
+template <int NV>
+__device__ __forceinline__ void tr_block_reduce_store(float v[NV], float* __restrict__ partial /* [gridDim.x][NV] */) {
+    __shared__ float s_red[RED_MAXV][16];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        float x = v[q];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
+        if (lane == 0) s_red[q][wid] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        float x = 0.f;
+        for (int w = 0; w < nw; ++w) x += s_red[threadIdx.x][w];
+        partial[(long long)blockIdx.x * NV + threadIdx.x] = x;
+    }
+}
+
+// out[q] = scale[q] * sum_b partial[b][q]   (fixed order)
+struct TrScale { float s[RED_MAXV]; };
+__global__ void tr_final_reduce(const float* __restrict__ partial, int nblocks, int nv, TrScale scale, float* __restrict__ out) {
+    const int q = threadIdx.x;
+    if (q >= nv) return;
+    float x = 0.f;
+    for (int b = 0; b < nblocks; ++b) x += partial[(long long)b * nv + q];
+    out[q] = x * scale.s[q];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// RPN losses forward: "iou" localisation loss + L1 centerness loss (+ the four logged anchor counts)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rpn_losses_kernel(TrLevels lv, const float* __restrict__ cell, int n, const float* __restrict__ pred_deltas,
+                                                         const float* __restrict__ pred_ctr, const signed char* __restrict__ labels_reg,
+                                                         const signed char* __restrict__ labels_obj, const float* __restrict__ matched_boxes,
+                                                         const float* __restrict__ ctr_target, float* __restrict__ partial) {
+    float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // loc, ctr, num_pos, num_neg, obj_pos, obj_neg
+    const long long total = (long long)n * lv.R;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int img = (int)(i / lv.R), r = (int)(i - (long long)img * lv.R);
+        const signed char lr = labels_reg[i], lo = labels_obj[i];
+        v[2] += lr == 1; v[3] += lr == 0; v[4] += lo == 1; v[5] += lo == 0;
+        if (lr != 1 && lo == -1) continue;
+        int l, ci;
+        const float4 a = tr_anchor(lv, cell, r, &l, &ci);
+        const long long pi = lv.pred_off[l] + (long long)img * (lv.aoff[l + 1] - lv.aoff[l]) + ci;
+        if (lr == 1) {
+            const float4 d = *reinterpret_cast<const float4*>(pred_deltas + pi * 4);
+            const float cx = 0.5f * (a.x + a.z), cy = 0.5f * (a.y + a.w), aw = a.z - a.x, ah = a.w - a.y;
+            const float4 pb = make_float4(cx - fmaxf(d.x, 0.f) * aw, cy - fmaxf(d.y, 0.f) * ah, cx + fmaxf(d.z, 0.f) * aw, cy + fmaxf(d.w, 0.f) * ah);
+            const float4 g = *reinterpret_cast<const float4*>(matched_boxes + i * 4);
+            // diag(pairwise_iou(pred, gt)).clamp(min=1e-6): pred plays the "b1" role (box_regression_w_iou.py:56)
+            v[0] += 1.0f - fmaxf(tr_iou(pb, g), 1e-6f);
+        }
+        if (lo != -1) v[1] += fabsf(pred_ctr[pi] - ctr_target[i]);
+    }
+    tr_block_reduce_store<6>(v, partial);
+}
+
+extern "C" osr_status osr_rpn_losses_fwd(const osr_rpn_levels* lvl, const float* cell_anchors, int32_t n, const float* pred_deltas,
+                                         const float* pred_ctr, const int8_t* labels_reg, const int8_t* labels_obj, const float* matched_boxes,
+                                         const float* ctr_target, float loc_weight, float ctr_weight, int32_t batch_size_per_image, float* out6,
+                                         void* workspace, int64_t workspace_bytes, void* stream) {
+    TrLevels lv;
+    OSR_REQUIRE(tr_fill(lvl, &lv), OSR_ERR_INVALID_ARG, "osr_rpn_losses_fwd: bad level table");
+    OSR_REQUIRE(cell_anchors && pred_deltas && pred_ctr && labels_reg && labels_obj && matched_boxes && ctr_target && out6 && workspace,
+                OSR_ERR_INVALID_ARG, "osr_rpn_losses_fwd: null pointer");
+    OSR_REQUIRE(n >= 1 && batch_size_per_image >= 1, OSR_ERR_INVALID_ARG, "osr_rpn_losses_fwd: bad n / batch size");
+    OSR_REQUIRE(workspace_bytes >= (int64_t)RED_BLOCKS * 6 * 4, OSR_ERR_WORKSPACE, "osr_rpn_losses_fwd: workspace needs %d bytes", RED_BLOCKS * 6 * 4);
+    OSR_REQUIRE((((uintptr_t)pred_deltas | (uintptr_t)matched_boxes) & 15) == 0, OSR_ERR_INVALID_ARG, "osr_rpn_losses_fwd: box arrays must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    const float norm = (float)batch_size_per_image * (float)n;
+    const TrScale scale = {{1.0f / norm * loc_weight, 1.0f / norm * ctr_weight, 1.f, 1.f, 1.f, 1.f, 0.f, 0.f}};
+    hipLaunchKernelGGL(rpn_losses_kernel, dim3(RED_BLOCKS), dim3(256), 0, st, lv, cell_anchors, n, pred_deltas, pred_ctr, (const signed char*)labels_reg,
+                       (const signed char*)labels_obj, matched_boxes, ctr_target, partial);
+    OSR_CHECK_LAUNCH("osr_rpn_losses_fwd");
+    hipLaunchKernelGGL(tr_final_reduce, dim3(1), dim3(64), 0, st, partial, RED_BLOCKS, 6, scale, out6);
+    OSR_CHECK_LAUNCH("osr_rpn_losses_fwd(final)");
+    return OSR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// RoI heads: append GT, match, sample (osrcnn_roi_heads.py:177-216): one workgroup per image
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TR_THREADS) void roi_match_sample_kernel(const float* __restrict__ prop_boxes, const float* __restrict__ prop_logits,
+                                                                      const int* __restrict__ prop_count, long long pcap, const float* __restrict__ gt,
+                                                                      const long long* __restrict__ gt_classes, const int* __restrict__ gt_count,
+                                                                      int gmax, const float* __restrict__ keys, int num_classes, int batch_size,
+                                                                      float pos_fraction, float iou_thr, float gt_logit, int* __restrict__ ws_cls,
+                                                                      float* __restrict__ ws_iou, int* __restrict__ ws_midx, float* __restrict__ out_boxes,
+                                                                      float* __restrict__ out_logits, long long* __restrict__ out_cls,
+                                                                      float* __restrict__ out_iou, float* __restrict__ out_gt, int* __restrict__ out_src,
+                                                                      int* __restrict__ out_counts) {
+    __shared__ unsigned long long s_sel[TR_MAXK];
+    __shared__ int s_idx[TR_MAXK];
+    __shared__ int s_hist[256], s_scan[32];
+    __shared__ unsigned int s_bc[2];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int P = min((long long)prop_count[img], pcap), G = min(gt_count[img], gmax);
+    const int C = P + G;
+    const long long cstride = pcap + gmax;
+    int* cls = ws_cls + img * cstride;
+    float* miou = ws_iou + img * cstride;
+    int* midx = ws_midx + img * cstride;
+    const float* ky = keys + img * cstride;
+    auto keyf = [&](int j) { return ky[j < P ? j : (int)pcap + (j - P)]; };  // keys are laid out (pcap proposals, gmax GT)
+    auto cand_box = [&](int j) {
+        return j < P ? *reinterpret_cast<const float4*>(prop_boxes + ((long long)img * pcap + j) * 4)
+                     : *reinterpret_cast<const float4*>(gt + ((long long)img * gmax + (j - P)) * 4);
+    };
+    for (int j = tid; j < C; j += blockDim.x) {
+        const float4 b = cand_box(j);
+        float best = 0.f;
+        int bi = 0;
+        for (int g = 0; g < G; ++g) {
+            const float v = tr_iou(*reinterpret_cast<const float4*>(gt + ((long long)img * gmax + g) * 4), b);
+            if (g == 0 || v > best) { best = v; bi = g; }
+        }
+        const bool fg = G > 0 && best >= iou_thr;  // [d2] Matcher([0.5], [0, 1])
+        cls[j] = fg ? (int)gt_classes[(long long)img * gmax + bi] : num_classes;
+        miou[j] = G > 0 ? best : 0.f;
+        midx[j] = bi;
+    }
+    __syncthreads();
+    // [d2] subsample_labels(gt_classes, batch_size, positive_fraction, bg = num_classes): fg first, then bg
+    const int want_fg = (int)((float)batch_size * pos_fraction);
+    int nsel = 0;
+    const int nfg = tr_select_smallest([&](int i) { return cls[i] != num_classes && cls[i] != -1; }, keyf, C, want_fg, s_sel, s_hist, s_scan, s_bc);
+    for (int j = tid; j < nfg; j += blockDim.x) s_idx[j] = (int)(0xffffffffu - (unsigned int)(s_sel[j] & 0xffffffffull));
+    __syncthreads();
+    nsel = nfg;
+    const int nbg = tr_select_smallest([&](int i) { return cls[i] == num_classes; }, keyf, C, batch_size - nfg, s_sel, s_hist, s_scan, s_bc);
+    for (int j = tid; j < nbg; j += blockDim.x) s_idx[nsel + j] = (int)(0xffffffffu - (unsigned int)(s_sel[j] & 0xffffffffull));
+    __syncthreads();
+    nsel += nbg;
+    for (int j = tid; j < batch_size; j += blockDim.x) {
+        const long long o = (long long)img * batch_size + j;
+        if (j < nsel) {
+            const int s = s_idx[j];
+            *reinterpret_cast<float4*>(out_boxes + o * 4) = cand_box(s);
+            out_logits[o] = s < P ? prop_logits[(long long)img * pcap + s] : gt_logit;
+            out_cls[o] = cls[s];
+            out_iou[o] = miou[s];
+            *reinterpret_cast<float4*>(out_gt + o * 4) = G > 0 ? *reinterpret_cast<const float4*>(gt + ((long long)img * gmax + midx[s]) * 4)
+                                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+            out_src[o] = s;
+        } else {
+            *reinterpret_cast<float4*>(out_boxes + o * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(out_gt + o * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            out_logits[o] = 0.f; out_cls[o] = -1; out_iou[o] = 0.f; out_src[o] = -1;
+        }
+    }
+    if (tid == 0) { out_counts[img * 3 + 0] = nsel; out_counts[img * 3 + 1] = nfg; out_counts[img * 3 + 2] = nbg; }
+}
+
+extern "C" int64_t osr_roi_match_sample_workspace_bytes(int32_t n, int64_t pcap, int32_t gmax) {
+    if (n < 1 || pcap < 1 || gmax < 1) { osr_set_error("osr_roi_match_sample_workspace_bytes: bad arguments"); return OSR_ERR_INVALID_ARG; }
+    return (int64_t)n * (pcap + gmax) * 12;
+}
+
+extern "C" osr_status osr_roi_match_and_sample(const float* prop_boxes, const float* prop_logits, const int32_t* prop_count, int64_t pcap,
+                                               const float* gt_boxes, const int64_t* gt_classes, const int32_t* gt_count, int32_t gmax, int32_t n,
+                                               const float* keys, int32_t num_classes, int32_t batch_size, float positive_fraction, float iou_thr,
+                                               float* out_boxes, float* out_logits, int64_t* out_classes, float* out_ious, float* out_gt_boxes,
+                                               int32_t* out_src, int32_t* out_counts, void* workspace, int64_t workspace_bytes, void* stream) {
+    OSR_REQUIRE(prop_boxes && prop_logits && prop_count && gt_boxes && gt_classes && gt_count && keys && out_boxes && out_logits && out_classes &&
+                    out_ious && out_gt_boxes && out_src && out_counts && workspace, OSR_ERR_INVALID_ARG, "osr_roi_match_and_sample: null pointer");
+    OSR_REQUIRE(n >= 1 && pcap >= 1 && gmax >= 1 && pcap + gmax < (1ll << 30), OSR_ERR_INVALID_ARG, "osr_roi_match_and_sample: bad sizes");
+    OSR_REQUIRE(batch_size >= 1 && batch_size <= TR_MAXK, OSR_ERR_UNSUPPORTED, "osr_roi_match_and_sample: batch_size must be in 1..%d", TR_MAXK);
+    const int64_t need = (int64_t)n * (pcap + gmax) * 12;
+    OSR_REQUIRE(workspace_bytes >= need, OSR_ERR_WORKSPACE, "osr_roi_match_and_sample: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+    OSR_REQUIRE((((uintptr_t)prop_boxes | (uintptr_t)gt_boxes | (uintptr_t)out_boxes | (uintptr_t)out_gt_boxes) & 15) == 0, OSR_ERR_INVALID_ARG,
+                "osr_roi_match_and_sample: box arrays must be 16-byte aligned");
+    char* ws = (char*)workspace;
+    const int64_t c = (int64_t)n * (pcap + gmax);
+    // add_ground_truth_to_proposals: logit of a GT box = log((1 - 1e-10) / (1 - (1 - 1e-10))) evaluated in double, then fp32
+    const double gt_prob = 1.0 - 1e-10;
+    const float gt_logit = (float)log(gt_prob / (1.0 - gt_prob));
+    hipLaunchKernelGGL(roi_match_sample_kernel, dim3(n), dim3(TR_THREADS), 0, (hipStream_t)stream, prop_boxes, prop_logits, prop_count, (long long)pcap,
+                       gt_boxes, (const long long*)gt_classes, gt_count, gmax, keys, num_classes, batch_size, positive_fraction, iou_thr, gt_logit,
+                       (int*)ws, (float*)(ws + c * 4), (int*)(ws + c * 8), out_boxes, out_logits, (long long*)out_classes, out_ious, out_gt_boxes,
+                       out_src, out_counts);
+    OSR_CHECK_LAUNCH("osr_roi_match_and_sample");
+    return OSR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// box / IoU regression losses forward (osrcnn_fast_rcnn.py:312-370)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void roi_box_losses_kernel(const float* __restrict__ pred_deltas, const float* __restrict__ pred_iou,
+                                                             const float* __restrict__ prop, const float* __restrict__ gtb,
+                                                             const long long* __restrict__ cls, const float* __restrict__ gt_iou, long long m,
+                                                             int num_classes, float wx, float wy, float ww, float wh, float* __restrict__ partial) {
+    float v[2] = {0.f, 0.f};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
+        const long long c = cls[i];
+        if (c < 0 || c >= num_classes) continue;
+        const float4 s = *reinterpret_cast<const float4*>(prop + i * 4), t = *reinterpret_cast<const float4*>(gtb + i * 4);
+        const float4 d = *reinterpret_cast<const float4*>(pred_deltas + i * 4);
+        // [d2] Box2BoxTransform.get_deltas
+        const float sw = s.z - s.x, sh = s.w - s.y, scx = s.x + 0.5f * sw, scy = s.y + 0.5f * sh;
+        const float tw = t.z - t.x, th = t.w - t.y, tcx = t.x + 0.5f * tw, tcy = t.y + 0.5f * th;
+        const float dx = wx * (tcx - scx) / sw, dy = wy * (tcy - scy) / sh, dw = ww * logf(tw / sw), dh = wh * logf(th / sh);
+        v[0] += fabsf(d.x - dx) + fabsf(d.y - dy) + fabsf(d.z - dw) + fabsf(d.w - dh);
+        v[1] += fabsf(pred_iou[i] - gt_iou[i]);
+    }
+    tr_block_reduce_store<2>(v, partial);
+}
+
+extern "C" osr_status osr_roi_box_losses_fwd(const float* pred_deltas, const float* pred_iou, const float* proposal_boxes, const float* gt_boxes,
+                                             const int64_t* gt_classes, const float* gt_iou, int64_t m, int32_t num_classes, const float reg_weights[4],
+                                             float box_weight, float iou_weight, float* out2, void* workspace, int64_t workspace_bytes, void* stream) {
+    OSR_REQUIRE(pred_deltas && pred_iou && proposal_boxes && gt_boxes && gt_classes && gt_iou && reg_weights && out2 && workspace, OSR_ERR_INVALID_ARG,
+                "osr_roi_box_losses_fwd: null pointer");
+    OSR_REQUIRE(m >= 0, OSR_ERR_INVALID_ARG, "osr_roi_box_losses_fwd: m < 0");
+    OSR_REQUIRE(workspace_bytes >= (int64_t)RED_BLOCKS * 2 * 4, OSR_ERR_WORKSPACE, "osr_roi_box_losses_fwd: workspace needs %d bytes", RED_BLOCKS * 2 * 4);
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    const float r = m > 0 ? (float)m : 1.0f;
+    const TrScale scale = {{box_weight / r, iou_weight / r, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
+    hipLaunchKernelGGL(roi_box_losses_kernel, dim3(RED_BLOCKS), dim3(256), 0, st, pred_deltas, pred_iou, proposal_boxes, gt_boxes, (const long long*)gt_classes,
+                       gt_iou, (long long)m, num_classes, reg_weights[0], reg_weights[1], reg_weights[2], reg_weights[3], partial);
+    OSR_CHECK_LAUNCH("osr_roi_box_losses_fwd");
+    hipLaunchKernelGGL(tr_final_reduce, dim3(1), dim3(64), 0, st, partial, RED_BLOCKS, 2, scale, out2);
+    OSR_CHECK_LAUNCH("osr_roi_box_losses_fwd(final)");
+    return OSR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// PLN hinge loss forward (prototype_learning_network.py:133-187, COS distance, one prototype per class)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pln_loss_kernel(const float* __restrict__ emb, long long m, int d, const float* __restrict__ protos, int K,
+                                                       const long long* __restrict__ cls, const float* __restrict__ ious, float iou_thr, float alpha,
+                                                       float beta, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float s_p[];  // [K][d]
+    for (int i = threadIdx.x; i < K * d; i += blockDim.x) s_p[i] = protos[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    float v[3] = {0.f, 0.f, 0.f};  // intra, inter, center
+    for (long long r = (long long)blockIdx.x * nw + wid; r < m; r += (long long)gridDim.x * nw) {
+        const long long y = cls[r];
+        if (!(y >= 0 && y < K && ious[r] > iou_thr)) continue;  // foreground of a known class with IoU above the threshold
+        const float* e = emb + r * d;
+        float ss = 0.f;
+        for (int i = lane; i < d; i += 64) { const float x = e[i]; ss += x * x; }
+        ss = osr_wave_sum(ss);
+        const float den = fmaxf(sqrtf(ss), 1e-12f);
+        float intra = 0.f, inter = 1000.f;  // the reference overwrites the own-class column with 1000 before the min
+        for (int c = 0; c < K; ++c) {
+            float dot = 0.f;
+            for (int i = lane; i < d; i += 64) dot += (e[i] / den) * s_p[c * d + i];
+            dot = osr_wave_sum(dot);
+            const float dist = 1.0f - dot;
+            if (c == (int)y) intra = dist; else inter = fminf(inter, dist);
+        }
+        if (lane == 0) { v[0] += fmaxf(intra - alpha, 0.f); v[1] += fmaxf(beta - inter, 0.f); }
+    }
+    // prototype-to-prototype term, once (workgroup 0): c_dist[k] = min_{j != k} (1 - p_k . p_j)
+    if (blockIdx.x == 0) {
+        for (int k = wid; k < K; k += nw) {
+            float cd = 1000.f;
+            for (int j = 0; j < K; ++j) {
+                if (j == k) continue;
+                float dot = 0.f;
+                for (int i = lane; i < d; i += 64) dot += s_p[k * d + i] * s_p[j * d + i];
+                dot = osr_wave_sum(dot);
+                cd = fminf(cd, 1.0f - dot);
+            }
+            if (lane == 0) v[2] += fmaxf(beta + alpha - cd, 0.f);
+        }
+    }
+    tr_block_reduce_store<3>(v, partial);
+}
+
+// loss = weight / M * (sum intra + sum inter + sum center), each sum in workgroup order
+__global__ void pln_finish(const float* __restrict__ partial, int nblocks, float scale, float* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int i = 0; i < nblocks; ++i) { a += partial[i * 3]; b += partial[i * 3 + 1]; c += partial[i * 3 + 2]; }
+    out[0] = ((a + b) + c) * scale;
+}
+
+extern "C" osr_status osr_pln_loss_fwd(const float* emb, int64_t m, int32_t d, const float* protos_normed, int32_t num_known, const int64_t* gt_classes,
+                                       const float* ious, float iou_thr, float alpha, float beta, float loss_weight, float* out1, void* workspace,
+                                       int64_t workspace_bytes, void* stream) {
+    OSR_REQUIRE(emb && protos_normed && gt_classes && ious && out1 && workspace, OSR_ERR_INVALID_ARG, "osr_pln_loss_fwd: null pointer");
+    OSR_REQUIRE(m >= 0 && d >= 1 && num_known >= 1 && (long long)num_known * d <= 16384, OSR_ERR_UNSUPPORTED, "osr_pln_loss_fwd: bad sizes");
+    OSR_REQUIRE(workspace_bytes >= (int64_t)RED_BLOCKS * 3 * 4, OSR_ERR_WORKSPACE, "osr_pln_loss_fwd: workspace needs %d bytes", RED_BLOCKS * 3 * 4);
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    const float s = loss_weight / (m > 0 ? (float)m : 1.0f);
+    hipLaunchKernelGGL(pln_loss_kernel, dim3(RED_BLOCKS), dim3(256), (size_t)num_known * d * 4, st, emb, (long long)m, d, protos_normed, num_known,
+                       (const long long*)gt_classes, ious, iou_thr, alpha, beta, partial);
+    OSR_CHECK_LAUNCH("osr_pln_loss_fwd");
+    hipLaunchKernelGGL(pln_finish, dim3(1), dim3(64), 0, st, (const float*)partial, RED_BLOCKS, s, out1);
+    OSR_CHECK_LAUNCH("osr_pln_loss_fwd(final)");
+    return OSR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// softmax cross-entropy forward (softmax_classifier.py:276-285)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ logits, long long m, int nc /* K+1 */, const long long* __restrict__ cls,
+                                                      int num_classes, int K, float* __restrict__ partial) {
+    float v[2] = {0.f, 0.f};  // sum of -log p[target], count
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
+        const long long c = cls[i];
+        const int t = (c >= 0 && c < K) ? (int)c : (c == num_classes ? K : -1);  // id_map: known -> itself, background -> K, others -> -1
+        if (t < 0) continue;
+        const float* lg = logits + i * nc;
+        float mx = lg[0];
+        for (int j = 1; j < nc; ++j) mx = fmaxf(mx, lg[j]);
+        float s = 0.f;
+        for (int j = 0; j < nc; ++j) s += expf(lg[j] - mx);
+        v[0] += (logf(s) + mx) - lg[t];
+        v[1] += 1.f;
+    }
+    tr_block_reduce_store<2>(v, partial);
+}
+
+__global__ void ce_finish(const float* __restrict__ partial, int nblocks, float weight, float* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    float s = 0.f, c = 0.f;
+    for (int b = 0; b < nblocks; ++b) { s += partial[b * 2]; c += partial[b * 2 + 1]; }
+    out[0] = c > 0.f ? weight * (s / c) : 0.f;
+}
+
+extern "C" osr_status osr_softmax_ce_loss_fwd(const float* logits, int64_t m, int32_t num_known, const int64_t* gt_classes, int32_t num_classes,
+                                              float loss_weight, float* out1, void* workspace, int64_t workspace_bytes, void* stream) {
+    OSR_REQUIRE(logits && gt_classes && out1 && workspace, OSR_ERR_INVALID_ARG, "osr_softmax_ce_loss_fwd: null pointer");
+    OSR_REQUIRE(m >= 0 && num_known >= 1 && num_known <= 1024, OSR_ERR_INVALID_ARG, "osr_softmax_ce_loss_fwd: bad sizes");
+    OSR_REQUIRE(workspace_bytes >= (int64_t)RED_BLOCKS * 2 * 4, OSR_ERR_WORKSPACE, "osr_softmax_ce_loss_fwd: workspace needs %d bytes", RED_BLOCKS * 2 * 4);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ce_loss_kernel, dim3(RED_BLOCKS), dim3(256), 0, st, logits, (long long)m, num_known + 1, (const long long*)gt_classes, num_classes, num_known,
+                       (float*)workspace);
+    OSR_CHECK_LAUNCH("osr_softmax_ce_loss_fwd");
+    hipLaunchKernelGGL(ce_finish, dim3(1), dim3(64), 0, st, (const float*)workspace, RED_BLOCKS, loss_weight, out1);
+    OSR_CHECK_LAUNCH("osr_softmax_ce_loss_fwd(final)");
+    return OSR_OK;
+}

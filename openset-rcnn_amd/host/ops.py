@@ -353,3 +353,137 @@ def assemble_detections(cands, k_keep, k_keep_count, u_keep, u_keep_count, n, un
                                       _p(u_keep_count), cands["u_boxes"].shape[1], u_topk, n, int(unknown_id), _p(class_map), _p(ob),
                                       _p(os_), _p(oc), _p(on), _stream()), "osr_assemble_detections")
     return ob, os_, oc, on
+
+
+# ----------------------------------------------------------------------------------------------------------
+# training step, forward half (targets + losses)
+# ----------------------------------------------------------------------------------------------------------
+def _levels_r(lv: RpnLevels) -> int:
+    return sum(lv.h[i] * lv.w[i] for i in range(lv.num_levels)) * lv.num_anchors
+
+
+def rpn_match_anchors(lv: RpnLevels, cell_anchors, n: int, gt_boxes, gt_count, reg_thr=(0.3, 0.7), obj_thr=(0.1, 0.3)):
+    """gt_boxes (n,gmax,4) fp32 padded, gt_count (n) int32. Returns matched_idx, matched_iou, labels_reg, labels_obj (n,R)."""
+    lib = _lib.load()
+    _need(cell_anchors, torch.float32, "cell_anchors"); _need(gt_boxes, torch.float32, "gt_boxes"); _need(gt_count, torch.int32, "gt_count")
+    gmax, r, dev = gt_boxes.shape[1], _levels_r(lv), gt_boxes.device
+    midx = torch.empty((n, r), dtype=torch.int32, device=dev)
+    miou = torch.empty((n, r), dtype=torch.float32, device=dev)
+    lr = torch.empty((n, r), dtype=torch.int8, device=dev)
+    lo = torch.empty((n, r), dtype=torch.int8, device=dev)
+    ws = torch.empty((n * gmax * 4,), dtype=torch.uint8, device=dev)
+    check(lib.osr_rpn_match_anchors(C.byref(lv), _p(cell_anchors), n, _p(gt_boxes), _p(gt_count), gmax, reg_thr[0], reg_thr[1], obj_thr[0],
+                                    obj_thr[1], _p(midx), _p(miou), _p(lr), _p(lo), _p(ws), ws.numel(), _stream()), "osr_rpn_match_anchors")
+    return midx, miou, lr, lo
+
+
+def subsample_labels_(labels, keys, num_samples: int, positive_fraction: float):
+    """In place on labels (n,r) int8; keys (n,r) fp32 uniform. Returns (num_pos, num_neg) int32 (n)."""
+    lib = _lib.load()
+    _need(labels, torch.int8, "labels"); _need(keys, torch.float32, "keys")
+    if labels.shape != keys.shape or labels.dim() != 2:
+        raise OsrError("labels and keys must both be (n, r)")
+    n, r = labels.shape
+    npos = torch.empty((n,), dtype=torch.int32, device=labels.device)
+    nneg = torch.empty((n,), dtype=torch.int32, device=labels.device)
+    check(lib.osr_subsample_labels(_p(labels), _p(keys), n, r, num_samples, positive_fraction, _p(npos), _p(nneg), _stream()),
+          "osr_subsample_labels")
+    return npos, nneg
+
+
+def rpn_anchor_targets(lv: RpnLevels, cell_anchors, n: int, gt_boxes, gt_count, matched_idx, labels_obj):
+    lib = _lib.load()
+    _need(matched_idx, torch.int32, "matched_idx"); _need(labels_obj, torch.int8, "labels_obj")
+    r, dev = _levels_r(lv), gt_boxes.device
+    mb = torch.empty((n, r, 4), dtype=torch.float32, device=dev)
+    ct = torch.empty((n, r), dtype=torch.float32, device=dev)
+    check(lib.osr_rpn_anchor_targets(C.byref(lv), _p(cell_anchors), n, _p(gt_boxes), _p(gt_count), gt_boxes.shape[1], _p(matched_idx),
+                                     _p(labels_obj), _p(mb), _p(ct), _stream()), "osr_rpn_anchor_targets")
+    return mb, ct
+
+
+def rpn_losses_fwd(lv: RpnLevels, cell_anchors, n: int, pred_deltas, pred_ctr, labels_reg, labels_obj, matched_boxes, ctr_target,
+                   loc_weight=0.5, ctr_weight=0.5, batch_size_per_image=256) -> torch.Tensor:
+    """pred_*: level-major (as the RPN head writes them). Returns 6 floats: loss_rpn_loc, loss_rpn_ctr, 4 anchor counts."""
+    lib = _lib.load()
+    _need(pred_deltas, torch.float32, "pred_deltas"); _need(pred_ctr, torch.float32, "pred_ctr")
+    _need(matched_boxes, torch.float32, "matched_boxes"); _need(ctr_target, torch.float32, "ctr_target")
+    dev = pred_ctr.device
+    out = torch.empty((6,), dtype=torch.float32, device=dev)
+    ws = torch.empty((256 * 6 * 4,), dtype=torch.uint8, device=dev)
+    check(lib.osr_rpn_losses_fwd(C.byref(lv), _p(cell_anchors), n, _p(pred_deltas), _p(pred_ctr), _p(labels_reg), _p(labels_obj),
+                                 _p(matched_boxes), _p(ctr_target), loc_weight, ctr_weight, batch_size_per_image, _p(out), _p(ws),
+                                 ws.numel(), _stream()), "osr_rpn_losses_fwd")
+    return out
+
+
+def roi_match_and_sample(prop_boxes, prop_logits, prop_count, gt_boxes, gt_classes, gt_count, keys, num_classes: int,
+                         batch_size: int = 512, positive_fraction: float = 0.25, iou_thr: float = 0.5):
+    """prop_boxes (n,pcap,4), prop_logits (n,pcap), prop_count (n) int32, gt_boxes (n,gmax,4), gt_classes (n,gmax) int64,
+    gt_count (n) int32, keys (n,pcap+gmax). Returns a dict of padded (n,batch_size,...) outputs."""
+    lib = _lib.load()
+    _need(prop_boxes, torch.float32, "prop_boxes"); _need(prop_logits, torch.float32, "prop_logits"); _need(prop_count, torch.int32, "prop_count")
+    _need(gt_boxes, torch.float32, "gt_boxes"); _need(gt_classes, torch.int64, "gt_classes"); _need(gt_count, torch.int32, "gt_count")
+    _need(keys, torch.float32, "keys")
+    n, pcap = prop_boxes.shape[0], prop_boxes.shape[1]
+    gmax, dev = gt_boxes.shape[1], prop_boxes.device
+    if tuple(keys.shape) != (n, pcap + gmax):
+        raise OsrError(f"keys must be (n, pcap+gmax) = ({n}, {pcap + gmax}), got {tuple(keys.shape)}")
+    wsb = lib.osr_roi_match_sample_workspace_bytes(n, pcap, gmax)
+    if wsb < 0:
+        check(int(wsb), "osr_roi_match_sample_workspace_bytes")
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    o = dict(boxes=torch.empty((n, batch_size, 4), dtype=torch.float32, device=dev),
+             logits=torch.empty((n, batch_size), dtype=torch.float32, device=dev),
+             gt_classes=torch.empty((n, batch_size), dtype=torch.int64, device=dev),
+             ious=torch.empty((n, batch_size), dtype=torch.float32, device=dev),
+             gt_boxes=torch.empty((n, batch_size, 4), dtype=torch.float32, device=dev),
+             src=torch.empty((n, batch_size), dtype=torch.int32, device=dev),
+             counts=torch.empty((n, 3), dtype=torch.int32, device=dev))
+    check(lib.osr_roi_match_and_sample(_p(prop_boxes), _p(prop_logits), _p(prop_count), pcap, _p(gt_boxes), _p(gt_classes), _p(gt_count), gmax, n,
+                                       _p(keys), num_classes, batch_size, positive_fraction, iou_thr, _p(o["boxes"]), _p(o["logits"]),
+                                       _p(o["gt_classes"]), _p(o["ious"]), _p(o["gt_boxes"]), _p(o["src"]), _p(o["counts"]), _p(ws), wsb,
+                                       _stream()), "osr_roi_match_and_sample")
+    return o
+
+
+def _loss_ws(dev, nv: int):
+    return torch.empty((256 * nv * 4,), dtype=torch.uint8, device=dev)
+
+
+def roi_box_losses_fwd(pred_deltas, pred_iou, proposal_boxes, gt_boxes, gt_classes, gt_iou, num_classes: int,
+                       reg_weights=(10.0, 10.0, 5.0, 5.0), box_weight=0.5, iou_weight=0.5) -> torch.Tensor:
+    lib = _lib.load()
+    for t, nm in ((pred_deltas, "pred_deltas"), (pred_iou, "pred_iou"), (proposal_boxes, "proposal_boxes"), (gt_boxes, "gt_boxes"), (gt_iou, "gt_iou")):
+        _need(t, torch.float32, nm)
+    _need(gt_classes, torch.int64, "gt_classes")
+    m, dev = gt_classes.numel(), pred_iou.device
+    out = torch.empty((2,), dtype=torch.float32, device=dev)
+    ws = _loss_ws(dev, 2)
+    rw = (C.c_float * 4)(*reg_weights)
+    check(lib.osr_roi_box_losses_fwd(_p(pred_deltas), _p(pred_iou), _p(proposal_boxes), _p(gt_boxes), _p(gt_classes), _p(gt_iou), m, num_classes,
+                                     rw, box_weight, iou_weight, _p(out), _p(ws), ws.numel(), _stream()), "osr_roi_box_losses_fwd")
+    return out
+
+
+def pln_loss_fwd(emb, protos_normed, gt_classes, ious, iou_thr: float, alpha: float, beta: float, loss_weight: float) -> torch.Tensor:
+    lib = _lib.load()
+    _need(emb, torch.float32, "emb"); _need(protos_normed, torch.float32, "protos_normed"); _need(gt_classes, torch.int64, "gt_classes")
+    _need(ious, torch.float32, "ious")
+    m, d = emb.shape
+    out = torch.empty((1,), dtype=torch.float32, device=emb.device)
+    ws = _loss_ws(emb.device, 3)
+    check(lib.osr_pln_loss_fwd(_p(emb), m, d, _p(protos_normed), protos_normed.shape[0], _p(gt_classes), _p(ious), iou_thr, alpha, beta,
+                               loss_weight, _p(out), _p(ws), ws.numel(), _stream()), "osr_pln_loss_fwd")
+    return out
+
+
+def softmax_ce_loss_fwd(logits, gt_classes, num_classes: int, loss_weight: float) -> torch.Tensor:
+    lib = _lib.load()
+    _need(logits, torch.float32, "logits"); _need(gt_classes, torch.int64, "gt_classes")
+    m, nk1 = logits.shape
+    out = torch.empty((1,), dtype=torch.float32, device=logits.device)
+    ws = _loss_ws(logits.device, 2)
+    check(lib.osr_softmax_ce_loss_fwd(_p(logits), m, nk1 - 1, _p(gt_classes), num_classes, loss_weight, _p(out), _p(ws), ws.numel(), _stream()),
+          "osr_softmax_ce_loss_fwd")
+    return out

@@ -765,3 +765,121 @@ def pln_loss(feats, gt_classes, ious, p, alpha, beta, loss_weight, num_known=20,
     loss = (torch.clamp(intra - alpha, min=0).sum() + torch.clamp(beta - inter, min=0).sum()
             + torch.clamp(beta + alpha - cdist, min=0).sum())
     return emb, rec, loss * loss_weight / max(gt_classes.numel(), 1.0)
+
+
+# --------------------------------------------------------------------------------------
+# Training targets / losses, continued (forward only). Random sampling: the reference draws
+# torch.randperm inside [d2] subsample_labels (RNG-stream dependent, SURVEY H6). Oracle and HIP
+# kernels instead take caller-supplied uniform keys and keep the k smallest keys of each class
+# (ties: lower index) -- the same distribution, reproducible, and the selected lists are ordered
+# by key, which plays the role of the randperm order.
+# --------------------------------------------------------------------------------------
+
+
+def _k_smallest(keys: torch.Tensor, mask: torch.Tensor, k: int) -> torch.Tensor:
+    idx = torch.nonzero(mask).squeeze(1)
+    if k <= 0 or idx.numel() == 0:
+        return idx[:0]
+    order = torch.sort(keys[idx], stable=True)[1]
+    return idx[order[:k]]
+
+
+def subsample_by_keys(labels: torch.Tensor, keys: torch.Tensor, num_samples: int, positive_fraction: float, bg_label: int):
+    """[d2] subsample_labels(labels, num_samples, positive_fraction, bg_label) with keys instead of randperm.
+    Returns (pos_idx, neg_idx), each ordered by key."""
+    pos = (labels != -1) & (labels != bg_label)
+    neg = labels == bg_label
+    num_pos = min(int(num_samples * positive_fraction), int(pos.sum()))
+    num_neg = min(num_samples - num_pos, int(neg.sum()))
+    return _k_smallest(keys, pos, num_pos), _k_smallest(keys, neg, num_neg)
+
+
+def rpn_label_and_sample(anchors: torch.Tensor, gt_boxes: torch.Tensor, keys_reg: torch.Tensor, keys_obj: torch.Tensor,
+                         reg_thr=(0.3, 0.7), obj_thr=(0.1, 0.3), batch_size=256, pos_frac=0.5, obj_pos_frac=1.0):
+    """ClsFreeRPN.label_and_sample_anchors for one image (classification_free_rpn.py:359-409)."""
+    q = pairwise_iou(gt_boxes, anchors)
+    midx, lab = matcher(q, list(reg_thr), [0, -1, 1], True)
+    _, olab = matcher(q, list(obj_thr), [0, -1, 1], True)
+    miou = q.max(dim=0)[0] if q.numel() else torch.zeros(anchors.shape[0])
+
+    def sub(l, keys, frac):
+        p, n = subsample_by_keys(l, keys, batch_size, frac, 0)
+        out = torch.full_like(l, -1)
+        out[p] = 1
+        out[n] = 0
+        return out
+
+    lab_s, olab_s = sub(lab, keys_reg, pos_frac), sub(olab, keys_obj, obj_pos_frac)
+    if len(gt_boxes) == 0:
+        mboxes = torch.zeros_like(anchors)
+        ctr = torch.zeros(anchors.shape[0])
+    else:
+        mboxes = gt_boxes[midx]
+        ctr = centerness_target(anchors, gt_boxes[midx], olab_s)
+    return dict(matched_idx=midx, matched_iou=miou, labels_pre=lab, obj_labels_pre=olab, labels=lab_s, obj_labels=olab_s,
+                matched_boxes=mboxes, ctr_target=ctr)
+
+
+def rpn_losses(anchors: torch.Tensor, pred_deltas: torch.Tensor, pred_ctr: torch.Tensor, labels: torch.Tensor, obj_labels: torch.Tensor,
+               matched_boxes: torch.Tensor, ctr_target: torch.Tensor, batch_size=256, w_loc=0.5, w_ctr=0.5):
+    """ClsFreeRPN.losses with BBOX_REG_LOSS_TYPE "iou" (classification_free_rpn.py:446-490; box_regression_w_iou.py:49-61).
+    All inputs stacked over images: pred_deltas (N,R,4), pred_ctr (N,R), labels (N,R) ..."""
+    n = labels.shape[0]
+    pos = labels == 1
+    pb = torch.stack([ltrb_apply_deltas(pred_deltas[i], anchors) for i in range(n)])
+    ious = elementwise_iou(pb[pos], matched_boxes[pos]).clamp(min=1e-6)
+    loss_loc = torch.sum(1 - ious)
+    om = obj_labels != -1
+    loss_ctr = torch.sum(torch.abs(pred_ctr[om] - ctr_target[om]))
+    norm = batch_size * n
+    return dict(loss_rpn_loc=loss_loc / norm * w_loc, loss_rpn_ctr=loss_ctr / norm * w_ctr,
+                num_pos=int(pos.sum()), num_neg=int((labels == 0).sum()),
+                obj_num_pos=int((obj_labels == 1).sum()), obj_num_neg=int((obj_labels == 0).sum()))
+
+
+GT_PROPOSAL_LOGIT = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))
+
+
+def roi_label_and_sample(prop_boxes: torch.Tensor, prop_logits: torch.Tensor, gt_boxes: torch.Tensor, gt_classes: torch.Tensor,
+                         keys: torch.Tensor, num_classes=81, batch_size=512, pos_frac=0.25, iou_thr=0.5):
+    """OpensetROIHeads.label_and_sample_proposals for one image (osrcnn_roi_heads.py:177-216):
+    append GT ([d2] add_ground_truth_to_proposals), IoU, Matcher([0.5],[0,1]), matched_iou, sample 512 (<=25% fg).
+    keys has one entry per (proposal..., gt...) candidate. Output rows are [fg by key..., bg by key...]."""
+    boxes = torch.cat((prop_boxes, gt_boxes))
+    logits = torch.cat((prop_logits, torch.full((len(gt_boxes),), GT_PROPOSAL_LOGIT)))
+    q = pairwise_iou(gt_boxes, boxes)
+    midx, mlab = matcher(q, [iou_thr], [0, 1], False)
+    if len(gt_boxes):
+        miou = q[midx, torch.arange(q.shape[1])]
+        cls = gt_classes[midx].clone()
+        cls[mlab == 0] = num_classes
+    else:
+        miou = torch.zeros(len(boxes))
+        cls = torch.full((len(boxes),), num_classes, dtype=torch.int64)
+    fg, bg = subsample_by_keys(cls, keys, batch_size, pos_frac, num_classes)
+    sidx = torch.cat((fg, bg))
+    gtb = gt_boxes[midx[sidx]] if len(gt_boxes) else torch.zeros(len(sidx), 4)
+    return dict(sampled_idx=sidx, boxes=boxes[sidx], logits=logits[sidx], gt_classes=cls[sidx], ious=miou[sidx], gt_boxes=gtb,
+                num_fg=len(fg), num_bg=len(bg))
+
+
+def roi_box_losses(pred_deltas, pred_iou, proposal_boxes, gt_boxes, gt_classes, gt_iou, num_classes=81, w_box=0.5, w_iou=0.5):
+    """OpensetFastRCNNOutputLayers.losses (osrcnn_fast_rcnn.py:266-370): L1 on Box2BoxTransform deltas and L1 on the
+    predicted IoU over foreground rows, both divided by the total number of rows."""
+    fg = (gt_classes >= 0) & (gt_classes < num_classes)
+    tgt = b2b_get_deltas(proposal_boxes[fg], gt_boxes[fg])
+    lb = torch.abs(pred_deltas[fg] - tgt).sum()
+    li = torch.abs(pred_iou[fg] - gt_iou[fg]).sum()
+    r = max(gt_classes.numel(), 1.0)
+    return lb / r * w_box, li / r * w_iou
+
+
+def softmax_ce_loss(logits, gt_classes, num_classes=81, num_known=20, weight=0.9):
+    """SoftMaxClassifier.loss (softmax_classifier.py:266-285): id_map (known i -> i, background -> K, anything else -> -1),
+    mean cross entropy. Targets of -1 cannot occur with the VOC training data; they are ignored here."""
+    id_map = torch.full((num_classes + 1,), -1, dtype=torch.int64)
+    id_map[:num_known] = torch.arange(num_known)
+    id_map[num_classes] = num_known
+    t = id_map[gt_classes]
+    keep = t >= 0
+    return weight * F.cross_entropy(logits[keep], t[keep], reduction="mean") if bool(keep.any()) else logits.sum() * 0

@@ -316,3 +316,76 @@ def test_fast_rcnn_inference_is_sort_topk():
     order = torch.sort(scores[:, 0], descending=True, stable=True)[1]
     order = order[scores[order, 0] > 0.05][:10]
     assert torch.equal(k, order) and torch.equal(f[:, 0], order.float())
+
+
+# ------------------------------------------------------------------------------------------------------
+# training targets / losses: hand-computed answers
+# ------------------------------------------------------------------------------------------------------
+def test_subsample_by_keys_kat():
+    labels = torch.tensor([1, 1, 0, 0, -1, 1], dtype=torch.int8)
+    keys = torch.tensor([0.5, 0.1, 0.9, 0.2, 0.0, 0.3])
+    pos, neg = O.subsample_by_keys(labels, keys, 4, 0.5, 0)
+    assert pos.tolist() == [1, 5] and neg.tolist() == [3, 2]
+    pos, neg = O.subsample_by_keys(labels, keys, 6, 1.0, 0)  # the objectness sampler: positives first, negatives fill up
+    assert pos.tolist() == [1, 5, 0] and neg.tolist() == [3, 2]
+    pos, neg = O.subsample_by_keys(labels, torch.zeros(6), 2, 0.5, 0)  # all keys tie: lower index wins
+    assert pos.tolist() == [0] and neg.tolist() == [2]
+
+
+def test_rpn_label_and_sample_kat():
+    anchors = torch.tensor([[0.0, 0, 10, 10], [5.0, 0, 15, 10], [20.0, 20, 30, 30]])
+    gt = torch.tensor([[0.0, 0, 10, 10]])
+    keys = torch.tensor([0.3, 0.2, 0.1])
+    r = O.rpn_label_and_sample(anchors, gt, keys, keys)
+    assert r["matched_iou"].tolist() == pytest.approx([1.0, 50.0 / 150.0, 0.0])
+    assert r["labels_pre"].tolist() == [1, -1, 0]       # thresholds (0.3, 0.7)
+    assert r["obj_labels_pre"].tolist() == [1, 1, 0]    # thresholds (0.1, 0.3)
+    assert r["labels"].tolist() == [1, -1, 0] and r["obj_labels"].tolist() == [1, 1, 0]
+    # anchor 0: centre (5,5) inside the GT, l=r=t=b -> 1; anchor 1: centre on the GT's right edge -> 0; anchor 2: label 0 -> 0
+    assert r["ctr_target"].tolist() == pytest.approx([1.0, 0.0, 0.0])
+    assert torch.equal(r["matched_boxes"], gt.expand(3, 4))
+    # no GT: everything background, zero targets
+    r0 = O.rpn_label_and_sample(anchors, torch.zeros(0, 4), keys, keys)
+    assert r0["labels"].tolist() == [0, 0, 0] and float(r0["ctr_target"].abs().sum()) == 0.0
+
+
+def test_rpn_losses_kat():
+    anchors = torch.tensor([[0.0, 0, 10, 10], [20.0, 20, 30, 30]])
+    # deltas (l,t,r,b)/size: anchor 0 -> box [0,0,10,10] (IoU 1 with its GT), anchor 1 -> [20,20,30,30] vs GT [20,20,30,40] (IoU .5)
+    deltas = torch.tensor([[[0.5, 0.5, 0.5, 0.5], [0.5, 0.5, 0.5, 0.5]]])
+    mboxes = torch.tensor([[[0.0, 0, 10, 10], [20.0, 20, 30, 40]]])
+    out = O.rpn_losses(anchors, deltas, torch.tensor([[0.25, 0.5]]), torch.tensor([[1, 1]], dtype=torch.int8),
+                       torch.tensor([[1, 0]], dtype=torch.int8), mboxes, torch.tensor([[1.0, 0.0]]), batch_size=2, w_loc=0.5, w_ctr=0.5)
+    assert float(out["loss_rpn_loc"]) == pytest.approx((0.0 + 0.5) / 2 * 0.5)
+    assert float(out["loss_rpn_ctr"]) == pytest.approx((0.75 + 0.5) / 2 * 0.5)
+    assert (out["num_pos"], out["num_neg"], out["obj_num_pos"], out["obj_num_neg"]) == (2, 0, 1, 1)
+
+
+def test_roi_label_and_sample_kat():
+    props = torch.tensor([[0.0, 0, 10, 10], [50.0, 50, 60, 60], [0.0, 0, 10, 20]])
+    gt, cls = torch.tensor([[0.0, 0, 10, 10]]), torch.tensor([7])
+    r = O.roi_label_and_sample(props, torch.tensor([0.1, 0.2, 0.3]), gt, cls, torch.tensor([0.9, 0.5, 0.4, 0.1]), num_classes=81,
+                               batch_size=4, pos_frac=0.25)
+    # candidates: 3 proposals + the GT box; IoU 1, 0, .5, 1 -> fg {0, 2, 3}; one fg slot: the smallest key is the GT (0.1)
+    assert r["sampled_idx"].tolist() == [3, 1] and r["gt_classes"].tolist() == [7, 81]
+    assert r["ious"].tolist() == [1.0, 0.0] and r["num_fg"] == 1 and r["num_bg"] == 1
+    assert float(r["logits"][0]) == pytest.approx(23.02585, rel=1e-5)  # log((1-1e-10)/1e-10)
+
+
+def test_box_pln_ce_loss_kats():
+    # proposal == gt -> zero deltas; prediction 0.1 everywhere -> L1 = 0.4 on the single foreground row of 2
+    cls = torch.tensor([3, 81])
+    b = torch.tensor([[0.0, 0, 10, 10], [5.0, 5, 9, 9]])
+    lb, li = O.roi_box_losses(torch.full((2, 4), 0.1), torch.tensor([0.5, 0.9]), b, b, cls, torch.tensor([1.0, 0.0]))
+    assert float(lb) == pytest.approx(0.4 / 2 * 0.5) and float(li) == pytest.approx(0.5 / 2 * 0.5)
+    # uniform logits: CE = log(K+1)
+    ce = O.softmax_ce_loss(torch.zeros(3, 21), torch.tensor([0, 81, 19]), 81, 20, 0.9)
+    assert float(ce) == pytest.approx(0.9 * math.log(21.0), rel=1e-6)
+    # PLN with orthonormal prototypes and an embedding equal to its own prototype: intra 0, inter 1, centre distances 1
+    p = {"roi_heads.dml.encoder.weight": torch.eye(4), "roi_heads.dml.encoder.bias": torch.zeros(4),
+         "roi_heads.dml.decoder.weight": torch.eye(4), "roi_heads.dml.decoder.bias": torch.zeros(4),
+         "roi_heads.dml.representatives": torch.eye(4)[:3] * 2.0}
+    feats = torch.tensor([[3.0, 0, 0, 0], [0.0, 1, 0, 0]])
+    _, _, loss = O.pln_loss(feats, torch.tensor([0, 81]), torch.tensor([0.9, 0.9]), p, alpha=0.1, beta=1.5, loss_weight=2.0, num_known=3)
+    # row 0: relu(0-.1)=0 + relu(1.5-1)=.5 ; prototypes: 3 * relu(1.6-1)=1.8 ; * 2 / 2 rows
+    assert float(loss) == pytest.approx((0.5 + 1.8) * 2.0 / 2, rel=1e-6)

@@ -1,0 +1,207 @@
+"""GPU parity tests for the training-step forward kernels (targets + losses)
+against the oracle's restatement on the same seeded inputs.
+
+Bar: bit-exact for matched indices, labels, sampled index lists, classes, counts and for fp32 values that are
+pure per-element arithmetic (IoUs, matched boxes); 2 ulp for the centerness targets; 1e-5 relative for the loss scalars (sums
+in a different order than torch-CPU, and device logf/expf)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import osr_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops(osr):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: the HIP path has no CPU fallback")
+    osr._lib.load()
+    return osr.ops
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _gt_case(seed, n, hw, gmax, counts, degenerate=False):
+    gg = g(seed)
+    h, w = hw
+    gt = torch.zeros(n, gmax, 4)
+    cls = torch.zeros(n, gmax, dtype=torch.int64)
+    for i, c in enumerate(counts):
+        ctr = torch.rand(c, 2, generator=gg) * torch.tensor([w * 1.0, h * 1.0])
+        size = torch.exp(torch.rand(c, 2, generator=gg) * 3.5 + 2.0)  # 7 .. 245 px
+        b = torch.cat((ctr - size / 2, ctr + size / 2), dim=1)
+        b[:, 0::2].clamp_(0, w)
+        b[:, 1::2].clamp_(0, h)
+        gt[i, :c] = b
+        cls[i, :c] = torch.randint(0, 20, (c,), generator=gg)
+    if degenerate and counts[0] > 1:
+        gt[0, 1] = torch.tensor([17.0, 23.0, 17.0, 23.0])  # zero area: IoU 0 with every anchor ("0 == 0" low-quality quirk)
+    return gt, cls, torch.tensor(counts, dtype=torch.int32)
+
+
+def _rpn_case(ops, seed, shapes, strides, sizes, n, hw, counts, degenerate=False, ties=False):
+    gg = g(seed)
+    gt, _, cnt = _gt_case(seed + 100, n, hw, 8, counts, degenerate)
+    anchors = torch.cat(O.anchor_grid(shapes, strides, sizes))
+    r = anchors.shape[0]
+    kr, ko = torch.rand(n, r, generator=gg), torch.rand(n, r, generator=gg)
+    if ties:
+        kr, ko = (kr * 50).round() / 50, (ko * 50).round() / 50
+    lv = ops.make_rpn_levels(shapes, strides, n, 1)
+    cell = torch.tensor([[[-s / 2, -s / 2, s / 2, s / 2]] for s in sizes], dtype=torch.float32).to(DEV)
+    ref = [O.rpn_label_and_sample(anchors, gt[i, :counts[i]], kr[i], ko[i]) for i in range(n)]
+    return dict(gt=gt, cnt=cnt, anchors=anchors, kr=kr, ko=ko, lv=lv, cell=cell, ref=ref, n=n, r=r, shapes=shapes)
+
+
+def _check_rpn_targets(ops, c, obj_pos_frac=1.0):
+    n = c["n"]
+    midx, miou, lr, lo = ops.rpn_match_anchors(c["lv"], c["cell"], n, c["gt"].to(DEV), c["cnt"].to(DEV))
+    for i, ref in enumerate(c["ref"]):
+        assert torch.equal(midx[i].cpu().long(), ref["matched_idx"]), f"image {i}: matched GT index differs"
+        assert torch.equal(miou[i].cpu(), ref["matched_iou"]), f"image {i}: matched IoU not bit-exact"
+        assert torch.equal(lr[i].cpu(), ref["labels_pre"]), f"image {i}: regression labels differ"
+        assert torch.equal(lo[i].cpu(), ref["obj_labels_pre"]), f"image {i}: objectness labels differ"
+    np_, nn_ = ops.subsample_labels_(lr, c["kr"].to(DEV), 256, 0.5)
+    op_, on_ = ops.subsample_labels_(lo, c["ko"].to(DEV), 256, obj_pos_frac)
+    mb, ct = ops.rpn_anchor_targets(c["lv"], c["cell"], n, c["gt"].to(DEV), c["cnt"].to(DEV), midx, lo)
+    for i, ref in enumerate(c["ref"]):
+        assert torch.equal(lr[i].cpu(), ref["labels"]), f"image {i}: sampled regression labels differ"
+        assert torch.equal(lo[i].cpu(), ref["obj_labels"]), f"image {i}: sampled objectness labels differ"
+        assert int(np_[i]) == int((ref["labels"] == 1).sum()) and int(nn_[i]) == int((ref["labels"] == 0).sum())
+        assert int(op_[i]) == int((ref["obj_labels"] == 1).sum()) and int(on_[i]) == int((ref["obj_labels"] == 0).sum())
+        assert torch.equal(mb[i].cpu(), ref["matched_boxes"]), f"image {i}: matched boxes differ"
+        # sqrt(div*div): torch-CPU's vectorised kernels differ by 1 ulp between hosts (AVX2 vs AVX-512 boxes) on ~10% of
+        # the non-zero entries, so this one is held to 2 ulp instead of bit equality; zeros must stay exact zeros.
+        assert torch.allclose(ct[i].cpu(), ref["ctr_target"], rtol=2.4e-7, atol=0.0), f"image {i}: centerness targets differ"
+        assert torch.equal(ct[i].cpu() == 0, ref["ctr_target"] == 0)
+    return lr, lo, mb, ct
+
+
+def _check_rpn_losses(ops, c, lr, lo, mb, ct, seed):
+    gg = g(seed)
+    n, r, shapes = c["n"], c["r"], c["shapes"]
+    # predictions as the head writes them: level-major, image inside level
+    pd = [torch.randn(n, h * w, 4, generator=gg) * 0.8 for h, w in shapes]
+    pc = [torch.rand(n, h * w, generator=gg) for h, w in shapes]
+    pd_img, pc_img = torch.cat(pd, dim=1), torch.cat(pc, dim=1)  # (n, R, ...) image-major for the oracle
+    ref = O.rpn_losses(c["anchors"], pd_img, pc_img, torch.stack([x["labels"] for x in c["ref"]]),
+                       torch.stack([x["obj_labels"] for x in c["ref"]]), torch.stack([x["matched_boxes"] for x in c["ref"]]),
+                       torch.stack([x["ctr_target"] for x in c["ref"]]))
+    out = ops.rpn_losses_fwd(c["lv"], c["cell"], n, torch.cat([d.reshape(-1, 4) for d in pd]).to(DEV),
+                             torch.cat([x.reshape(-1) for x in pc]).to(DEV), lr, lo, mb, ct).cpu()
+    assert out[0].item() == pytest.approx(float(ref["loss_rpn_loc"]), rel=1e-5, abs=1e-7)
+    assert out[1].item() == pytest.approx(float(ref["loss_rpn_ctr"]), rel=1e-5, abs=1e-7)
+    assert [int(v) for v in out[2:]] == [ref["num_pos"], ref["num_neg"], ref["obj_num_pos"], ref["obj_num_neg"]]
+    out2 = ops.rpn_losses_fwd(c["lv"], c["cell"], n, torch.cat([d.reshape(-1, 4) for d in pd]).to(DEV),
+                              torch.cat([x.reshape(-1) for x in pc]).to(DEV), lr, lo, mb, ct).cpu()
+    assert torch.equal(out, out2), "loss reduction must be bitwise reproducible"
+
+
+def test_rpn_targets_and_losses_small(ops):
+    shapes, strides, sizes = [(24, 40), (12, 20), (6, 10), (3, 5)], (4, 8, 16, 32), (32, 64, 128, 256)
+    c = _rpn_case(ops, 31, shapes, strides, sizes, 3, (96, 160), [5, 0, 2], ties=True)  # image 1 has no GT
+    lr, lo, mb, ct = _check_rpn_targets(ops, c)
+    _check_rpn_losses(ops, c, lr, lo, mb, ct, 32)
+
+
+def test_rpn_targets_degenerate_gt(ops):
+    shapes, strides, sizes = [(24, 40), (12, 20), (6, 10), (3, 5)], (4, 8, 16, 32), (32, 64, 128, 256)
+    c = _rpn_case(ops, 33, shapes, strides, sizes, 2, (96, 160), [3, 8], degenerate=True)
+    assert int((c["ref"][0]["labels_pre"] == 1).sum()) > 1000  # the quirk: (almost) every anchor is a low-quality match
+    lr, lo, mb, ct = _check_rpn_targets(ops, c)
+    _check_rpn_losses(ops, c, lr, lo, mb, ct, 34)
+
+
+def test_rpn_targets_full_size(ops):
+    shapes = O.level_shapes(800, 1344)
+    c = _rpn_case(ops, 35, shapes, O.FPN_STRIDES, O.ANCHOR_SIZES, 2, (800, 1333), [8, 3])
+    assert c["r"] == 89523
+    lr, lo, mb, ct = _check_rpn_targets(ops, c)
+    _check_rpn_losses(ops, c, lr, lo, mb, ct, 36)
+
+
+# ------------------------------------------------------------------------------------------------------
+def _roi_case(seed, n, pcap, counts_p, counts_g, hw=(600, 800), gmax=8, ties=False):
+    gg = g(seed)
+    gt, cls, gcnt = _gt_case(seed + 7, n, hw, gmax, counts_g)
+    pb = torch.zeros(n, pcap, 4)
+    pl = torch.zeros(n, pcap)
+    for i, (p, c) in enumerate(zip(counts_p, counts_g)):
+        # half jittered copies of GT boxes (foreground candidates), half random boxes
+        k = p // 2 if c else 0
+        if k:
+            src = gt[i, torch.randint(0, c, (k,), generator=gg)]
+            wh = (src[:, 2:] - src[:, :2]).repeat(1, 2)
+            pb[i, :k] = src + (torch.rand(k, 4, generator=gg) - 0.5) * 0.5 * wh
+        ctr = torch.rand(p - k, 2, generator=gg) * torch.tensor([hw[1] * 1.0, hw[0] * 1.0])
+        size = torch.exp(torch.rand(p - k, 2, generator=gg) * 4.0 + 1.5)
+        pb[i, k:p] = torch.cat((ctr - size / 2, ctr + size / 2), dim=1)
+        pl[i, :p] = torch.randn(p, generator=gg)
+    keys = torch.rand(n, pcap + gmax, generator=gg)
+    if ties:
+        keys = (keys * 40).round() / 40
+    return pb, pl, torch.tensor(counts_p, dtype=torch.int32), gt, cls, gcnt, keys
+
+
+@pytest.mark.parametrize("pcap,counts_p,counts_g,ties", [(300, [300, 120, 40], [4, 0, 8], True), (7323, [7323, 5000], [6, 2], False)])
+def test_roi_match_and_sample(ops, pcap, counts_p, counts_g, ties):
+    n = len(counts_p)
+    pb, pl, pcnt, gt, cls, gcnt, keys = _roi_case(41, n, pcap, counts_p, counts_g, ties=ties)
+    o = ops.roi_match_and_sample(pb.to(DEV), pl.to(DEV), pcnt.to(DEV), gt.to(DEV), cls.to(DEV), gcnt.to(DEV), keys.to(DEV), 81)
+    o = {k: v.cpu() for k, v in o.items()}
+    for i in range(n):
+        p, c = counts_p[i], counts_g[i]
+        ki = torch.cat((keys[i, :p], keys[i, pcap:pcap + c]))  # candidate order: proposals then GT
+        ref = O.roi_label_and_sample(pb[i, :p], pl[i, :p], gt[i, :c], cls[i, :c], ki)
+        m = len(ref["sampled_idx"])
+        assert o["counts"][i].tolist() == [m, ref["num_fg"], ref["num_bg"]], f"image {i}: counts {o['counts'][i].tolist()}"
+        assert torch.equal(o["src"][i, :m].long(), ref["sampled_idx"]), f"image {i}: sampled candidates differ"
+        assert torch.equal(o["gt_classes"][i, :m], ref["gt_classes"])
+        assert torch.equal(o["boxes"][i, :m], ref["boxes"])
+        assert torch.equal(o["ious"][i, :m], ref["ious"]), f"image {i}: matched IoU not bit-exact"
+        assert torch.equal(o["gt_boxes"][i, :m], ref["gt_boxes"])
+        assert torch.equal(o["logits"][i, :m], ref["logits"].float())
+        assert bool((o["gt_classes"][i, m:] == -1).all()) and bool((o["src"][i, m:] == -1).all())
+        if c:
+            assert ref["num_fg"] > 0
+
+
+def test_roi_box_pln_ce_losses(ops):
+    gg = g(51)
+    m, K, NC = 1024, 20, 81
+    cls = torch.randint(0, K, (m,), generator=gg)
+    cls[torch.rand(m, generator=gg) < 0.7] = NC  # background
+    cls[5] = 40    # a class outside the known set (ignored by PLN and CE, foreground for the box loss)
+    cls[6] = -1    # ignore label
+    prop = torch.rand(m, 4, generator=gg) * 300
+    prop[:, 2:] = prop[:, :2] + 8 + torch.rand(m, 2, generator=gg) * 200
+    gtb = prop + torch.randn(m, 4, generator=gg) * 6
+    gtb[:, 2:] = torch.max(gtb[:, 2:], gtb[:, :2] + 2)
+    pd, pi, gi = torch.randn(m, 4, generator=gg), torch.rand(m, generator=gg), torch.rand(m, generator=gg)
+    ref_b, ref_i = O.roi_box_losses(pd, pi, prop, gtb, cls, gi)
+    out = ops.roi_box_losses_fwd(pd.to(DEV), pi.to(DEV), prop.to(DEV), gtb.to(DEV), cls.to(DEV), gi.to(DEV), NC).cpu()
+    assert out[0].item() == pytest.approx(float(ref_b), rel=1e-5)
+    assert out[1].item() == pytest.approx(float(ref_i), rel=1e-5)
+
+    # PLN hinge loss: embeddings near / far from prototypes so that all three terms are active
+    d = 256
+    p = O.make_head_params(seed=3, num_known=K)
+    protos = F.normalize(p["roi_heads.dml.representatives"])
+    feats = torch.randn(m, 1024, generator=gg)
+    emb_ref, _, ref_l = O.pln_loss(feats, cls, gi, p, alpha=0.15, beta=1.2, loss_weight=1.0, num_known=K, iou_thr=0.5)
+    out = ops.pln_loss_fwd(emb_ref.contiguous().to(DEV), protos.contiguous().to(DEV), cls.to(DEV), gi.to(DEV), 0.5, 0.15, 1.2, 1.0).cpu()
+    assert float(ref_l) > 0
+    assert out[0].item() == pytest.approx(float(ref_l), rel=2e-5)
+
+    logits = torch.randn(m, K + 1, generator=gg) * 3
+    ref_c = O.softmax_ce_loss(logits, cls.clamp(min=0), NC, K, 0.9)
+    out = ops.softmax_ce_loss_fwd(logits.to(DEV), cls.clamp(min=0).to(DEV), NC, 0.9).cpu()
+    assert out[0].item() == pytest.approx(float(ref_c), rel=1e-5)
+    # no rows / no valid rows
+    z = ops.softmax_ce_loss_fwd(logits[:4].to(DEV), torch.full((4,), 50, dtype=torch.int64).to(DEV), NC, 0.9).cpu()
+    assert z[0].item() == 0.0
