@@ -291,7 +291,9 @@ osr_status osr_rpn_losses_fwd(const osr_rpn_levels* levels, const float* cell_an
  * [proposals 0..prop_count[i]), GT 0..gt_count[i])]; keys is (n, pcap+gmax): the key of proposal j is keys[i][j],
  * the key of GT g is keys[i][pcap+g], whatever the counts are.
  * Output rows per image: foreground by ascending key, then background by ascending key, padded to batch_size
- * (class -1, src -1). out_counts: (n,3) = {rows, foreground, background}. batch_size <= 512.
+ * (class -1, src -1, batch index -1; the loss kernels below skip rows with class < 0 and leave them out of their
+ * normalisers, RoIAlign skips rows with batch index -1). out_src: candidate index of each row; out_batch_idx: image
+ * of each row; out_counts: (n,3) = {rows, foreground, background}. batch_size <= 512.
  * --------------------------------------------------------------------------------------------------------- */
 int64_t osr_roi_match_sample_workspace_bytes(int32_t n, int64_t pcap, int32_t gmax);
 osr_status osr_roi_match_and_sample(const float* prop_boxes, const float* prop_logits, const int32_t* prop_count,
@@ -299,21 +301,26 @@ osr_status osr_roi_match_and_sample(const float* prop_boxes, const float* prop_l
                                     const int32_t* gt_count, int32_t gmax, int32_t n, const float* keys,
                                     int32_t num_classes, int32_t batch_size, float positive_fraction, float iou_thr,
                                     float* out_boxes, float* out_logits, int64_t* out_classes, float* out_ious,
-                                    float* out_gt_boxes, int32_t* out_src, int32_t* out_counts, void* workspace,
-                                    int64_t workspace_bytes, void* stream);
+                                    float* out_gt_boxes, int32_t* out_src, int32_t* out_batch_idx, int32_t* out_counts,
+                                    void* workspace, int64_t workspace_bytes, void* stream);
 
-/* OpensetFastRCNNOutputLayers.losses (osrcnn_fast_rcnn.py:312-370): L1 between the predicted deltas and
- * Box2BoxTransform(reg_weights).get_deltas(proposal, gt), and L1 between the predicted and the matched IoU,
- * over rows with 0 <= class < num_classes; both divided by m. out2 = {loss_box_reg, loss_iou}. workspace 2 KiB. */
-osr_status osr_roi_box_losses_fwd(const float* pred_deltas, const float* pred_iou, const float* proposal_boxes,
+/* OpensetFastRCNNOutputLayers.losses (osrcnn_fast_rcnn.py:266-370): L1 between the predicted deltas and
+ * Box2BoxTransform(reg_weights).get_deltas(proposal, gt), and L1 between the predicted and the matched IoU, over
+ * rows with 0 <= class < num_classes; both divided by the number of rows with class >= 0 (the reference's
+ * gt_classes.numel(): its row list has no padding). Predictions are read in place from the predictor GEMM output:
+ * row i's deltas at pred_deltas[i*delta_stride .. +4), its IoU at pred_iou[i*iou_stride]; iou_is_logit applies the
+ * sigmoid of OpensetFastRCNNOutputLayers.forward (:262) in the kernel.
+ * out3 = {loss_box_reg, loss_iou, rows counted}. workspace 3 KiB. */
+osr_status osr_roi_box_losses_fwd(const float* pred_deltas, int32_t delta_stride, const float* pred_iou,
+                                  int32_t iou_stride, int32_t iou_is_logit, const float* proposal_boxes,
                                   const float* gt_boxes, const int64_t* gt_classes, const float* gt_iou, int64_t m,
                                   int32_t num_classes, const float reg_weights[4], float box_weight, float iou_weight,
-                                  float* out2, void* workspace, int64_t workspace_bytes, void* stream);
+                                  float* out3, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* PLN.loss, COS distance, one prototype per class (prototype_learning_network.py:133-187): rows with a known
  * class and IoU > iou_thr contribute relu(d_own - alpha) + relu(beta - min d_other); the prototypes contribute
- * sum_k relu(alpha + beta - min_{j!=k} d(p_k,p_j)); total * loss_weight / m. emb: (m,d) un-normalised encoder
- * output; protos_normed (num_known, d). workspace 3 KiB. */
+ * sum_k relu(alpha + beta - min_{j!=k} d(p_k,p_j)); total * loss_weight / (rows with class >= 0). emb: (m,d)
+ * un-normalised encoder output; protos_normed (num_known, d). workspace 4 KiB. */
 osr_status osr_pln_loss_fwd(const float* emb, int64_t m, int32_t d, const float* protos_normed, int32_t num_known,
                             const int64_t* gt_classes, const float* ious, float iou_thr, float alpha, float beta,
                             float loss_weight, float* out1, void* workspace, int64_t workspace_bytes, void* stream);

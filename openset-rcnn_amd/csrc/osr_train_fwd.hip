@@ -335,11 +335,17 @@ __device__ __forceinline__ void tr_block_reduce_store(float v[NV], float* __rest
 
 // out[q] = scale[q] * sum_b partial[b][q]   (fixed order)
 struct TrScale { float s[RED_MAXV]; };
-__global__ void tr_final_reduce(const float* __restrict__ partial, int nblocks, int nv, TrScale scale, float* __restrict__ out) {
+// out[q] = scale[q] * sum_b partial[b][q] (fixed order); with norm_col >= 0 every column q < norm_col is also divided by
+// max(sum_b partial[b][norm_col], 1) -- the "rows that count" normaliser when the row list is padded.
+__global__ void tr_final_reduce(const float* __restrict__ partial, int nblocks, int nv, TrScale scale, int norm_col, float* __restrict__ out) {
     const int q = threadIdx.x;
     if (q >= nv) return;
-    float x = 0.f;
+    float x = 0.f, c = 0.f;
     for (int b = 0; b < nblocks; ++b) x += partial[(long long)b * nv + q];
+    if (norm_col >= 0 && q < norm_col) {
+        for (int b = 0; b < nblocks; ++b) c += partial[(long long)b * nv + norm_col];
+        x = x / fmaxf(c, 1.0f);
+    }
     out[q] = x * scale.s[q];
 }
 
@@ -391,7 +397,7 @@ extern "C" osr_status osr_rpn_losses_fwd(const osr_rpn_levels* lvl, const float*
     hipLaunchKernelGGL(rpn_losses_kernel, dim3(RED_BLOCKS), dim3(256), 0, st, lv, cell_anchors, n, pred_deltas, pred_ctr, (const signed char*)labels_reg,
                        (const signed char*)labels_obj, matched_boxes, ctr_target, partial);
     OSR_CHECK_LAUNCH("osr_rpn_losses_fwd");
-    hipLaunchKernelGGL(tr_final_reduce, dim3(1), dim3(64), 0, st, partial, RED_BLOCKS, 6, scale, out6);
+    hipLaunchKernelGGL(tr_final_reduce, dim3(1), dim3(64), 0, st, partial, RED_BLOCKS, 6, scale, -1, out6);
     OSR_CHECK_LAUNCH("osr_rpn_losses_fwd(final)");
     return OSR_OK;
 }
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(TR_THREADS) void roi_match_sample_kernel(const floa
                                                                       float* __restrict__ ws_iou, int* __restrict__ ws_midx, float* __restrict__ out_boxes,
                                                                       float* __restrict__ out_logits, long long* __restrict__ out_cls,
                                                                       float* __restrict__ out_iou, float* __restrict__ out_gt, int* __restrict__ out_src,
-                                                                      int* __restrict__ out_counts) {
+                                                                      int* __restrict__ out_bidx, int* __restrict__ out_counts) {
     __shared__ unsigned long long s_sel[TR_MAXK];
     __shared__ int s_idx[TR_MAXK];
     __shared__ int s_hist[256], s_scan[32];
@@ -461,10 +467,11 @@ __global__ __launch_bounds__(TR_THREADS) void roi_match_sample_kernel(const floa
             *reinterpret_cast<float4*>(out_gt + o * 4) = G > 0 ? *reinterpret_cast<const float4*>(gt + ((long long)img * gmax + midx[s]) * 4)
                                                                : make_float4(0.f, 0.f, 0.f, 0.f);
             out_src[o] = s;
+            out_bidx[o] = img;
         } else {
             *reinterpret_cast<float4*>(out_boxes + o * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4*>(out_gt + o * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-            out_logits[o] = 0.f; out_cls[o] = -1; out_iou[o] = 0.f; out_src[o] = -1;
+            out_logits[o] = 0.f; out_cls[o] = -1; out_iou[o] = 0.f; out_src[o] = -1; out_bidx[o] = -1;
         }
     }
     if (tid == 0) { out_counts[img * 3 + 0] = nsel; out_counts[img * 3 + 1] = nfg; out_counts[img * 3 + 2] = nbg; }
@@ -479,9 +486,9 @@ extern "C" osr_status osr_roi_match_and_sample(const float* prop_boxes, const fl
                                                const float* gt_boxes, const int64_t* gt_classes, const int32_t* gt_count, int32_t gmax, int32_t n,
                                                const float* keys, int32_t num_classes, int32_t batch_size, float positive_fraction, float iou_thr,
                                                float* out_boxes, float* out_logits, int64_t* out_classes, float* out_ious, float* out_gt_boxes,
-                                               int32_t* out_src, int32_t* out_counts, void* workspace, int64_t workspace_bytes, void* stream) {
+                                               int32_t* out_src, int32_t* out_batch_idx, int32_t* out_counts, void* workspace, int64_t workspace_bytes, void* stream) {
     OSR_REQUIRE(prop_boxes && prop_logits && prop_count && gt_boxes && gt_classes && gt_count && keys && out_boxes && out_logits && out_classes &&
-                    out_ious && out_gt_boxes && out_src && out_counts && workspace, OSR_ERR_INVALID_ARG, "osr_roi_match_and_sample: null pointer");
+                    out_ious && out_gt_boxes && out_src && out_batch_idx && out_counts && workspace, OSR_ERR_INVALID_ARG, "osr_roi_match_and_sample: null pointer");
     OSR_REQUIRE(n >= 1 && pcap >= 1 && gmax >= 1 && pcap + gmax < (1ll << 30), OSR_ERR_INVALID_ARG, "osr_roi_match_and_sample: bad sizes");
     OSR_REQUIRE(batch_size >= 1 && batch_size <= TR_MAXK, OSR_ERR_UNSUPPORTED, "osr_roi_match_and_sample: batch_size must be in 1..%d", TR_MAXK);
     const int64_t need = (int64_t)n * (pcap + gmax) * 12;
@@ -496,7 +503,7 @@ extern "C" osr_status osr_roi_match_and_sample(const float* prop_boxes, const fl
     hipLaunchKernelGGL(roi_match_sample_kernel, dim3(n), dim3(TR_THREADS), 0, (hipStream_t)stream, prop_boxes, prop_logits, prop_count, (long long)pcap,
                        gt_boxes, (const long long*)gt_classes, gt_count, gmax, keys, num_classes, batch_size, positive_fraction, iou_thr, gt_logit,
                        (int*)ws, (float*)(ws + c * 4), (int*)(ws + c * 8), out_boxes, out_logits, (long long*)out_classes, out_ious, out_gt_boxes,
-                       out_src, out_counts);
+                       out_src, out_batch_idx, out_counts);
     OSR_CHECK_LAUNCH("osr_roi_match_and_sample");
     return OSR_OK;
 }
@@ -504,41 +511,48 @@ extern "C" osr_status osr_roi_match_and_sample(const float* prop_boxes, const fl
 // ------------------------------------------------------------------------------------------------------
 // box / IoU regression losses forward (osrcnn_fast_rcnn.py:312-370)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void roi_box_losses_kernel(const float* __restrict__ pred_deltas, const float* __restrict__ pred_iou,
-                                                             const float* __restrict__ prop, const float* __restrict__ gtb,
-                                                             const long long* __restrict__ cls, const float* __restrict__ gt_iou, long long m,
-                                                             int num_classes, float wx, float wy, float ww, float wh, float* __restrict__ partial) {
-    float v[2] = {0.f, 0.f};
+__global__ __launch_bounds__(256) void roi_box_losses_kernel(const float* __restrict__ pred_deltas, int delta_stride, const float* __restrict__ pred_iou,
+                                                             int iou_stride, int iou_is_logit, const float* __restrict__ prop,
+                                                             const float* __restrict__ gtb, const long long* __restrict__ cls,
+                                                             const float* __restrict__ gt_iou, long long m, int num_classes, float wx, float wy, float ww,
+                                                             float wh, float* __restrict__ partial) {
+    float v[3] = {0.f, 0.f, 0.f};  // box L1, IoU L1, rows that count (class >= 0; padding rows carry -1)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
         const long long c = cls[i];
-        if (c < 0 || c >= num_classes) continue;
+        if (c < 0) continue;
+        v[2] += 1.f;
+        if (c >= num_classes) continue;
         const float4 s = *reinterpret_cast<const float4*>(prop + i * 4), t = *reinterpret_cast<const float4*>(gtb + i * 4);
-        const float4 d = *reinterpret_cast<const float4*>(pred_deltas + i * 4);
+        const float* d = pred_deltas + i * delta_stride;
         // [d2] Box2BoxTransform.get_deltas
         const float sw = s.z - s.x, sh = s.w - s.y, scx = s.x + 0.5f * sw, scy = s.y + 0.5f * sh;
         const float tw = t.z - t.x, th = t.w - t.y, tcx = t.x + 0.5f * tw, tcy = t.y + 0.5f * th;
         const float dx = wx * (tcx - scx) / sw, dy = wy * (tcy - scy) / sh, dw = ww * logf(tw / sw), dh = wh * logf(th / sh);
-        v[0] += fabsf(d.x - dx) + fabsf(d.y - dy) + fabsf(d.z - dw) + fabsf(d.w - dh);
-        v[1] += fabsf(pred_iou[i] - gt_iou[i]);
+        v[0] += fabsf(d[0] - dx) + fabsf(d[1] - dy) + fabsf(d[2] - dw) + fabsf(d[3] - dh);
+        float pi = pred_iou[i * iou_stride];
+        if (iou_is_logit) pi = 1.0f / (1.0f + expf(-pi));  // OpensetFastRCNNOutputLayers.forward: iou_pred(x).sigmoid()
+        v[1] += fabsf(pi - gt_iou[i]);
     }
-    tr_block_reduce_store<2>(v, partial);
+    tr_block_reduce_store<3>(v, partial);
 }
 
-extern "C" osr_status osr_roi_box_losses_fwd(const float* pred_deltas, const float* pred_iou, const float* proposal_boxes, const float* gt_boxes,
-                                             const int64_t* gt_classes, const float* gt_iou, int64_t m, int32_t num_classes, const float reg_weights[4],
-                                             float box_weight, float iou_weight, float* out2, void* workspace, int64_t workspace_bytes, void* stream) {
-    OSR_REQUIRE(pred_deltas && pred_iou && proposal_boxes && gt_boxes && gt_classes && gt_iou && reg_weights && out2 && workspace, OSR_ERR_INVALID_ARG,
+extern "C" osr_status osr_roi_box_losses_fwd(const float* pred_deltas, int32_t delta_stride, const float* pred_iou, int32_t iou_stride,
+                                             int32_t iou_is_logit, const float* proposal_boxes, const float* gt_boxes, const int64_t* gt_classes,
+                                             const float* gt_iou, int64_t m, int32_t num_classes, const float reg_weights[4], float box_weight,
+                                             float iou_weight, float* out3, void* workspace, int64_t workspace_bytes, void* stream) {
+    OSR_REQUIRE(pred_deltas && pred_iou && proposal_boxes && gt_boxes && gt_classes && gt_iou && reg_weights && out3 && workspace, OSR_ERR_INVALID_ARG,
                 "osr_roi_box_losses_fwd: null pointer");
-    OSR_REQUIRE(m >= 0, OSR_ERR_INVALID_ARG, "osr_roi_box_losses_fwd: m < 0");
-    OSR_REQUIRE(workspace_bytes >= (int64_t)RED_BLOCKS * 2 * 4, OSR_ERR_WORKSPACE, "osr_roi_box_losses_fwd: workspace needs %d bytes", RED_BLOCKS * 2 * 4);
+    OSR_REQUIRE(m >= 0 && delta_stride >= 4 && iou_stride >= 1, OSR_ERR_INVALID_ARG, "osr_roi_box_losses_fwd: bad m / strides");
+    OSR_REQUIRE(workspace_bytes >= (int64_t)RED_BLOCKS * 3 * 4, OSR_ERR_WORKSPACE, "osr_roi_box_losses_fwd: workspace needs %d bytes", RED_BLOCKS * 3 * 4);
+    OSR_REQUIRE((((uintptr_t)proposal_boxes | (uintptr_t)gt_boxes) & 15) == 0, OSR_ERR_INVALID_ARG, "osr_roi_box_losses_fwd: box arrays must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)workspace;
-    const float r = m > 0 ? (float)m : 1.0f;
-    const TrScale scale = {{box_weight / r, iou_weight / r, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
-    hipLaunchKernelGGL(roi_box_losses_kernel, dim3(RED_BLOCKS), dim3(256), 0, st, pred_deltas, pred_iou, proposal_boxes, gt_boxes, (const long long*)gt_classes,
-                       gt_iou, (long long)m, num_classes, reg_weights[0], reg_weights[1], reg_weights[2], reg_weights[3], partial);
+    const TrScale scale = {{box_weight, iou_weight, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
+    hipLaunchKernelGGL(roi_box_losses_kernel, dim3(RED_BLOCKS), dim3(256), 0, st, pred_deltas, delta_stride, pred_iou, iou_stride, iou_is_logit, proposal_boxes,
+                       gt_boxes, (const long long*)gt_classes, gt_iou, (long long)m, num_classes, reg_weights[0], reg_weights[1], reg_weights[2],
+                       reg_weights[3], partial);
     OSR_CHECK_LAUNCH("osr_roi_box_losses_fwd");
-    hipLaunchKernelGGL(tr_final_reduce, dim3(1), dim3(64), 0, st, partial, RED_BLOCKS, 2, scale, out2);
+    hipLaunchKernelGGL(tr_final_reduce, dim3(1), dim3(64), 0, st, partial, RED_BLOCKS, 3, scale, 2, out3);
     OSR_CHECK_LAUNCH("osr_roi_box_losses_fwd(final)");
     return OSR_OK;
 }
@@ -553,9 +567,10 @@ __global__ __launch_bounds__(256) void pln_loss_kernel(const float* __restrict__
     for (int i = threadIdx.x; i < K * d; i += blockDim.x) s_p[i] = protos[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    float v[3] = {0.f, 0.f, 0.f};  // intra, inter, center
+    float v[4] = {0.f, 0.f, 0.f, 0.f};  // intra, inter, center, rows that count (class >= 0; padding rows carry -1)
     for (long long r = (long long)blockIdx.x * nw + wid; r < m; r += (long long)gridDim.x * nw) {
         const long long y = cls[r];
+        if (lane == 0 && y >= 0) v[3] += 1.f;
         if (!(y >= 0 && y < K && ious[r] > iou_thr)) continue;  // foreground of a known class with IoU above the threshold
         const float* e = emb + r * d;
         float ss = 0.f;
@@ -586,15 +601,15 @@ __global__ __launch_bounds__(256) void pln_loss_kernel(const float* __restrict__
             if (lane == 0) v[2] += fmaxf(beta + alpha - cd, 0.f);
         }
     }
-    tr_block_reduce_store<3>(v, partial);
+    tr_block_reduce_store<4>(v, partial);
 }
 
 // loss = weight / M * (sum intra + sum inter + sum center), each sum in workgroup order
 __global__ void pln_finish(const float* __restrict__ partial, int nblocks, float scale, float* __restrict__ out) {
     if (threadIdx.x != 0) return;
-    float a = 0.f, b = 0.f, c = 0.f;
-    for (int i = 0; i < nblocks; ++i) { a += partial[i * 3]; b += partial[i * 3 + 1]; c += partial[i * 3 + 2]; }
-    out[0] = ((a + b) + c) * scale;
+    float a = 0.f, b = 0.f, c = 0.f, rows = 0.f;
+    for (int i = 0; i < nblocks; ++i) { a += partial[i * 4]; b += partial[i * 4 + 1]; c += partial[i * 4 + 2]; rows += partial[i * 4 + 3]; }
+    out[0] = ((a + b) + c) * scale / fmaxf(rows, 1.0f);
 }
 
 extern "C" osr_status osr_pln_loss_fwd(const float* emb, int64_t m, int32_t d, const float* protos_normed, int32_t num_known, const int64_t* gt_classes,
@@ -602,14 +617,13 @@ extern "C" osr_status osr_pln_loss_fwd(const float* emb, int64_t m, int32_t d, c
                                        int64_t workspace_bytes, void* stream) {
     OSR_REQUIRE(emb && protos_normed && gt_classes && ious && out1 && workspace, OSR_ERR_INVALID_ARG, "osr_pln_loss_fwd: null pointer");
     OSR_REQUIRE(m >= 0 && d >= 1 && num_known >= 1 && (long long)num_known * d <= 16384, OSR_ERR_UNSUPPORTED, "osr_pln_loss_fwd: bad sizes");
-    OSR_REQUIRE(workspace_bytes >= (int64_t)RED_BLOCKS * 3 * 4, OSR_ERR_WORKSPACE, "osr_pln_loss_fwd: workspace needs %d bytes", RED_BLOCKS * 3 * 4);
+    OSR_REQUIRE(workspace_bytes >= (int64_t)RED_BLOCKS * 4 * 4, OSR_ERR_WORKSPACE, "osr_pln_loss_fwd: workspace needs %d bytes", RED_BLOCKS * 4 * 4);
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)workspace;
-    const float s = loss_weight / (m > 0 ? (float)m : 1.0f);
     hipLaunchKernelGGL(pln_loss_kernel, dim3(RED_BLOCKS), dim3(256), (size_t)num_known * d * 4, st, emb, (long long)m, d, protos_normed, num_known,
                        (const long long*)gt_classes, ious, iou_thr, alpha, beta, partial);
     OSR_CHECK_LAUNCH("osr_pln_loss_fwd");
-    hipLaunchKernelGGL(pln_finish, dim3(1), dim3(64), 0, st, (const float*)partial, RED_BLOCKS, s, out1);
+    hipLaunchKernelGGL(pln_finish, dim3(1), dim3(64), 0, st, (const float*)partial, RED_BLOCKS, loss_weight, out1);
     OSR_CHECK_LAUNCH("osr_pln_loss_fwd(final)");
     return OSR_OK;
 }

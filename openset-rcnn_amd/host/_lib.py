@@ -82,8 +82,8 @@ PROTOTYPES = {
     "osr_rpn_anchor_targets": (I32, [P, P, I32, P, P, I32, P, P, P, P, P]),
     "osr_rpn_losses_fwd": (I32, [P, P, I32, P, P, P, P, P, P, F32, F32, I32, P, P, I64, P]),
     "osr_roi_match_sample_workspace_bytes": (I64, [I32, I64, I32]),
-    "osr_roi_match_and_sample": (I32, [P, P, P, I64, P, P, P, I32, I32, P, I32, I32, F32, F32, P, P, P, P, P, P, P, P, I64, P]),
-    "osr_roi_box_losses_fwd": (I32, [P, P, P, P, P, P, I64, I32, P, F32, F32, P, P, I64, P]),
+    "osr_roi_match_and_sample": (I32, [P, P, P, I64, P, P, P, I32, I32, P, I32, I32, F32, F32, P, P, P, P, P, P, P, P, P, I64, P]),
+    "osr_roi_box_losses_fwd": (I32, [P, I32, P, I32, I32, P, P, P, P, I64, I32, P, F32, F32, P, P, I64, P]),
     "osr_pln_loss_fwd": (I32, [P, I64, I32, P, I32, P, P, F32, F32, F32, F32, P, P, I64, P]),
     "osr_softmax_ce_loss_fwd": (I32, [P, I64, I32, P, I32, F32, P, P, I64, P]),
 }

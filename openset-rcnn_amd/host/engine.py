@@ -29,6 +29,11 @@ DEFAULT_CFG = dict(
     known_score_thresh=0.05, known_nms_thresh=0.5, known_topk=50,
     unknown_score_thresh=0.0, unknown_nms_thresh=0.5, unknown_topk=50,
     num_classes=81, num_known=20, reps_per_class=1, unknown_id=80, unk_thr=0.23,
+    # training step (configs/VOC-COCO/openset_rcnn_R50_FPN_128k.yaml + [d2] defaults)
+    pre_nms_topk_train=2000, rpn_batch_size=256, rpn_positive_fraction=0.5, rpn_positive_fraction_objectness=1.0,
+    rpn_iou_thresholds=(0.3, 0.7), rpn_iou_thresholds_objectness=(0.1, 0.3), rpn_loc_weight=0.5, rpn_ctr_weight=0.5,
+    roi_batch_size=512, roi_positive_fraction=0.25, roi_iou_threshold=0.5, box_reg_weight=0.5, iou_reg_weight=0.5,
+    pln_alpha=0.1, pln_beta=0.9, pln_iou_threshold=0.5, pln_loss_weight=0.5, cls_loss_weight=0.9,
 )
 
 
@@ -166,7 +171,7 @@ class OpensetRCNNEngine:
             self._lv_cache[key] = ops.make_rpn_levels(shapes, self.cfg["fpn_strides"], n, 1)
         return self._lv_cache[key]
 
-    def _rpn(self, feats: Dict[str, torch.Tensor], image_hw: torch.Tensor, keep: Optional[dict] = None):
+    def _rpn(self, feats: Dict[str, torch.Tensor], image_hw: torch.Tensor, keep: Optional[dict] = None, topk: Optional[int] = None):
         fl = [feats[k] for k in ("p2", "p3", "p4", "p5", "p6")]
         n = fl[0].shape[0]
         shapes = [(f.shape[1], f.shape[2]) for f in fl]
@@ -187,8 +192,9 @@ class OpensetRCNNEngine:
                 self._conv(f, "proposal_generator.rpn_head.conv", 1, 1, relu=True, out=t_all[off:off + r])
                 off += r
             deltas, ctr = ops.cfrpn_head_tail(t_all, self.rpn_wd, self.rpn_bd, self.rpn_wc, self.rpn_bc)
-        sel = ops.rpn_select(self._levels(shapes, n), self.cell_anchors, ctr, deltas, n, image_hw, self.cfg["pre_nms_topk_test"],
-                             self.cfg["min_box_size"])
+        sel = ops.rpn_select(self._levels(shapes, n), self.cell_anchors, ctr, deltas, n, image_hw,
+                             self.cfg["pre_nms_topk_test"] if topk is None else topk, self.cfg["min_box_size"])
+        sel.update(pred_deltas=deltas, pred_ctr=ctr, levels=self._levels(shapes, n))
         if keep is not None:
             keep.update(rpn_t=t_all, rpn_deltas=deltas, rpn_ctr=ctr, rpn_shapes=shapes)
         return sel
@@ -297,6 +303,53 @@ class OpensetRCNNEngine:
         with torch.cuda.graph(graph):
             out = self.forward_device_streams(images, image_hw, hp, wp, nstreams)
         return graph, out
+
+    # ---- training step, forward half ----------------------------------------------------------------------
+    def forward_losses(self, images: torch.Tensor, image_hw: torch.Tensor, hp: int, wp: int, gt_boxes: torch.Tensor,
+                       gt_classes: torch.Tensor, gt_count: torch.Tensor, keys: Dict[str, torch.Tensor], keep: Optional[dict] = None):
+        """GeneralizedRCNN.forward in training mode, forward values only (no gradients yet): the loss dict of
+        ClsFreeRPN.forward (classification_free_rpn.py:493-547) and OpensetROIHeads._forward_box (osrcnn_roi_heads.py:282-
+        318) for a batch, every tensor staying on the GPU. gt_boxes (n,gmax,4) fp32 / gt_classes (n,gmax) int64 padded,
+        gt_count (n) int32. keys: uniform fp32 sampling keys 'rpn_reg' (n,R), 'rpn_obj' (n,R), 'roi' (n, cap+gmax) -- the
+        randomness [d2] subsample_labels draws with torch.randperm (see include/osr.h). Returns a dict of 0-d / small GPU
+        tensors named as the reference names its losses."""
+        c = self.cfg
+        n = images.shape[0]
+        feats = self._backbone(images, hp, wp, keep)
+        sel = self._rpn(feats, image_hw, keep, topk=c["pre_nms_topk_train"])
+        lv = sel["levels"]
+        midx, miou, lab, olab = ops.rpn_match_anchors(lv, self.cell_anchors, n, gt_boxes, gt_count, c["rpn_iou_thresholds"],
+                                                      c["rpn_iou_thresholds_objectness"])
+        if keep is not None:
+            keep.update(feats=feats, sel=sel, matched_idx=midx, matched_iou=miou, labels_pre=lab.clone(), obj_labels_pre=olab.clone())
+        ops.subsample_labels_(lab, keys["rpn_reg"], c["rpn_batch_size"], c["rpn_positive_fraction"])
+        ops.subsample_labels_(olab, keys["rpn_obj"], c["rpn_batch_size"], c["rpn_positive_fraction_objectness"])
+        mboxes, ctr_t = ops.rpn_anchor_targets(lv, self.cell_anchors, n, gt_boxes, gt_count, midx, olab)
+        rpn = ops.rpn_losses_fwd(lv, self.cell_anchors, n, sel["pred_deltas"], sel["pred_ctr"], lab, olab, mboxes, ctr_t,
+                                 c["rpn_loc_weight"], c["rpn_ctr_weight"], c["rpn_batch_size"])
+        # RoI heads: proposals are fixed inputs here (predict_proposals runs under no_grad, :575)
+        smp = ops.roi_match_and_sample(sel["boxes"], sel["scores"], sel["counts"], gt_boxes, gt_classes, gt_count, keys["roi"],
+                                       c["num_classes"], c["roi_batch_size"], c["roi_positive_fraction"], c["roi_iou_threshold"])
+        boxes = smp["boxes"].view(-1, 4)
+        pooled = ops.roi_align([feats[k] for k in ("p2", "p3", "p4", "p5")], c["pooler_scales"], boxes, smp["batch_idx"],
+                               c["pooler_resolution"], self.dtype, c["canonical_level"], c["canonical_size"], 2)
+        m = pooled.shape[0]
+        h1 = self._linear(pooled.view(m, -1), self.fc1_w, self.fc1_b, True, name="roi_heads.box_head.fc1")
+        box_feats = self._linear(h1, self.fc2_w, self.fc2_b, True, torch.float32, name="roi_heads.box_head.fc2")
+        pred = ops.gemm_f32(box_feats, self.pred_w, self.pred_b)  # (m,5): 4 deltas + IoU logit
+        cls, ious = smp["gt_classes"].view(-1), smp["ious"].view(-1)
+        box = ops.roi_box_losses_fwd(pred[:, :4], pred[:, 4], boxes, smp["gt_boxes"].view(-1, 4), cls, ious, c["num_classes"],
+                                     c["bbox_reg_weights"], c["box_reg_weight"], c["iou_reg_weight"], iou_is_logit=True)
+        emb = ops.gemm_f32(box_feats, self.enc_w, self.enc_b)
+        rec = ops.gemm_f32(emb, self.dec_w, self.dec_b)
+        dml = ops.pln_loss_fwd(emb, self.protos, cls, ious, c["pln_iou_threshold"], c["pln_alpha"], c["pln_beta"], c["pln_loss_weight"])
+        logits = ops.gemm_f32(rec, self.cls_w, self.cls_b)
+        ce = ops.softmax_ce_loss_fwd(logits, cls, c["num_classes"], c["cls_loss_weight"])
+        if keep is not None:
+            keep.update(labels=lab, obj_labels=olab, matched_boxes=mboxes, ctr_target=ctr_t, sampled=smp, pooled=pooled, box_feats=box_feats,
+                        pred=pred, emb=emb, rec=rec, logits=logits)
+        return dict(loss_rpn_loc=rpn[0], loss_rpn_ctr=rpn[1], loss_box_reg=box[0], loss_iou=box[1], loss_dml=dml[0], loss_cls=ce[0],
+                    rpn_anchor_counts=rpn[2:], roi_counts=smp["counts"])
 
     @staticmethod
     def to_instances(result, n: int) -> List[dict]:

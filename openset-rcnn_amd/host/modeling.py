@@ -7,7 +7,8 @@ registered names the yaml files select --
 
 -- with the same constructor configuration keys, forward signatures, output field names and state-dict key names.
 The modules own fp32 parameters under detectron2's names (checkpoint compatible); their inference forwards run on
-the HIP library through `OpensetRCNNEngine` (no eager path). Training forwards are not built this round and raise.
+the HIP library through `OpensetRCNNEngine` (no eager path). Training: the forward half (targets + loss values) is
+`GeneralizedRCNN.losses_forward`; module forwards in training mode raise until the backward kernels exist.
 Feature maps cross these signatures as logical (N,C,H,W) tensors in channels_last memory (= the kernels' NHWC)."""
 from __future__ import annotations
 
@@ -58,8 +59,8 @@ RPN_HEAD_REGISTRY = Registry("RPN_HEAD")
 ROI_HEADS_REGISTRY = Registry("ROI_HEADS")
 ROI_BOX_HEAD_REGISTRY = Registry("ROI_BOX_HEAD")
 
-_TRAIN_MSG = ("the training forward (targets, losses, backward) of the HIP path is the next scope row (DESIGN.md section 7); "
-              "this build implements inference only")
+_TRAIN_MSG = ("model(batched_inputs) in training mode must return losses that carry gradients; the HIP path has the forward half only "
+              "(targets + loss values: GeneralizedRCNN.losses_forward), the backward kernels are the next scope row (DESIGN.md section 7)")
 
 
 def _to_nhwc(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -349,6 +350,14 @@ def engine_cfg_from(cfg: CfgNode) -> dict:
         num_classes=rh.NUM_CLASSES, num_known=rh.NUM_KNOWN_CLASSES, reps_per_class=cfg.MODEL.PLN.REPS_PER_CLASS,
         # the reference hard-codes the unknown id: 80 with --opendet-benchmark, else 1000
         unknown_id=80 if cfg.OPENDET_BENCHMARK else 1000, unk_thr=cfg.MODEL.PLN.UNK_THR,
+        # training step
+        pre_nms_topk_train=cfg.MODEL.RPN.PRE_NMS_TOPK_TRAIN, rpn_batch_size=cfg.MODEL.RPN.BATCH_SIZE_PER_IMAGE,
+        rpn_positive_fraction=cfg.MODEL.RPN.POSITIVE_FRACTION, rpn_positive_fraction_objectness=cfg.MODEL.RPN.POSITIVE_FRACTION_OBJECTNESS,
+        rpn_iou_thresholds=tuple(cfg.MODEL.RPN.IOU_THRESHOLDS), rpn_iou_thresholds_objectness=tuple(cfg.MODEL.RPN.IOU_THRESHOLDS_OBJECTNESS),
+        rpn_loc_weight=cfg.MODEL.RPN.BBOX_REG_LOSS_WEIGHT, rpn_ctr_weight=cfg.MODEL.RPN.CTR_REG_LOSS_WEIGHT,
+        roi_batch_size=rh.BATCH_SIZE_PER_IMAGE, roi_positive_fraction=rh.POSITIVE_FRACTION, roi_iou_threshold=float(rh.IOU_THRESHOLDS[0]),
+        box_reg_weight=bh.BBOX_REG_LOSS_WEIGHT, iou_reg_weight=bh.IOU_REG_LOSS_WEIGHT, pln_alpha=cfg.MODEL.PLN.ALPHA, pln_beta=cfg.MODEL.PLN.BETA,
+        pln_iou_threshold=cfg.MODEL.PLN.IOU_THRESHOLD, pln_loss_weight=cfg.MODEL.PLN.LOSS_WEIGHT, cls_loss_weight=bh.CLS_LOSS_WEIGHT,
     )
 
 
@@ -465,6 +474,41 @@ class GeneralizedRCNN(_EngineOwner):
         if self.training:
             raise NotImplementedError(_TRAIN_MSG)
         return self.inference(batched_inputs)
+
+    @torch.no_grad()
+    def losses_forward(self, batched_inputs: List[dict], generator: Optional[torch.Generator] = None) -> Dict[str, torch.Tensor]:
+        """The loss dict GeneralizedRCNN.forward returns in training mode ([d2]; train.py:189 trainer loop), forward values
+        only: loss_rpn_loc, loss_rpn_ctr, loss_box_reg, loss_iou, loss_dml, loss_cls. Each input dict carries "image" and
+        "instances" (gt_boxes: Boxes, gt_classes). Images must share one size (the trainer's batches are padded by the
+        caller). `generator` seeds the uniform keys that replace torch.randperm in the two samplers."""
+        eng = self.engine()
+        imgs = [x["image"] for x in batched_inputs]
+        sizes = [(int(i.shape[-2]), int(i.shape[-1])) for i in imgs]
+        if len(set(sizes)) != 1:
+            raise ValueError("losses_forward needs images of one size; pad the batch first")
+        n, dev = len(imgs), self.device
+        batch = torch.stack([i.to(dev) for i in imgs])
+        gmax = max(1, max(len(x["instances"]) for x in batched_inputs))
+        gt = torch.zeros((n, gmax, 4), dtype=torch.float32)
+        gcls = torch.zeros((n, gmax), dtype=torch.int64)
+        gcnt = torch.zeros((n,), dtype=torch.int32)
+        for i, x in enumerate(batched_inputs):
+            k = len(x["instances"])
+            gcnt[i] = k
+            if k:
+                gt[i, :k] = x["instances"].gt_boxes.tensor.float().cpu()
+                gcls[i, :k] = x["instances"].gt_classes.cpu()
+        d = eng.cfg["size_divisibility"]
+        hp, wp = (sizes[0][0] + d - 1) // d * d, (sizes[0][1] + d - 1) // d * d
+        shapes = [((hp // s), (wp // s)) for s in eng.cfg["fpn_strides"][:4]]
+        shapes.append(((shapes[-1][0] - 1) // 2 + 1, (shapes[-1][1] - 1) // 2 + 1))
+        r = sum(a * b for a, b in shapes)
+        cap = sum(min(eng.cfg["pre_nms_topk_train"], a * b) for a, b in shapes)
+        keys = {k: torch.rand(shape, generator=generator).to(dev) for k, shape in
+                (("rpn_reg", (n, r)), ("rpn_obj", (n, r)), ("roi", (n, cap + gmax)))}
+        hw = torch.tensor(sizes, dtype=torch.int32, device=dev)
+        out = eng.forward_losses(batch, hw, hp, wp, gt.to(dev), gcls.to(dev), gcnt.to(dev), keys)
+        return {k: v for k, v in out.items() if k.startswith("loss_")}
 
     @torch.no_grad()
     def inference(self, batched_inputs: List[dict], do_postprocess: bool = True):

@@ -439,10 +439,11 @@ def roi_match_and_sample(prop_boxes, prop_logits, prop_count, gt_boxes, gt_class
              ious=torch.empty((n, batch_size), dtype=torch.float32, device=dev),
              gt_boxes=torch.empty((n, batch_size, 4), dtype=torch.float32, device=dev),
              src=torch.empty((n, batch_size), dtype=torch.int32, device=dev),
+             batch_idx=torch.empty((n * batch_size,), dtype=torch.int32, device=dev),
              counts=torch.empty((n, 3), dtype=torch.int32, device=dev))
     check(lib.osr_roi_match_and_sample(_p(prop_boxes), _p(prop_logits), _p(prop_count), pcap, _p(gt_boxes), _p(gt_classes), _p(gt_count), gmax, n,
                                        _p(keys), num_classes, batch_size, positive_fraction, iou_thr, _p(o["boxes"]), _p(o["logits"]),
-                                       _p(o["gt_classes"]), _p(o["ious"]), _p(o["gt_boxes"]), _p(o["src"]), _p(o["counts"]), _p(ws), wsb,
+                                       _p(o["gt_classes"]), _p(o["ious"]), _p(o["gt_boxes"]), _p(o["src"]), _p(o["batch_idx"]), _p(o["counts"]), _p(ws), wsb,
                                        _stream()), "osr_roi_match_and_sample")
     return o
 
@@ -452,17 +453,23 @@ def _loss_ws(dev, nv: int):
 
 
 def roi_box_losses_fwd(pred_deltas, pred_iou, proposal_boxes, gt_boxes, gt_classes, gt_iou, num_classes: int,
-                       reg_weights=(10.0, 10.0, 5.0, 5.0), box_weight=0.5, iou_weight=0.5) -> torch.Tensor:
+                       reg_weights=(10.0, 10.0, 5.0, 5.0), box_weight=0.5, iou_weight=0.5, iou_is_logit: bool = False) -> torch.Tensor:
+    """pred_deltas (m,>=4) / pred_iou (m) may be column views of one row-major predictor output (stride(1) == 1).
+    Returns 3 floats: loss_box_reg, loss_iou, rows counted (class >= 0)."""
     lib = _lib.load()
-    for t, nm in ((pred_deltas, "pred_deltas"), (pred_iou, "pred_iou"), (proposal_boxes, "proposal_boxes"), (gt_boxes, "gt_boxes"), (gt_iou, "gt_iou")):
+    for t, nm in ((proposal_boxes, "proposal_boxes"), (gt_boxes, "gt_boxes"), (gt_iou, "gt_iou")):
         _need(t, torch.float32, nm)
     _need(gt_classes, torch.int64, "gt_classes")
-    m, dev = gt_classes.numel(), pred_iou.device
-    out = torch.empty((2,), dtype=torch.float32, device=dev)
-    ws = _loss_ws(dev, 2)
+    for t, nm in ((pred_deltas, "pred_deltas"), (pred_iou, "pred_iou")):
+        if not t.is_cuda or t.dtype != torch.float32 or (t.dim() == 2 and t.stride(1) != 1):
+            raise OsrError(f"{nm} must be an fp32 GPU tensor with unit stride inside a row")
+    m, dev = gt_classes.numel(), proposal_boxes.device
+    out = torch.empty((3,), dtype=torch.float32, device=dev)
+    ws = _loss_ws(dev, 3)
     rw = (C.c_float * 4)(*reg_weights)
-    check(lib.osr_roi_box_losses_fwd(_p(pred_deltas), _p(pred_iou), _p(proposal_boxes), _p(gt_boxes), _p(gt_classes), _p(gt_iou), m, num_classes,
-                                     rw, box_weight, iou_weight, _p(out), _p(ws), ws.numel(), _stream()), "osr_roi_box_losses_fwd")
+    check(lib.osr_roi_box_losses_fwd(_p(pred_deltas), pred_deltas.stride(0), _p(pred_iou), pred_iou.stride(0), int(iou_is_logit), _p(proposal_boxes),
+                                     _p(gt_boxes), _p(gt_classes), _p(gt_iou), m, num_classes, rw, box_weight, iou_weight, _p(out), _p(ws),
+                                     ws.numel(), _stream()), "osr_roi_box_losses_fwd")
     return out
 
 
@@ -472,7 +479,7 @@ def pln_loss_fwd(emb, protos_normed, gt_classes, ious, iou_thr: float, alpha: fl
     _need(ious, torch.float32, "ious")
     m, d = emb.shape
     out = torch.empty((1,), dtype=torch.float32, device=emb.device)
-    ws = _loss_ws(emb.device, 3)
+    ws = _loss_ws(emb.device, 4)
     check(lib.osr_pln_loss_fwd(_p(emb), m, d, _p(protos_normed), protos_normed.shape[0], _p(gt_classes), _p(ious), iou_thr, alpha, beta,
                                loss_weight, _p(out), _p(ws), ws.numel(), _stream()), "osr_pln_loss_fwd")
     return out

@@ -174,3 +174,35 @@ def test_mirrored_modules_run_on_the_hip_path(osr, tmp_path):
     # ragged batch path
     out2 = model([{"image": imgs[0]}, {"image": imgs[1][:, :180, :250]}])
     assert len(out2) == 2
+
+
+@pytest.mark.gpu
+def test_losses_forward_through_the_mirror(osr, tmp_path):
+    from openset_rcnn_amd.host import modeling as M
+    from openset_rcnn_amd.host.structures import Boxes, Instances
+    from openset_rcnn_amd.host.weights import random_params
+    cfg = _cfg(osr, tmp_path)
+    model = M.build_model(cfg)
+    p = random_params(0)
+    sd = model.state_dict()
+    for k, v in p.items():
+        if k in sd:
+            sd[k] = v
+        elif k.endswith(".bias") and k[:-5] + ".norm.bias" in sd:
+            sd[k[:-5] + ".norm.bias"] = v
+    model.load_state_dict(sd)
+    model.train()
+    g = torch.Generator().manual_seed(5)
+    inputs = []
+    for i in range(2):
+        inst = Instances((200, 300))
+        inst.gt_boxes = Boxes(torch.tensor([[20.0, 30.0, 120.0, 150.0], [150.0, 40.0, 280.0, 190.0]])[: 2 - i])
+        inst.gt_classes = torch.tensor([3, 17])[: 2 - i]
+        inputs.append({"image": torch.randint(0, 256, (3, 200, 300), generator=g, dtype=torch.uint8), "instances": inst})
+    with pytest.raises(NotImplementedError):
+        model(inputs)  # gradients are not available: the training-mode call must not silently return detached losses
+    l1 = model.losses_forward(inputs, torch.Generator().manual_seed(9))
+    l2 = model.losses_forward(inputs, torch.Generator().manual_seed(9))
+    assert set(l1) == {"loss_rpn_loc", "loss_rpn_ctr", "loss_box_reg", "loss_iou", "loss_dml", "loss_cls"}
+    for k in l1:
+        assert torch.isfinite(l1[k]).all() and float(l1[k]) > 0 and torch.equal(l1[k], l2[k]), k  # reproducible bit for bit

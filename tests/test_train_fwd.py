@@ -167,6 +167,8 @@ def test_roi_match_and_sample(ops, pcap, counts_p, counts_g, ties):
         assert torch.equal(o["gt_boxes"][i, :m], ref["gt_boxes"])
         assert torch.equal(o["logits"][i, :m], ref["logits"].float())
         assert bool((o["gt_classes"][i, m:] == -1).all()) and bool((o["src"][i, m:] == -1).all())
+        bi = o["batch_idx"].view(n, -1)[i]
+        assert bool((bi[:m] == i).all()) and bool((bi[m:] == -1).all())
         if c:
             assert ref["num_fg"] > 0
 
@@ -183,17 +185,25 @@ def test_roi_box_pln_ce_losses(ops):
     gtb = prop + torch.randn(m, 4, generator=gg) * 6
     gtb[:, 2:] = torch.max(gtb[:, 2:], gtb[:, :2] + 2)
     pd, pi, gi = torch.randn(m, 4, generator=gg), torch.rand(m, generator=gg), torch.rand(m, generator=gg)
-    ref_b, ref_i = O.roi_box_losses(pd, pi, prop, gtb, cls, gi)
+    ok = cls >= 0  # the HIP kernels treat class -1 rows as padding; the reference's row list has none
+    ref_b, ref_i = O.roi_box_losses(pd[ok], pi[ok], prop[ok], gtb[ok], cls[ok], gi[ok])
     out = ops.roi_box_losses_fwd(pd.to(DEV), pi.to(DEV), prop.to(DEV), gtb.to(DEV), cls.to(DEV), gi.to(DEV), NC).cpu()
     assert out[0].item() == pytest.approx(float(ref_b), rel=1e-5)
     assert out[1].item() == pytest.approx(float(ref_i), rel=1e-5)
+    assert int(out[2]) == m - 1
+    # the same through column views of a (m,5) predictor output holding IoU logits
+    raw = torch.cat((pd, torch.logit(pi.clamp(1e-4, 1 - 1e-4)).unsqueeze(1)), dim=1).to(DEV)
+    ref_b2, ref_i2 = O.roi_box_losses(pd[ok], torch.sigmoid(raw[:, 4].cpu())[ok], prop[ok], gtb[ok], cls[ok], gi[ok])
+    out = ops.roi_box_losses_fwd(raw[:, :4], raw[:, 4], prop.to(DEV), gtb.to(DEV), cls.to(DEV), gi.to(DEV), NC, iou_is_logit=True).cpu()
+    assert out[0].item() == pytest.approx(float(ref_b2), rel=1e-5) and out[1].item() == pytest.approx(float(ref_i2), rel=1e-5)
 
     # PLN hinge loss: embeddings near / far from prototypes so that all three terms are active
     d = 256
     p = O.make_head_params(seed=3, num_known=K)
     protos = F.normalize(p["roi_heads.dml.representatives"])
     feats = torch.randn(m, 1024, generator=gg)
-    emb_ref, _, ref_l = O.pln_loss(feats, cls, gi, p, alpha=0.15, beta=1.2, loss_weight=1.0, num_known=K, iou_thr=0.5)
+    emb_ref, _, ref_l = O.pln_loss(feats[ok], cls[ok], gi[ok], p, alpha=0.15, beta=1.2, loss_weight=1.0, num_known=K, iou_thr=0.5)
+    emb_ref = F.linear(feats, p["roi_heads.dml.encoder.weight"], p["roi_heads.dml.encoder.bias"])
     out = ops.pln_loss_fwd(emb_ref.contiguous().to(DEV), protos.contiguous().to(DEV), cls.to(DEV), gi.to(DEV), 0.5, 0.15, 1.2, 1.0).cpu()
     assert float(ref_l) > 0
     assert out[0].item() == pytest.approx(float(ref_l), rel=2e-5)
