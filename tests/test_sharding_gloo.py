@@ -66,3 +66,55 @@ def test_shard_range_partitions():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _eval_worker(rank, world, port, voc_dir, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as ge
+    ge.load_package()
+    from openset_rcnn_amd.host.evaluation import PascalVOCDetectionEvaluator, inference_on_dataset
+    from openset_rcnn_amd.host.structures import Boxes, Instances
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def model(batch):  # stand-in detector: one perfect "aeroplane" box per image
+        out = []
+        for x in batch:
+            i = Instances((100, 200))
+            i.pred_boxes = Boxes(torch.tensor([[10.0, 10.0, 60.0, 60.0]]))
+            i.scores = torch.tensor([0.9])
+            i.pred_classes = torch.tensor([0])
+            out.append({"instances": i})
+        return out
+
+    ev = PascalVOCDetectionEvaluator(voc_dir, "toy", ["aeroplane", "unknown"], 1)
+    res = inference_on_dataset(model, [[{"image_id": k}] for k in ("a", "b", "c", "d")], ev)
+    if rank == 0:
+        q.put(res)
+    else:
+        assert res is None
+    dist.destroy_process_group()
+
+
+def test_two_rank_evaluation(tmp_path):
+    d = tmp_path / "voc"
+    (d / "Annotations").mkdir(parents=True)
+    (d / "ImageSets" / "Main").mkdir(parents=True)
+    for k in "abcd":
+        (d / "Annotations" / f"{k}.xml").write_text(
+            "<annotation><size><width>200</width><height>100</height></size><object><name>aeroplane</name><difficult>0</difficult>"
+            "<bndbox><xmin>11</xmin><ymin>11</ymin><xmax>60</xmax><ymax>60</ymax></bndbox></object></annotation>")
+    (d / "ImageSets" / "Main" / "toy.txt").write_text("a\nb\nc\nd\n")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, str(d), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res["AP@K"] == 100.0 and res["R@K"] == 100.0 and res["AOSE"] == 0.0  # all four images counted exactly once
