@@ -75,6 +75,13 @@ def build(verbose: bool = False, force: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+        # clang's host pass silently drops a __global__ template whose body it cannot check (seen with a type-dependent
+        # argument of an amdgcn builtin): the launch stub then stays undefined and dlopen fails on the GPU box. Catch it here.
+        und = subprocess.run(["nm", "-D", "--undefined-only", LIB], capture_output=True, text=True).stdout
+        bad = [l.split()[-1] for l in und.splitlines() if "__device_stub__" in l]
+        if bad:
+            os.remove(LIB)
+            raise RuntimeError(f"{len(bad)} kernel launch stubs are undefined in {os.path.basename(LIB)} (host pass dropped them), e.g. {bad[0]}")
     return LIB
 
 

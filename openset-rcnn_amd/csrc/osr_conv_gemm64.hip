@@ -76,7 +76,7 @@ template <> __device__ __forceinline__ void store8_64<bf16_t>(bf16_t* p, const f
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <class TI, class TO, int BM, int BN, int WM, int WN, int EPI>
+template <class TI, class TO, int BM, int BN, int WM, int WN, int EPI, int TWO>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Args a) {  // >= 2 waves per SIMD: VGPR + AGPR <= 256
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int NW = WM * WN, NT = NW * 64;  // waves / threads per workgroup (4 or 8 waves)
@@ -108,11 +108,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
 
-    // ---- per-lane gather descriptors: this lane serves row (piece*8 + lane/8), LDS slot lane%8 ----
+    // ---- per-lane gather descriptors: this lane serves row (piece*8 + lane/8), LDS slot lane%8.
+    //      a_off0 = byte offset of element (n, ih0, iw0, chunk) -- wraps below zero where the window starts in the padding --
+    //      and a_mask has bit t set when tap t = kh*KW + kw of this row lies inside the image. The K loop then needs one add
+    //      and one select per piece: offset = mask bit ? a_off0 + (scalar tap offset) : out of bounds (zero fill).
+    //      Bit 31 is never set: tap 31 is the "issue nothing" tap of the last K step. ----
     const int lrow = lane >> 3, slot = lane & 7;
-    unsigned a_base[A_PIECES];  // byte offset of the pixel row's (n, 0, 0) origin + chunk, or OOB
-    int a_ih0[A_PIECES], a_iw0[A_PIECES];
-    unsigned a_chunk[A_PIECES];  // logical chunk (0..7) this lane fetches
+    unsigned a_off0[A_PIECES], a_mask[A_PIECES];
 #pragma unroll
     for (int j = 0; j < A_PIECES; ++j) {
         const int row = (wid * A_PIECES + j) * 8 + lrow;
@@ -121,10 +123,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
         const long long mm = ok ? m : 0;
         const int nimg = (int)(mm / howo), rem = (int)(mm - (long long)nimg * howo);
         const int oh = rem / p.wo, ow = rem - oh * p.wo;
-        a_ih0[j] = oh * p.stride_h - p.pad_h;
-        a_iw0[j] = ow * p.stride_w - p.pad_w;
-        a_chunk[j] = (unsigned)(slot ^ ((row >> 1) & 7));
-        a_base[j] = ok ? (unsigned)((long long)nimg * p.in_stride_n * 2) : OOB_OFF;
+        const int ih0 = oh * p.stride_h - p.pad_h, iw0 = ow * p.stride_w - p.pad_w;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        // stem view: two 32-wide taps per K slice, chunks 0-3 -> tap kh, 4-7 -> tap kh+1
+        const long long coff = a.stem ? (long long)(chunk >> 2) * p.in_stride_h + (chunk & 3) * 8 : (long long)chunk * 8;
+        a_off0[j] = (unsigned)(((long long)nimg * p.in_stride_n + (long long)ih0 * p.in_stride_h + (long long)iw0 * p.in_stride_w + coff) * 2);
+        unsigned mk = 0x7fffffffu;
+        if (p.pad_mode == 0) {
+            const int wlo = iw0 < 0 ? -iw0 : 0, whi = p.wi - iw0 < p.kw ? p.wi - iw0 : p.kw;
+            const unsigned wm = whi > wlo ? ((1u << whi) - 1u) & ~((1u << wlo) - 1u) : 0u;
+            mk = 0u;
+            for (int t = 0; t < p.kh; ++t)
+                if ((unsigned)(ih0 + t) < (unsigned)p.hi) mk |= wm << (t * p.kw);
+        }
+        a_mask[j] = ok ? mk : 0u;
     }
     unsigned b_off[B_PIECES];
 #pragma unroll
@@ -136,32 +148,37 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
     }
 
     int kh = 0, kw = 0, c0 = 0;  // tap / channel origin of the current K slice (non-stem)
-    int kbyte = 0;               // byte offset of the K slice inside a weight row
-
-#define C64_ISSUE(stage)                                                                                                         \
-    {                                                                                                                            \
-        unsigned char* sa_ = lds + (stage) * STAGE;                                                                              \
-        unsigned char* sb_ = sa_ + BM * 128;                                                                                     \
-        _Pragma("unroll") for (int j = 0; j < A_PIECES; ++j) {                                                                   \
-            int ih, iw, cc;                                                                                                      \
-            if (a.stem) { /* two 32-wide taps per slice: chunks 0-3 -> tap kh, 4-7 -> tap kh+1 */                                \
-                ih = a_ih0[j] + kh + (int)(a_chunk[j] >> 2); iw = a_iw0[j]; cc = (int)(a_chunk[j] & 3) * 8;                       \
-            } else { ih = a_ih0[j] + kh; iw = a_iw0[j] + kw; cc = c0 + (int)a_chunk[j] * 8; }                                     \
-            bool ok = a_base[j] != OOB_OFF;                                                                                      \
-            if (p.pad_mode == 0) ok = ok && (unsigned)ih < (unsigned)p.hi && (unsigned)iw < (unsigned)p.wi;                      \
-            const unsigned off = ok ? a_base[j] + (unsigned)(((long long)ih * p.in_stride_h + (long long)iw * p.in_stride_w + cc) * 2) : OOB_OFF; \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t*)(sa_ + (wid * A_PIECES + j) * 1024), 16, off, 0, 0, 0); \
-        }                                                                                                                        \
-        _Pragma("unroll") for (int j = 0; j < B_PIECES; ++j) {                                                                   \
-            const unsigned off = b_off[j] == OOB_OFF ? OOB_OFF : b_off[j] + (unsigned)kbyte;                                     \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(sb_ + (wid * B_PIECES + j) * 1024), 16, off, 0, 0, 0);  \
-        }                                                                                                                        \
+    int kbyte = 0;               // byte offset of the K slice inside a weight row (scalar offset of the B loads)
+    int tap = 0;                 // kh*KW + kw (0 for the stem view, whose taps are never padded); 31 = issue nothing
+    unsigned tap_off = 0;        // byte offset of (kh, kw, c0) relative to the window origin
+    // one 1-KiB LDS-DMA piece: q < A_PIECES -> activation rows, else weight rows
+#define C64_ISSUE_PIECE(stage, q)                                                                                                 \
+    {                                                                                                                             \
+        unsigned char* sa_ = lds + (stage) * STAGE;                                                                               \
+        if ((q) < A_PIECES) {                                                                                                     \
+            const int j_ = (q) < A_PIECES ? (q) : 0;                                                                              \
+            const unsigned off_ = ((a_mask[j_] >> tap) & 1u) ? a_off0[j_] + tap_off : OOB_OFF;                                     \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t*)(sa_ + (wid * A_PIECES + j_) * 1024), 16, off_, 0, 0, 0); \
+        } else {                                                                                                                  \
+            const int j_ = (q) >= A_PIECES ? (q) - A_PIECES : 0;                                                                  \
+            const unsigned boff_ = b_off[j_]; /* plain variables only: a type-dependent argument makes the host pass drop the kernel */ \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(sa_ + BM * 128 + (wid * B_PIECES + j_) * 1024), 16, boff_, kbyte, 0, 0); \
+        }                                                                                                                         \
     }
-#define C64_ADVANCE()                                                            \
-    {                                                                            \
-        kbyte += 128;                                                            \
-        if (a.stem) kh += 2;                                                     \
-        else { c0 += 64; if (c0 >= p.cin) { c0 = 0; if (++kw >= p.kw) { kw = 0; ++kh; } } } \
+#define C64_ISSUE(stage)                                                                  \
+    {                                                                                     \
+        _Pragma("unroll") for (int q_ = 0; q_ < A_PIECES + B_PIECES; ++q_) C64_ISSUE_PIECE(stage, q_); \
+    }
+#define C64_ADVANCE()                                                                                 \
+    {                                                                                                 \
+        kbyte += 128;                                                                                 \
+        if (a.stem) { kh += 2; tap_off = (unsigned)(kh * p.in_stride_h * 2); }                        \
+        else {                                                                                        \
+            c0 += 64;                                                                                 \
+            if (c0 >= p.cin) { c0 = 0; if (++kw >= p.kw) { kw = 0; ++kh; } }                          \
+            tap = kh * p.kw + kw;                                                                     \
+            tap_off = (unsigned)((kh * p.in_stride_h + kw * p.in_stride_w + c0) * 2);                 \
+        }                                                                                             \
     }
 
     // Accumulators of the wave's TM x TN macro tiles of 32 x 32. ACC(i,j,r) r=0..15 addresses them uniformly:
@@ -244,44 +261,80 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
             tbias[j][1] = a.bias[(wc * TN + j) * 32 + C64_COL(4)];
         }
     }
+#if C64_M16
+    // 16x16x32: a fragment = 16 rows x 32 K; lane l holds row l&15, K chunk (l>>4) of the 32-wide step.
+    // [set][tile][row half]; two 32-wide K steps per 64-wide slice, the second one's fragments are read under the first one's MFMAs.
+#define C64_LOAD_FRAGS(set, k32_)                                                                                                   \
+    {                                                                                                                               \
+        _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                                                          \
+            const int rr_ = hf * 16 + (lane & 15);                                                                                  \
+            const int sl_ = (((k32_) * 4 + (lane >> 4)) ^ ((rr_ >> 1) & 7)) * 16;                                                   \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                          \
+                fa[set][i][hf] = *reinterpret_cast<const frag_t*>(sa + ((wr * TM + i) * 32 + rr_) * 128 + sl_);                     \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                          \
+                fb[set][j][hf] = *reinterpret_cast<const frag_t*>(sb + ((wc * TN + j) * 32 + rr_) * 128 + sl_);                     \
+        }                                                                                                                           \
+    }
+    // MFMAs of one 64-wide K slice; with ISSUE the LDS-DMA pieces of the next slice go out one at a time between groups of
+    // MFMAs (their address arithmetic and issue slots sit in the matrix pipe's shadow instead of in front of it).
+    constexpr int NMFMA = 2 * TM * TN * 4, NPIECE = A_PIECES + B_PIECES, PSTEP = NMFMA / NPIECE;
+    static_assert(PSTEP >= 1, "more staging pieces than MFMAs per K slice");
+#define C64_KSLICE(ISSUE, nstage)                                                                                                   \
+    {                                                                                                                               \
+        frag_t fa[2][TM][2], fb[2][TN][2];                                                                                          \
+        C64_LOAD_FRAGS(0, 0);                                                                                                       \
+        _Pragma("unroll") for (int k32 = 0; k32 < 2; ++k32) {                                                                       \
+            if (k32 < 1) C64_LOAD_FRAGS(1, 1);                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                          \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                      \
+                    _Pragma("unroll") for (int si = 0; si < 2; ++si)                                                                \
+                        _Pragma("unroll") for (int sj = 0; sj < 2; ++sj) {                                                          \
+                            acc[i][j][si][sj] = Frag64<TI>::mfma16(fa[k32][i][si], fb[k32][j][sj], acc[i][j][si][sj]);              \
+                            if (ISSUE) {                                                                                            \
+                                const int done_ = (((k32 * TM + i) * TN + j) * 2 + si) * 2 + sj + 1;                                \
+                                if (done_ % PSTEP == 0 && done_ / PSTEP <= NPIECE) {                                                \
+                                    C64_ISSUE_PIECE(nstage, done_ / PSTEP - 1);                                                     \
+                                    __builtin_amdgcn_sched_barrier(0);                                                              \
+                                }                                                                                                   \
+                            }                                                                                                       \
+                        }                                                                                                           \
+        }                                                                                                                           \
+    }
+    if constexpr (TWO) {
+        for (int ks = 0; ks < nk; ++ks) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // tile ks landed for every wave; every wave is done reading the other stage
+            C64_ADVANCE();
+            if (ks + 1 >= nk) { tap = 31; kbyte = 0; }  // nothing left to stage: tap 31 is never valid (zero fill), weights re-read slice 0
+            const unsigned char* sa = lds + (ks & 1) * STAGE;
+            const unsigned char* sb = sa + BM * 128;
+            const int nstage = (ks + 1) & 1;
+            C64_KSLICE(true, nstage);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last slice's dummy pieces have landed before LDS is reused
+    } else {
+        for (int ks = 0; ks < nk; ++ks) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const unsigned char* sa = lds;
+            const unsigned char* sb = sa + BM * 128;
+            C64_KSLICE(false, 0);
+            if (ks + 1 < nk) {
+                __syncthreads();  // every wave has read the single staging buffer: refill it
+                C64_ADVANCE();
+                C64_ISSUE(0);
+            }
+        }
+    }
+#undef C64_KSLICE
+#undef C64_LOAD_FRAGS
+#else
     for (int ks = 0; ks < nk; ++ks) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // tile ks landed for every wave; every wave is done reading the other stage
-        if (a.two_stage && ks + 1 < nk) { C64_ADVANCE(); C64_ISSUE((ks + 1) & 1); }
-        const unsigned char* sa = lds + (a.two_stage ? (ks & 1) : 0) * STAGE;
+        if (TWO && ks + 1 < nk) { C64_ADVANCE(); C64_ISSUE((ks + 1) & 1); }
+        const unsigned char* sa = lds + (TWO ? (ks & 1) : 0) * STAGE;
         const unsigned char* sb = sa + BM * 128;
-        // fragment reads are software-pipelined one 16-wide K slice ahead of the MFMAs that consume them
-#if C64_M16
-        // 16x16x32: a fragment = 16 rows x 32 K; lane l holds row l&15, K chunk (l>>4) of the 32-wide step.
-        // [set][tile][row half] ; two 32-wide K steps per 64-wide slice, pipelined one step ahead.
-        frag_t fa[2][TM][2], fb[2][TN][2];
-#define C64_LOAD_FRAGS(set, k32_)                                                                                                   \
-        {                                                                                                                           \
-            _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                                                      \
-                const int rr_ = hf * 16 + (lane & 15);                                                                              \
-                const int sl_ = (((k32_) * 4 + (lane >> 4)) ^ ((rr_ >> 1) & 7)) * 16;                                               \
-                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                      \
-                    fa[set][i][hf] = *reinterpret_cast<const frag_t*>(sa + ((wr * TM + i) * 32 + rr_) * 128 + sl_);                 \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                      \
-                    fb[set][j][hf] = *reinterpret_cast<const frag_t*>(sb + ((wc * TN + j) * 32 + rr_) * 128 + sl_);                 \
-            }                                                                                                                       \
-        }
-        C64_LOAD_FRAGS(0, 0);
-#pragma unroll
-        for (int k32 = 0; k32 < 2; ++k32) {
-            if (k32 < 1) C64_LOAD_FRAGS(1, 1);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int si = 0; si < 2; ++si)
-#pragma unroll
-                        for (int sj = 0; sj < 2; ++sj)
-                            acc[i][j][si][sj] = Frag64<TI>::mfma16(fa[k32][i][si], fb[k32][j][sj], acc[i][j][si][sj]);
-        }
-#undef C64_LOAD_FRAGS
-#else
         frag_t fa[2][TM], fb[2][TN];
 #define C64_LOAD_FRAGS(set, kk_)                                                                                                    \
         {                                                                                                                           \
@@ -301,13 +354,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
                 for (int j = 0; j < TN; ++j) acc[i][j] = Frag64<TI>::mfma(fa[kk & 1][i], fb[kk & 1][j], acc[i][j]);
         }
 #undef C64_LOAD_FRAGS
-#endif
-        if (!a.two_stage && ks + 1 < nk) {
+        if (!TWO && ks + 1 < nk) {
             __syncthreads();  // every wave has read the single staging buffer: refill it
             C64_ADVANCE();
             C64_ISSUE(0);
         }
     }
+#endif
     __syncthreads();  // all waves done with the staging buffers before the epilogue reuses them
 
     if constexpr (EPI == 1) {
@@ -452,24 +505,32 @@ static osr_status conv64_launch(Conv64Args& a, hipStream_t st) {
         a.tiles_m = (int)((a.M + 255) / 256);
         a.tiles_n = a.p.cout / 256;
         static thread_local bool attr = false;
-        if (!attr) { allow_big_lds(conv_igemm64_kernel<TI, TO, 256, 256, 2, 4, 0>); attr = true; }
-        hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 256, 256, 2, 4, 0>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(512),
+        if (!attr) { allow_big_lds(conv_igemm64_kernel<TI, TO, 256, 256, 2, 4, 0, 1>); attr = true; }
+        hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 256, 256, 2, 4, 0, 1>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(512),
                            conv64_lds_bytes(256, 256, 1, 8), st, a);
     } else if (a.p.cout <= 64) {
         a.tiles_n = (a.p.cout + 63) / 64;
-        hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 128, 64, 4, 1, 0>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(256),
-                           conv64_lds_bytes(128, 64, a.two_stage), st, a);
+        if (a.two_stage)
+            hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 128, 64, 4, 1, 0, 1>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(256),
+                               conv64_lds_bytes(128, 64, 1), st, a);
+        else
+            hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 128, 64, 4, 1, 0, 0>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(256),
+                               conv64_lds_bytes(128, 64, 0), st, a);
     } else if (a.p.cout == 256 && a.p.res_mode == 0 && nk >= 8 && !a.two_stage && a.M >= wide_n_min_m()) {
         // 128 x 256 tiles for the big 256-channel layers (FPN output convs): the gathered activation rows are fetched once
         a.tiles_n = a.p.cout / 256;
         static thread_local bool attr = false;
-        if (!attr) { allow_big_lds(conv_igemm64_kernel<TI, TO, 128, 256, 2, 2, 0>); attr = true; }
-        hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 128, 256, 2, 2, 0>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(256),
-                           conv64_lds_bytes(128, 256, a.two_stage), st, a);
+        if (!attr) { allow_big_lds(conv_igemm64_kernel<TI, TO, 128, 256, 2, 2, 0, 0>); attr = true; }
+        hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 128, 256, 2, 2, 0, 0>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(256),
+                           conv64_lds_bytes(128, 256, 0), st, a);
     } else {
         a.tiles_n = (a.p.cout + 127) / 128;
-        hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 128, 128, 2, 2, 0>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(256),
-                           conv64_lds_bytes(128, 128, a.two_stage), st, a);
+        if (a.two_stage)
+            hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 128, 128, 2, 2, 0, 1>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(256),
+                               conv64_lds_bytes(128, 128, 1), st, a);
+        else
+            hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 128, 128, 2, 2, 0, 0>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(256),
+                               conv64_lds_bytes(128, 128, 0), st, a);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { osr_set_error("osr_conv2d_fwd(bk64): launch failed: %s", hipGetErrorString(e)); return OSR_ERR_LAUNCH; }
@@ -486,8 +547,8 @@ static osr_status cfrpn_fused_launch(Conv64Args& a, hipStream_t st) {
         a.tail_lds_off = (int)(t_bytes > stages ? t_bytes : stages);
         const size_t lds = (size_t)a.tail_lds_off + 5 * 256 * 4;
         static thread_local bool attr8 = false;
-        if (!attr8) { allow_big_lds(conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1>); attr8 = true; }
-        hipLaunchKernelGGL((conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1>), dim3((unsigned)a.tiles_m), dim3(512), lds, st, a);
+        if (!attr8) { allow_big_lds(conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1, 1>); attr8 = true; }
+        hipLaunchKernelGGL((conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1, 1>), dim3((unsigned)a.tiles_m), dim3(512), lds, st, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { osr_set_error("osr_cfrpn_head_fwd: launch failed: %s", hipGetErrorString(e)); return OSR_ERR_LAUNCH; }
         return OSR_OK;
@@ -498,8 +559,8 @@ static osr_status cfrpn_fused_launch(Conv64Args& a, hipStream_t st) {
     a.tail_lds_off = (int)(t_bytes > stage ? t_bytes : stage);
     const size_t lds = (size_t)a.tail_lds_off + 5 * 256 * 4;
     static thread_local bool attr = false;
-    if (!attr) { allow_big_lds(conv_igemm64_kernel<TI, TI, 128, 256, 2, 2, 1>); attr = true; }
-    hipLaunchKernelGGL((conv_igemm64_kernel<TI, TI, 128, 256, 2, 2, 1>), dim3((unsigned)a.tiles_m), dim3(256), lds, st, a);
+    if (!attr) { allow_big_lds(conv_igemm64_kernel<TI, TI, 128, 256, 2, 2, 1, 0>); attr = true; }
+    hipLaunchKernelGGL((conv_igemm64_kernel<TI, TI, 128, 256, 2, 2, 1, 0>), dim3((unsigned)a.tiles_m), dim3(256), lds, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { osr_set_error("osr_cfrpn_head_fwd: launch failed: %s", hipGetErrorString(e)); return OSR_ERR_LAUNCH; }
     return OSR_OK;
@@ -509,6 +570,7 @@ static osr_status cfrpn_fused_launch(Conv64Args& a, hipStream_t st) {
 int osr_conv64_eligible(const osr_conv_params* p, long long in_bytes, long long w_bytes) {
     const bool stem = p->pad_mode == 1 && p->cin == 32 && p->kw == 1 && (p->kh % 2) == 0;
     if (!stem && p->cin % 64 != 0) return 0;
+    if (!stem && p->kh * p->kw > 31) return 0;  // per-row tap validity mask: 31 bits
     if (in_bytes <= 0 || w_bytes <= 0 || in_bytes >= (1ll << 31) - 4096 || w_bytes >= (1ll << 31) - 4096) return 0;
     return 1;
 }
