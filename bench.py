@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--cpu-iters", type=int, default=1)
+    ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--streams", type=int, default=2, help="micro-batch streams inside one GPU (1 = single stream)")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage breakdown to stderr")
@@ -155,14 +155,16 @@ def main():
     # the one collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x2 per the gfx950
     # guide) on this very command and committed under profiles/; null when that file is absent.
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
+    tfile = os.path.join(ROOT, "profiles", "r01_d_kernel_times_and_traffic.json")
     if os.path.exists(tfile):
         with open(tfile) as fh:
-            traffic = {"GB_per_step": json.load(fh).get("conv_family_GB_per_step"), "source": "profiles/r01_c_pmc_traffic.json"}
+            cf = json.load(fh).get("conv_family", {})
+        traffic = {"GB_per_step": round(cf.get("fetch_GB_per_step_x2corrected", 0.0) + cf.get("write_GB_per_step", 0.0), 2),
+                   "source": "profiles/r01_d_kernel_times_and_traffic.json (scripts/profile_round.sh)"}
     algo_bytes = sum(nb for _, _, _, _, nb in prof)
     roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic,
                     algorithmic_GB_per_step=round(algo_bytes / 1e9, 2),
-                    kernel="conv_igemm_kernel (implicit-GEMM conv + FC)", launches_per_step=len(prof),
+                    kernel="conv_igemm64_kernel family (implicit-GEMM conv + FC)", launches_per_step=len(prof),
                     flops_per_step=mfma_flops, kernel_ms_per_step=round(mfma_ms, 3))
     if args.layers and rank == 0:
         for name, f, e0, e1, nb in prof:

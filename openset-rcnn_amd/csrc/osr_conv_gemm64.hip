@@ -15,6 +15,9 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef C64_PSPREAD
+#define C64_PSPREAD 2
+#endif
 #ifndef C64_M16
 #define C64_M16 1  // 1: v_mfma_f32_16x16x32 (four per 32x32 macro tile and 32-wide K step), 0: v_mfma_f32_32x32x16
 #endif
@@ -277,7 +280,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
     }
     // MFMAs of one 64-wide K slice; with ISSUE the LDS-DMA pieces of the next slice go out one at a time between groups of
     // MFMAs (their address arithmetic and issue slots sit in the matrix pipe's shadow instead of in front of it).
-    constexpr int NMFMA = 2 * TM * TN * 4, NPIECE = A_PIECES + B_PIECES, PSTEP = NMFMA / NPIECE;
+    constexpr int NMFMA = 2 * TM * TN * 4, NPIECE = A_PIECES + B_PIECES;
+    constexpr int PSTEP = (NMFMA / C64_PSPREAD) / NPIECE > 0 ? (NMFMA / C64_PSPREAD) / NPIECE : 1;  // pieces go out in the first 1/C64_PSPREAD of the slice
     static_assert(PSTEP >= 1, "more staging pieces than MFMAs per K slice");
 #define C64_KSLICE(ISSUE, nstage)                                                                                                   \
     {                                                                                                                               \
