@@ -15,6 +15,9 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef C64_COUNTED_FIRST_WAIT
+#define C64_COUNTED_FIRST_WAIT 0  // measured on one box: 13.34 ms (counted) vs 12.50 ms (wait for everything) per step
+#endif
 #ifndef C64_PSPREAD
 #define C64_PSPREAD 2
 #endif
@@ -36,6 +39,35 @@ template <> struct Frag64<bf16_t> {
     static __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 
+// Division of a 32-bit row index by an invariant (Granlund-Montgomery, unsigned): the magic pair is computed on the host,
+// the device pays one mul_hi and four integer ops instead of the ~150-instruction 64-bit division the row -> (n, oh, ow)
+// decomposition otherwise costs (it runs per staged row in the prologue and per stored row segment in the epilogue; stamped
+// diagnostics showed it, not memory, was most of a short-K tile's prologue and epilogue).
+struct FastDiv {
+    unsigned mp, sh1, sh2, d;
+};
+static FastDiv fastdiv_make(unsigned d) {
+    FastDiv f;
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;  // ceil(log2 d)
+    f.mp = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.sh1 = l < 1 ? l : 1;
+    f.sh2 = l > 0 ? l - 1 : 0;
+    f.d = d;
+    return f;
+}
+__device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv& f) {
+    const unsigned t = __umulhi(f.mp, n);
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+// row index -> image, output row, output column
+#define C64_ROW_TO_NHW(m_, nimg_, oh_, ow_)                          \
+    const unsigned mu_##nimg_ = (unsigned)(m_);                      \
+    const int nimg_ = (int)fastdiv(mu_##nimg_, a.div_howo);          \
+    const unsigned rem_##nimg_ = mu_##nimg_ - (unsigned)nimg_ * a.div_howo.d; \
+    const int oh_ = (int)fastdiv(rem_##nimg_, a.div_wo);             \
+    const int ow_ = (int)(rem_##nimg_ - (unsigned)oh_ * a.div_wo.d);
+
 struct Conv64Args {
     osr_conv_params p;
     const void* in;
@@ -55,9 +87,23 @@ struct Conv64Args {
     float* tail_deltas;
     float* tail_ctr;
     int tail_lds_off;      // byte offset of the tail weights in LDS
+    FastDiv div_howo, div_wo;  // row -> (image, oh, ow); M < 2^31
+#ifdef C64_STAMPS
+    unsigned long long* dbg;
+#endif
 };
 
 #define OOB_OFF 0x80000000u
+
+// Diagnostic build only (-DC64_STAMPS, never shipped): wave 0 of every workgroup records s_memrealtime (100 MHz) at
+// kernel entry, after the first staged slice has landed, after the K loop and at exit into a caller-provided buffer.
+#ifdef C64_STAMPS
+static unsigned long long* g_c64_stamps = nullptr;
+extern "C" void osr_debug_set_conv_stamps(unsigned long long* p) { g_c64_stamps = p; }
+#define C64_STAMP(i) if (a.dbg && tid == 0) a.dbg[(long long)blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define C64_STAMP(i)
+#endif
 
 template <class TO> __device__ __forceinline__ void store8_64(TO* p, const float v[8]);
 template <> __device__ __forceinline__ void store8_64<float>(float* p, const float v[8]) {
@@ -95,6 +141,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid / WN, wc = wid % WN;
+    C64_STAMP(0);
 
     // XCD-aware bijective remap of the linear block id (guide T1)
     const int nwg = a.tiles_m * a.tiles_n;
@@ -106,7 +153,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
     const int tile_n = t % a.tiles_n, tile_m = t / a.tiles_n;
     const long long m0 = (long long)tile_m * BM;
     const int n0 = tile_n * BN;
-    const int howo = p.ho * p.wo;
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
@@ -124,8 +170,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
         const long long m = m0 + row;
         const bool ok = m < a.M;
         const long long mm = ok ? m : 0;
-        const int nimg = (int)(mm / howo), rem = (int)(mm - (long long)nimg * howo);
-        const int oh = rem / p.wo, ow = rem - oh * p.wo;
+        C64_ROW_TO_NHW(mm, nimg, oh, ow);
         const int ih0 = oh * p.stride_h - p.pad_h, iw0 = ow * p.stride_w - p.pad_w;
         const int chunk = slot ^ ((row >> 1) & 7);
         // stem view: two 32-wide taps per K slice, chunks 0-3 -> tap kh, 4-7 -> tap kh+1
@@ -214,6 +259,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
     [[maybe_unused]] const int swz = ((lane & 31) >> 1) & 7;
     const int nk = a.K / 64;
     C64_ISSUE(0);
+    __builtin_amdgcn_sched_barrier(0);  // the loads below must stay younger than the slice-0 pieces (C64_FIRST_WAIT)
 
     // ---- epilogue operands that do not depend on the accumulators are fetched now, under the K loop:
     //      this lane's bias values and (128x128 / 128x64 tiles) its residual segments, one 16-byte load per staged row ----
@@ -228,9 +274,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
 #pragma unroll
         for (int jp = 0; jp < TNP; ++jp) {
             const int co = n0 + (wc * TN + jp * 2) * 32 + cseg;
-            const bool co_ok = co < p.cout;
-            const float4 b0 = co_ok ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 b1 = co_ok ? *reinterpret_cast<const float4*>(a.bias + co + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // always issued (clamped address): the first K-loop wait counts these loads (C64_FIRST_WAIT)
+            const int cb = co < p.cout ? co : 0;
+            const float4 b0 = *reinterpret_cast<const float4*>(a.bias + cb);
+            const float4 b1 = *reinterpret_cast<const float4*>(a.bias + cb + 4);
             bias8[jp][0] = b0.x; bias8[jp][1] = b0.y; bias8[jp][2] = b0.z; bias8[jp][3] = b0.w;
             bias8[jp][4] = b1.x; bias8[jp][5] = b1.y; bias8[jp][6] = b1.z; bias8[jp][7] = b1.w;
         }
@@ -244,8 +291,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
                         const long long m = m0 + (wr * TM + i) * 32 + pass * RPP + (lane >> 3);
                         const bool ok = m < a.M && co < p.cout;
                         const long long mm = ok ? m : 0;
-                        const int nimg = (int)(mm / howo), rem = (int)(mm - (long long)nimg * howo);
-                        const int oh = rem / p.wo, ow = rem - oh * p.wo;
+                        C64_ROW_TO_NHW(mm, nimg, oh, ow);
                         const int rh = p.res_mode == 2 ? (oh >> 1) : oh, rw = p.res_mode == 2 ? (ow >> 1) : ow;
                         const long long off = ok ? (long long)nimg * p.res_stride_n + (long long)rh * p.res_stride_h + (long long)rw * p.res_stride_w + co : 0ll;
                         rres[i][pass] = *reinterpret_cast<const frag_t*>(res + off);
@@ -304,10 +350,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
                         }                                                                                                           \
         }                                                                                                                           \
     }
+    // The first wait covers only the slice-0 pieces: the bias / residual loads issued after them (consumed in the epilogue)
+    // stay in flight under the K loop. vmcnt counts in issue order, so "all but the youngest N" is exactly that.
+#define C64_FIRST_WAIT()                                                                         \
+    {                                                                                            \
+        if constexpr (EPI == 0 && C64_COUNTED_FIRST_WAIT) {                                                                \
+            if (PRE_RES && p.res_mode != 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TNP * 2 + (PRE_RES ? TM * NPASS : 0)) : "memory"); \
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TNP * 2) : "memory");                  \
+        } else {                                                                                 \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
+        }                                                                                        \
+    }
     if constexpr (TWO) {
         for (int ks = 0; ks < nk; ++ks) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ks == 0) { C64_FIRST_WAIT(); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             __syncthreads();  // tile ks landed for every wave; every wave is done reading the other stage
+            if (ks == 0) { C64_STAMP(1); }
             C64_ADVANCE();
             if (ks + 1 >= nk) { tap = 31; kbyte = 0; }  // nothing left to stage: tap 31 is never valid (zero fill), weights re-read slice 0
             const unsigned char* sa = lds + (ks & 1) * STAGE;
@@ -318,8 +376,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last slice's dummy pieces have landed before LDS is reused
     } else {
         for (int ks = 0; ks < nk; ++ks) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ks == 0) { C64_FIRST_WAIT(); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             __syncthreads();
+            if (ks == 0) { C64_STAMP(1); }
             const unsigned char* sa = lds;
             const unsigned char* sb = sa + BM * 128;
             C64_KSLICE(false, 0);
@@ -366,6 +425,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
     }
 #endif
     __syncthreads();  // all waves done with the staging buffers before the epilogue reuses them
+    C64_STAMP(2);
 
     if constexpr (EPI == 1) {
         // ---- fused CF-RPN tail (classification_free_rpn.py:159-161): t = relu(conv + bias) is parked in LDS in the
@@ -441,8 +501,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
                     float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += bias8[jp][e];
-                    const int nimg = (int)(m / howo), rem = (int)(m - (long long)nimg * howo);
-                    const int oh = rem / p.wo, ow = rem - oh * p.wo;
+                    C64_ROW_TO_NHW(m, nimg, oh, ow);
                     if (p.res_mode != 0) {
                         if constexpr (PRE_RES) {
 #pragma unroll
@@ -465,6 +524,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
             __builtin_amdgcn_wave_barrier();
         }
     }
+    C64_STAMP(3);
 }
 
 static size_t conv64_lds_bytes(int bm, int bn, int two_stage, int nw = 4) {
@@ -575,6 +635,7 @@ int osr_conv64_eligible(const osr_conv_params* p, long long in_bytes, long long 
     const bool stem = p->pad_mode == 1 && p->cin == 32 && p->kw == 1 && (p->kh % 2) == 0;
     if (!stem && p->cin % 64 != 0) return 0;
     if (!stem && p->kh * p->kw > 31) return 0;  // per-row tap validity mask: 31 bits
+    if ((long long)p->n * p->ho * p->wo >= (1ll << 31) - 1024) return 0;  // 32-bit row indices (fastdiv)
     if (in_bytes <= 0 || w_bytes <= 0 || in_bytes >= (1ll << 31) - 4096 || w_bytes >= (1ll << 31) - 4096) return 0;
     return 1;
 }
@@ -585,10 +646,15 @@ osr_status osr_conv64_run(const osr_conv_params* p, const void* in, const void* 
     a.p = *p; a.in = in; a.w = weight; a.bias = bias; a.res = residual; a.out = out;
     a.M = (long long)p->n * p->ho * p->wo;
     a.K = p->kh * p->kw * p->cin;
+    a.div_howo = fastdiv_make((unsigned)(p->ho * p->wo));
+    a.div_wo = fastdiv_make((unsigned)p->wo);
     a.in_bytes = (unsigned)in_bytes; a.w_bytes = (unsigned)w_bytes;
     a.stem = (p->pad_mode == 1 && p->cin == 32) ? 1 : 0;
     a.tiles_m = a.tiles_n = 0;
     a.tail_w = a.tail_b = nullptr; a.tail_deltas = a.tail_ctr = nullptr;
+#ifdef C64_STAMPS
+    a.dbg = g_c64_stamps;
+#endif
     if (p->in_dtype == OSR_F16) {
         if (p->out_dtype == OSR_F16) return conv64_launch<f16_t, f16_t>(a, st);
         if (p->out_dtype == OSR_F32) return conv64_launch<f16_t, float>(a, st);
@@ -623,9 +689,14 @@ extern "C" osr_status osr_cfrpn_head_fwd(const osr_conv_params* p, const void* i
     a.p = *p; a.in = in; a.w = weight; a.bias = bias; a.res = nullptr; a.out = nullptr;
     a.M = (long long)p->n * p->ho * p->wo;
     a.K = p->kh * p->kw * p->cin;
+    a.div_howo = fastdiv_make((unsigned)(p->ho * p->wo));
+    a.div_wo = fastdiv_make((unsigned)p->wo);
     a.in_bytes = (unsigned)in_bytes; a.w_bytes = (unsigned)w_bytes;
     a.stem = 0;
     a.tail_w = w_tail; a.tail_b = b_tail; a.tail_deltas = deltas; a.tail_ctr = ctr;
+#ifdef C64_STAMPS
+    a.dbg = nullptr;
+#endif
     hipStream_t st = (hipStream_t)stream;
     return p->in_dtype == OSR_F16 ? cfrpn_fused_launch<f16_t>(a, st) : cfrpn_fused_launch<bf16_t>(a, st);
 }
