@@ -18,6 +18,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef C64_COUNTED_FIRST_WAIT
 #define C64_COUNTED_FIRST_WAIT 0  // measured on one box: 13.34 ms (counted) vs 12.50 ms (wait for everything) per step
 #endif
+#ifndef C64_PRE_RES
+#define C64_PRE_RES 1
+#endif
+#ifndef C64_LEAN_SINGLE
+#define C64_LEAN_SINGLE 0  // no measurable difference (12.5 ms either way); kept as an experiment knob
+#endif
+#ifndef C64_SINGLE_MINW
+#define C64_SINGLE_MINW 2
+#endif
 #ifndef C64_PSPREAD
 #define C64_PSPREAD 2
 #endif
@@ -126,7 +135,7 @@ template <> __device__ __forceinline__ void store8_64<bf16_t>(bf16_t* p, const f
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 template <class TI, class TO, int BM, int BN, int WM, int WN, int EPI, int TWO>
-__global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Args a) {  // >= 2 waves per SIMD: VGPR + AGPR <= 256
+__global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI != 0) ? 2 : C64_SINGLE_MINW) void conv_igemm64_kernel(Conv64Args a) {  // waves per SIMD the register budget must allow
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int NW = WM * WN, NT = NW * 64;  // waves / threads per workgroup (4 or 8 waves)
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
     //      this lane's bias values and (128x128 / 128x64 tiles) its residual segments, one 16-byte load per staged row ----
     constexpr int RPP = 8, NPASS = 4;               // 8 lanes x 8 channels cover the 64 staged columns; 8 rows per pass
     constexpr int TNP = TN / 2;                     // pairs of N tiles
-    constexpr bool PRE_RES = (TN == 2) && (TM <= 2) && (EPI == 0);
+    constexpr bool PRE_RES = (TN == 2) && (TM <= 2) && (EPI == 0) && C64_PRE_RES;
     const int cseg = (lane & 7) * 8;
     const TI* __restrict__ res = reinterpret_cast<const TI*>(a.res);
     float bias8[TNP][8];
@@ -329,17 +338,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm64_kernel(Conv64Arg
     constexpr int NMFMA = 2 * TM * TN * 4, NPIECE = A_PIECES + B_PIECES;
     constexpr int PSTEP = (NMFMA / C64_PSPREAD) / NPIECE > 0 ? (NMFMA / C64_PSPREAD) / NPIECE : 1;  // pieces go out in the first 1/C64_PSPREAD of the slice
     static_assert(PSTEP >= 1, "more staging pieces than MFMAs per K slice");
+    // fragment register sets: the double-buffered (MFMA-bound) kernels read the second 32-wide step's fragments under the first
+    // step's MFMAs; the single-buffer (latency-bound) kernels keep one set and trade that overlap for 32 fewer VGPRs
+    constexpr int FSETS = (TWO || !C64_LEAN_SINGLE) ? 2 : 1;
 #define C64_KSLICE(ISSUE, nstage)                                                                                                   \
     {                                                                                                                               \
-        frag_t fa[2][TM][2], fb[2][TN][2];                                                                                          \
+        frag_t fa[FSETS][TM][2], fb[FSETS][TN][2];                                                                                  \
         C64_LOAD_FRAGS(0, 0);                                                                                                       \
         _Pragma("unroll") for (int k32 = 0; k32 < 2; ++k32) {                                                                       \
-            if (k32 < 1) C64_LOAD_FRAGS(1, 1);                                                                                      \
+            if (FSETS == 2) { if (k32 < 1) C64_LOAD_FRAGS(1, 1); }                                                                  \
+            else if (k32 == 1) C64_LOAD_FRAGS(0, 1);                                                                                \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                          \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                      \
                     _Pragma("unroll") for (int si = 0; si < 2; ++si)                                                                \
                         _Pragma("unroll") for (int sj = 0; sj < 2; ++sj) {                                                          \
-                            acc[i][j][si][sj] = Frag64<TI>::mfma16(fa[k32][i][si], fb[k32][j][sj], acc[i][j][si][sj]);              \
+                            acc[i][j][si][sj] = Frag64<TI>::mfma16(fa[k32 % FSETS][i][si], fb[k32 % FSETS][j][sj], acc[i][j][si][sj]); \
                             if (ISSUE) {                                                                                            \
                                 const int done_ = (((k32 * TM + i) * TN + j) * 2 + si) * 2 + sj + 1;                                \
                                 if (done_ % PSTEP == 0 && done_ / PSTEP <= NPIECE) {                                                \
