@@ -61,7 +61,9 @@ osr_status osr_preprocess(const void* src, int32_t src_is_u8, int32_t n, int32_t
  * in/weight: fp16 or bf16; accumulate fp32; out: fp16/bf16/fp32. cin must be a multiple of 32, cout of 8.
  * A fully connected layer is the 1x1 case with hi=rows, wi=1.
  * res_mode: 0 none; 1 residual[n,oh,ow,co] (bottleneck shortcut); 2 residual[n,oh/2,ow/2,co]
- * (FPN top-down nearest-2x upsample-add). Strides are in ELEMENTS; the channel stride is 1.
+ * (FPN top-down nearest-2x upsample-add); 3 residual[n,oh,ow,co] is a forward activation used as a ReLU mask
+ * (out = residual > 0 ? value : 0; the backward-data pass, see osr_conv2d_wgrad below).
+ * Strides are in ELEMENTS; the channel stride is 1.
  * pad_mode: 0 = bounds-checked zero padding; 1 = the input buffer already holds the halo (stem view).
  * --------------------------------------------------------------------------------------------------------- */
 typedef struct osr_conv_params {
@@ -330,6 +332,23 @@ osr_status osr_pln_loss_fwd(const float* emb, int64_t m, int32_t d, const float*
 osr_status osr_softmax_ce_loss_fwd(const float* logits, int64_t m, int32_t num_known, const int64_t* gt_classes,
                                    int32_t num_classes, float loss_weight, float* out1, void* workspace,
                                    int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Backward of osr_conv2d_fwd (training step, backward half). `p` describes the FORWARD layer.
+ *  - data gradient: no entry point of its own -- dx = osr_conv2d_fwd(dy, flipped/transposed weights) with stride 1,
+ *    pad' = k-1-pad (host/weights.py pack_dgrad_weight); a stride-2 1x1 layer writes every second pixel of a zeroed dx
+ *    through the output strides; res_mode 3 applies the ReLU mask of the layer below, res_mode 1 adds a second gradient.
+ *  - weight gradient: dw[cout][kh][kw][cin] (fp32, the packed forward layout) = sum over output pixels of
+ *    dy[n,oh,ow,co] * x[n, oh*sh-ph+kh, ow*sw-pw+kw, ci]; x, dy fp16/bf16 (dy dense (n,ho,wo,cout)), fp32 accumulate,
+ *    split over the pixel axis with partials in the workspace and a fixed-order reduction (bitwise reproducible).
+ *    accumulate != 0 adds to dw.
+ *  - bias gradient: db[co] = sum_m dy[m][co]; workspace 512*cout*4 bytes.
+ * --------------------------------------------------------------------------------------------------------- */
+int64_t osr_conv2d_wgrad_workspace_bytes(const osr_conv_params* p);
+osr_status osr_conv2d_wgrad(const osr_conv_params* p, const void* x, const void* dy, float* dw, int32_t accumulate,
+                            void* workspace, int64_t workspace_bytes, void* stream);
+osr_status osr_bias_grad(const void* dy, int32_t dtype, int64_t m, int32_t cout, float* db, int32_t accumulate,
+                         void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

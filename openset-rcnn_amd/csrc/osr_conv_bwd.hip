@@ -1,0 +1,300 @@
+// Backward kernels of the dense layers (training step, backward half).
+//
+//  * backward-data (dgrad) needs no kernel of its own: it is a forward convolution of dy with the spatially flipped,
+//    transposed weights (host/weights.py pack_dgrad_weight) through osr_conv2d_fwd -- stride-2 1x1 layers write every
+//    second pixel of a zeroed dx through the output strides, and the ReLU mask / gradient sum of the layer below ride in
+//    the epilogue (res_mode 3 / 1).
+//  * backward-weights (wgrad):  dw[co][kh][kw][ci] = sum_m dy[m][co] * x[n, oh*sh-ph+kh, ow*sw-pw+kw, ci],  m = (n,oh,ow).
+//    The contraction index m is the ROW index of both operands in memory, so both MFMA operands are "k-strided". Tiles
+//    are staged row-major ([m][128 channels], 256-B rows, LDS-DMA with a source-side XOR swizzle of the 16-B chunks) and
+//    read with gfx950's transposing ds_read_b64_tr_b16: one read hands lane (g = lane>>4, c = lane&15) channel c of rows
+//    8g+4h .. 8g+4h+3, i.e. exactly half of its 16x16x32 fragment (k = 8g .. 8g+7), in natural k order.
+//    One workgroup = one 128(co) x 128(ci) tile of one tap over one M chunk (split-K); fp32 partials go to a workspace and
+//    a second kernel sums them in a fixed order (bitwise reproducible, no atomics).
+#include "osr_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef f16_t f16x8 __attribute__((ext_vector_type(8)));
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+
+template <class T> struct FragW;
+template <> struct FragW<f16_t> {
+    typedef f16x8 type;
+    static __device__ __forceinline__ f32x4 mfma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct FragW<bf16_t> {
+    typedef bf16x8 type;
+    static __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
+struct WDiv {
+    unsigned mp, sh1, sh2, d;
+};
+static WDiv wdiv_make(unsigned d) {
+    WDiv f;
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    f.mp = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.sh1 = l < 1 ? l : 1;
+    f.sh2 = l > 0 ? l - 1 : 0;
+    f.d = d;
+    return f;
+}
+__device__ __forceinline__ unsigned wdiv(unsigned n, const WDiv& f) {
+    const unsigned t = __umulhi(f.mp, n);
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
+struct WgradArgs {
+    osr_conv_params p;
+    const void* x;
+    const void* dy;
+    float* partial;       // [splits][cout][kh*kw][cin]
+    long long M;          // n*ho*wo
+    long long rows_per_split;  // multiple of 64
+    int splits, tiles_co, tiles_ci, taps;
+    unsigned x_bytes, dy_bytes;
+    WDiv div_howo, div_wo;
+};
+
+#define WG_OOB 0x80000000u
+#define WG_BM 64            // rows (m) per pipeline step
+#define WG_STAGE (2 * WG_BM * 256)  // dy tile + x tile, 256-B rows
+
+template <class TI>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // 2 stages
+    typedef typename FragW<TI>::type frag_t;
+    const osr_conv_params& p = a.p;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;  // wave's 64 output channels / 64 input channels inside the 128 x 128 tile
+
+    // tile decode: consecutive workgroups share the M chunk (same dy / x rows in L2), then the dy columns
+    const int ntiles = a.tiles_co * a.tiles_ci * a.taps;
+    const int split = blockIdx.x / ntiles;
+    int t = blockIdx.x - split * ntiles;
+    const int tile_ci = t % a.tiles_ci; t /= a.tiles_ci;
+    const int tap = t % a.taps;
+    const int tile_co = t / a.taps;
+    const int kh = tap / p.kw, kw = tap - kh * p.kw;
+    const int co0 = tile_co * 128, ci0 = tile_ci * 128;
+    const long long m_begin = (long long)split * a.rows_per_split;
+    const long long m_end = m_begin + a.rows_per_split < a.M ? m_begin + a.rows_per_split : a.M;
+    const int nsteps = (int)((m_end - m_begin + WG_BM - 1) / WG_BM);
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, a.dy_bytes, 0x00020000);
+
+    // staging: a 1-KiB piece = 4 rows x 16 chunks; this lane serves row (piece*4 + lane/16), LDS slot lane%16 and fetches the
+    // logical chunk slot ^ (row & 7). Per step 16 pieces per operand, 4 per wave and operand.
+    const int prow = lane >> 4, slot = lane & 15;
+    const bool plain = p.kh == 1 && p.kw == 1 && p.stride_h == 1 && p.stride_w == 1 && p.pad_h == 0 && p.pad_w == 0 &&
+                       p.in_stride_h == (long long)p.wi * p.in_stride_w && p.in_stride_n == (long long)p.hi * p.in_stride_h;  // x rows are linear in m
+#define WG_ISSUE(stage, step)                                                                                                   \
+    {                                                                                                                           \
+        unsigned char* sy_ = lds + (stage) * WG_STAGE;                                                                          \
+        unsigned char* sx_ = sy_ + WG_BM * 256;                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                         \
+            const int row_ = (wid * 4 + j) * 4 + prow;                                                                          \
+            const long long m_ = m_begin + (long long)(step) * WG_BM + row_;                                                    \
+            const int chunk_ = slot ^ (row_ & 7);                                                                               \
+            const bool mok_ = m_ < m_end;                                                                                       \
+            const long long yo_ = (m_ * p.cout + co0 + chunk_ * 8) * 2;                                                         \
+            const unsigned yoff_ = (mok_ && co0 + chunk_ * 8 < p.cout) ? (unsigned)yo_ : WG_OOB;                                \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_t*)(sy_ + (wid * 4 + j) * 1024), 16, yoff_, 0, 0, 0);       \
+            unsigned xoff_ = WG_OOB;                                                                                            \
+            if (mok_ && ci0 + chunk_ * 8 < p.cin) {                                                                             \
+                if (plain) {                                                                                                    \
+                    xoff_ = (unsigned)((m_ * p.in_stride_w + ci0 + chunk_ * 8) * 2);                                             \
+                } else {                                                                                                        \
+                    const unsigned mu_ = (unsigned)m_;                                                                          \
+                    const unsigned ni_ = wdiv(mu_, a.div_howo), rem_ = mu_ - ni_ * a.div_howo.d;                                 \
+                    const unsigned oh_ = wdiv(rem_, a.div_wo), ow_ = rem_ - oh_ * a.div_wo.d;                                    \
+                    const int ih_ = (int)oh_ * p.stride_h - p.pad_h + kh, iw_ = (int)ow_ * p.stride_w - p.pad_w + kw;            \
+                    if ((unsigned)ih_ < (unsigned)p.hi && (unsigned)iw_ < (unsigned)p.wi)                                        \
+                        xoff_ = (unsigned)(((long long)ni_ * p.in_stride_n + (long long)ih_ * p.in_stride_h + (long long)iw_ * p.in_stride_w + ci0 + chunk_ * 8) * 2); \
+                }                                                                                                               \
+            }                                                                                                                   \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(sx_ + (wid * 4 + j) * 1024), 16, xoff_, 0, 0, 0);       \
+        }                                                                                                                       \
+    }
+
+    f32x4 acc[4][4];  // [co sub-tile][ci sub-tile]: rows = output channels, columns = input channels
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transposing fragment read: lane (g, q, pp) of a 16-lane group supplies the address of row 8g+4h+q, 4 elements at
+    // column 16*sub + 4*pp of the wave's 64 channels; it receives column (lane & 15) of the four rows.
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    if (nsteps > 0) WG_ISSUE(0, 0);
+    for (int s = 0; s < nsteps; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < nsteps) WG_ISSUE((s + 1) & 1, s + 1);
+        const unsigned char* sy = lds + (s & 1) * WG_STAGE;
+        const unsigned char* sx = sy + WG_BM * 256;
+#pragma unroll
+        for (int kk = 0; kk < WG_BM / 32; ++kk) {
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            s16x4 va[2][4], vb[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = kk * 32 + g * 8 + h * 4 + q;
+                const int sw = row & 7;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int chunk_a = (wr * 8 + i * 2 + (pp >> 1)) ^ sw;
+                    const int chunk_b = (wc * 8 + i * 2 + (pp >> 1)) ^ sw;
+                    va[h][i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(sy + row * 256 + chunk_a * 16 + (pp & 1) * 8));
+                    vb[h][i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(sx + row * 256 + chunk_b * 16 + (pp & 1) * 8));
+                }
+            }
+            frag_t fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const s16x8 ta = {va[0][i][0], va[0][i][1], va[0][i][2], va[0][i][3], va[1][i][0], va[1][i][1], va[1][i][2], va[1][i][3]};
+                const s16x8 tb = {vb[0][i][0], vb[0][i][1], vb[0][i][2], vb[0][i][3], vb[1][i][0], vb[1][i][1], vb[1][i][2], vb[1][i][3]};
+                fa[i] = __builtin_bit_cast(frag_t, ta);
+                fb[i] = __builtin_bit_cast(frag_t, tb);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = FragW<TI>::mfma(fa[i], fb[j], acc[i][j]);
+        }
+    }
+    // partial[split][co][tap][ci]: C/D layout col = lane&15 (ci), row = (lane>>4)*4 + r (co)
+    float* out = a.partial + (long long)split * p.cout * a.taps * p.cin;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ci = ci0 + wc * 64 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
+                if (co < p.cout && ci < p.cin) out[((long long)co * a.taps + tap) * p.cin + ci] = acc[i][j][r];
+            }
+        }
+}
+
+// dw[i] = (accumulate ? dw[i] : 0) + sum_s partial[s][i]  (fixed order)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, long long n, int splits, int accumulate,
+                                                           float* __restrict__ dw) {
+    const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    float4 s = accumulate ? *reinterpret_cast<const float4*>(dw + i4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < splits; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(partial + (long long)k * n + i4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dw + i4) = s;
+}
+
+static int wgrad_splits(const osr_conv_params* p) {
+    const long long M = (long long)p->n * p->ho * p->wo;
+    const long long ntiles = (long long)((p->cout + 127) / 128) * ((p->cin + 127) / 128) * p->kh * p->kw;
+    long long splits = (1024 + ntiles - 1) / ntiles;  // enough workgroups for 256 CUs x 2 x 2
+    const long long max_splits = (M + 255) / 256;     // at least 256 rows per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    return (int)splits;
+}
+
+extern "C" int64_t osr_conv2d_wgrad_workspace_bytes(const osr_conv_params* p) {
+    if (!p || p->cout < 1 || p->cin < 1 || p->kh < 1 || p->kw < 1 || p->n < 1 || p->ho < 1 || p->wo < 1) {
+        osr_set_error("osr_conv2d_wgrad_workspace_bytes: bad parameters");
+        return OSR_ERR_INVALID_ARG;
+    }
+    return (int64_t)wgrad_splits(p) * p->cout * p->kh * p->kw * p->cin * 4;
+}
+
+extern "C" osr_status osr_conv2d_wgrad(const osr_conv_params* p, const void* x, const void* dy, float* dw, int32_t accumulate, void* workspace,
+                                       int64_t workspace_bytes, void* stream) {
+    OSR_REQUIRE(p && x && dy && dw && workspace, OSR_ERR_INVALID_ARG, "osr_conv2d_wgrad: null pointer");
+    OSR_REQUIRE(p->n >= 1 && p->hi >= 1 && p->wi >= 1 && p->ho >= 1 && p->wo >= 1, OSR_ERR_INVALID_ARG, "osr_conv2d_wgrad: bad spatial sizes");
+    OSR_REQUIRE(p->cin >= 8 && p->cin % 8 == 0 && p->cout >= 8 && p->cout % 8 == 0, OSR_ERR_UNSUPPORTED, "osr_conv2d_wgrad: cin and cout must be multiples of 8");
+    OSR_REQUIRE(p->kh >= 1 && p->kw >= 1 && p->kh <= 16 && p->kw <= 16 && p->stride_h >= 1 && p->stride_w >= 1 && p->pad_h >= 0 && p->pad_w >= 0,
+                OSR_ERR_INVALID_ARG, "osr_conv2d_wgrad: bad kernel geometry");
+    OSR_REQUIRE(p->in_dtype == OSR_F16 || p->in_dtype == OSR_BF16, OSR_ERR_UNSUPPORTED, "osr_conv2d_wgrad: x / dy must be f16 or bf16");
+    OSR_REQUIRE(p->pad_mode == 0, OSR_ERR_UNSUPPORTED, "osr_conv2d_wgrad: pad_mode 1 (stem view) has no weight gradient: the stem is frozen");
+    OSR_REQUIRE((p->hi + 2 * p->pad_h - p->kh) / p->stride_h + 1 == p->ho && (p->wi + 2 * p->pad_w - p->kw) / p->stride_w + 1 == p->wo, OSR_ERR_INVALID_ARG,
+                "osr_conv2d_wgrad: ho/wo inconsistent with hi/wi/kernel/stride/pad");
+    OSR_REQUIRE(p->out_stride_w == p->cout && p->out_stride_h == (int64_t)p->wo * p->cout && p->out_stride_n == (int64_t)p->ho * p->wo * p->cout,
+                OSR_ERR_UNSUPPORTED, "osr_conv2d_wgrad: dy must be dense (n, ho, wo, cout)");
+    OSR_REQUIRE(p->in_stride_w % 8 == 0 && p->in_stride_h % 8 == 0 && p->in_stride_n % 8 == 0 && p->in_stride_n > 0, OSR_ERR_INVALID_ARG,
+                "osr_conv2d_wgrad: x strides must be multiples of 8 elements");
+    OSR_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)workspace) & 15) == 0, OSR_ERR_INVALID_ARG, "osr_conv2d_wgrad: pointers must be 16-byte aligned");
+    WgradArgs a;
+    a.p = *p; a.x = x; a.dy = dy; a.partial = (float*)workspace;
+    a.M = (long long)p->n * p->ho * p->wo;
+    const long long x_bytes = (long long)p->n * p->in_stride_n * 2, dy_bytes = a.M * p->cout * 2;
+    OSR_REQUIRE(a.M < (1ll << 31) - 1024 && x_bytes < (1ll << 31) - 4096 && dy_bytes < (1ll << 31) - 4096, OSR_ERR_UNSUPPORTED,
+                "osr_conv2d_wgrad: tensor too large for 32-bit buffer offsets");
+    a.x_bytes = (unsigned)x_bytes; a.dy_bytes = (unsigned)dy_bytes;
+    a.splits = wgrad_splits(p);
+    a.rows_per_split = ((a.M + a.splits - 1) / a.splits + WG_BM - 1) / WG_BM * WG_BM;
+    a.splits = (int)((a.M + a.rows_per_split - 1) / a.rows_per_split);
+    a.tiles_co = (p->cout + 127) / 128; a.tiles_ci = (p->cin + 127) / 128; a.taps = p->kh * p->kw;
+    a.div_howo = wdiv_make((unsigned)(p->ho * p->wo));
+    a.div_wo = wdiv_make((unsigned)p->wo);
+    const long long wn = (long long)p->cout * a.taps * p->cin;
+    OSR_REQUIRE(workspace_bytes >= (int64_t)a.splits * wn * 4, OSR_ERR_WORKSPACE, "osr_conv2d_wgrad: workspace %lld < %lld bytes", (long long)workspace_bytes,
+                (long long)a.splits * wn * 4);
+    const long long grid = (long long)a.tiles_co * a.tiles_ci * a.taps * a.splits;
+    OSR_REQUIRE(grid < (1ll << 31), OSR_ERR_UNSUPPORTED, "osr_conv2d_wgrad: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (p->in_dtype == OSR_F16) hipLaunchKernelGGL(conv_wgrad_kernel<f16_t>, dim3((unsigned)grid), dim3(256), 2 * WG_STAGE, st, a);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 2 * WG_STAGE, st, a);
+    OSR_CHECK_LAUNCH("osr_conv2d_wgrad");
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((wn / 4 + 255) / 256)), dim3(256), 0, st, (const float*)workspace, wn, a.splits, accumulate, dw);
+    OSR_CHECK_LAUNCH("osr_conv2d_wgrad(reduce)");
+    return OSR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// bias gradient: db[co] = sum_m dy[m][co]   (two stages, fixed order)
+// ------------------------------------------------------------------------------------------------------
+template <class TI>
+__global__ __launch_bounds__(256) void bias_grad_kernel(const TI* __restrict__ dy, long long M, int cout, long long rows_per_block, float* __restrict__ partial) {
+    const int co = blockIdx.y * 256 + threadIdx.x;
+    if (co >= cout) return;
+    const long long m0 = (long long)blockIdx.x * rows_per_block, m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+    float s = 0.f;
+    for (long long m = m0; m < m1; ++m) s += osr_to_float(dy[m * cout + co]);
+    partial[(long long)blockIdx.x * cout + co] = s;
+}
+
+__global__ __launch_bounds__(256) void bias_grad_reduce(const float* __restrict__ partial, int nblocks, int cout, int accumulate, float* __restrict__ db) {
+    const int co = blockIdx.x * 256 + threadIdx.x;
+    if (co >= cout) return;
+    float s = accumulate ? db[co] : 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partial[(long long)b * cout + co];
+    db[co] = s;
+}
+
+#define BG_BLOCKS 512
+extern "C" osr_status osr_bias_grad(const void* dy, int32_t dtype, int64_t m, int32_t cout, float* db, int32_t accumulate, void* workspace,
+                                    int64_t workspace_bytes, void* stream) {
+    OSR_REQUIRE(dy && db && workspace, OSR_ERR_INVALID_ARG, "osr_bias_grad: null pointer");
+    OSR_REQUIRE(m >= 1 && cout >= 1 && osr_dtype_ok(dtype), OSR_ERR_INVALID_ARG, "osr_bias_grad: bad sizes / dtype");
+    long long rpb = (m + BG_BLOCKS - 1) / BG_BLOCKS;
+    if (rpb < 64) rpb = 64;
+    const int nb = (int)((m + rpb - 1) / rpb);
+    OSR_REQUIRE(workspace_bytes >= (int64_t)nb * cout * 4, OSR_ERR_WORKSPACE, "osr_bias_grad: workspace needs %lld bytes", (long long)BG_BLOCKS * cout * 4);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(nb, (cout + 255) / 256);
+    if (dtype == OSR_F16) hipLaunchKernelGGL(bias_grad_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t*)dy, (long long)m, cout, rpb, (float*)workspace);
+    else if (dtype == OSR_BF16) hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy, (long long)m, cout, rpb, (float*)workspace);
+    else hipLaunchKernelGGL(bias_grad_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, (long long)m, cout, rpb, (float*)workspace);
+    OSR_CHECK_LAUNCH("osr_bias_grad");
+    hipLaunchKernelGGL(bias_grad_reduce, dim3((cout + 255) / 256), dim3(256), 0, st, (const float*)workspace, nb, cout, accumulate, db);
+    OSR_CHECK_LAUNCH("osr_bias_grad(reduce)");
+    return OSR_OK;
+}

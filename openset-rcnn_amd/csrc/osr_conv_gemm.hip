@@ -225,8 +225,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                     const int rh = p.res_mode == 2 ? (oh >> 1) : oh, rw = p.res_mode == 2 ? (ow >> 1) : ow;
                     const frag_t rv = *reinterpret_cast<const frag_t*>(res + (long long)nimg * p.res_stride_n + (long long)rh * p.res_stride_h +
                                                                         (long long)rw * p.res_stride_w + co);
+                    if (p.res_mode == 3) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                        for (int e = 0; e < 8; ++e) v[e] = (float)rv[e] > 0.f ? v[e] : 0.f;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                    }
                 }
                 if (p.relu) {
 #pragma unroll
@@ -274,7 +279,7 @@ extern "C" osr_status osr_conv2d_fwd(const osr_conv_params* p, const void* in, c
                 OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: bad kernel geometry");
     OSR_REQUIRE(p->in_dtype == OSR_F16 || p->in_dtype == OSR_BF16, OSR_ERR_UNSUPPORTED, "osr_conv2d_fwd: in_dtype must be f16/bf16");
     OSR_REQUIRE(osr_dtype_ok(p->out_dtype), OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: bad out_dtype");
-    OSR_REQUIRE(p->res_mode >= 0 && p->res_mode <= 2 && (p->res_mode == 0 || residual), OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: bad res_mode / residual");
+    OSR_REQUIRE(p->res_mode >= 0 && p->res_mode <= 3 && (p->res_mode == 0 || residual), OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: bad res_mode / residual");
     OSR_REQUIRE(p->pad_mode == 0 || p->pad_mode == 1, OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: bad pad_mode");
     if (p->pad_mode == 0) {
         // the computed output size must agree with the convolution arithmetic, so that every tap index the kernel

@@ -516,13 +516,18 @@ __global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI !=
                     for (int e = 0; e < 8; ++e) v[e] += bias8[jp][e];
                     C64_ROW_TO_NHW(m, nimg, oh, ow);
                     if (p.res_mode != 0) {
+                        frag_t rv;
                         if constexpr (PRE_RES) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] += (float)rres[i][pass][e];
+                            rv = rres[i][pass];
                         } else {
                             const int rh = p.res_mode == 2 ? (oh >> 1) : oh, rw = p.res_mode == 2 ? (ow >> 1) : ow;
-                            const frag_t rv = *reinterpret_cast<const frag_t*>(res + (long long)nimg * p.res_stride_n + (long long)rh * p.res_stride_h +
-                                                                                (long long)rw * p.res_stride_w + co);
+                            rv = *reinterpret_cast<const frag_t*>(res + (long long)nimg * p.res_stride_n + (long long)rh * p.res_stride_h +
+                                                                  (long long)rw * p.res_stride_w + co);
+                        }
+                        if (p.res_mode == 3) {  // backward of a ReLU: keep the gradient where the forward activation was positive
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = (float)rv[e] > 0.f ? v[e] : 0.f;
+                        } else {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
                         }

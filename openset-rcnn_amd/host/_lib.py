@@ -86,6 +86,10 @@ PROTOTYPES = {
     "osr_roi_box_losses_fwd": (I32, [P, I32, P, I32, I32, P, P, P, P, I64, I32, P, F32, F32, P, P, I64, P]),
     "osr_pln_loss_fwd": (I32, [P, I64, I32, P, I32, P, P, F32, F32, F32, F32, P, P, I64, P]),
     "osr_softmax_ce_loss_fwd": (I32, [P, I64, I32, P, I32, F32, P, P, I64, P]),
+    # training step, backward half
+    "osr_conv2d_wgrad_workspace_bytes": (I64, [P]),
+    "osr_conv2d_wgrad": (I32, [P, P, P, P, I32, P, I64, P]),
+    "osr_bias_grad": (I32, [P, I32, I64, I32, P, I32, P, I64, P]),
 }
 
 _lib = None

@@ -84,7 +84,7 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, stride: in
     if res_mode:
         _need(residual, x.dtype, "residual")
         rn, rh, rw, rc = residual.shape
-        exp = (n, ho, wo, cout) if res_mode == 1 else (n, (ho + 1) // 2, (wo + 1) // 2, cout)
+        exp = (n, ho, wo, cout) if res_mode in (1, 3) else (n, (ho + 1) // 2, (wo + 1) // 2, cout)
         if (rn, rh, rw, rc) != exp:
             raise OsrError(f"residual shape {tuple(residual.shape)} != expected {exp} for res_mode {res_mode}")
         p.res_stride_n, p.res_stride_h, p.res_stride_w = rh * rw * rc, rw * rc, rc
@@ -494,3 +494,99 @@ def softmax_ce_loss_fwd(logits, gt_classes, num_classes: int, loss_weight: float
     check(lib.osr_softmax_ce_loss_fwd(_p(logits), m, nk1 - 1, _p(gt_classes), num_classes, loss_weight, _p(out), _p(ws), ws.numel(), _stream()),
           "osr_softmax_ce_loss_fwd")
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+# training step, backward half: dense layers
+# ----------------------------------------------------------------------------------------------------------
+def _conv_params(n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, dt_in, dt_out) -> ConvParams:
+    p = ConvParams()
+    p.n, p.hi, p.wi, p.cin, p.ho, p.wo, p.cout = n, hi, wi, cin, ho, wo, cout
+    p.kh, p.kw, p.stride_h, p.stride_w, p.pad_h, p.pad_w = kh, kw, stride, stride, pad, pad
+    p.in_stride_n, p.in_stride_h, p.in_stride_w = hi * wi * cin, wi * cin, cin
+    p.out_stride_n, p.out_stride_h, p.out_stride_w = ho * wo * cout, wo * cout, cout
+    p.relu, p.res_mode, p.pad_mode = 0, 0, 0
+    p.in_dtype, p.out_dtype = _DT[dt_in], _DT[dt_out]
+    return p
+
+
+def conv2d_dgrad(dy: torch.Tensor, w_dgrad: torch.Tensor, x_hw: Tuple[int, int], stride: int = 1, pad: int = 0,
+                 mask: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """Gradient w.r.t. the input of a convolution: dy (n,ho,wo,cout), w_dgrad = pack_dgrad_weight(w) (cin,kh,kw,cout).
+    mask: forward activation at dx's positions (n,hi,wi,cin) -> dx is zeroed where mask <= 0 (the ReLU below);
+    add: a second gradient of dx's shape summed in (residual / shortcut branch). At most one of the two (a conv epilogue has
+    one auxiliary operand); stride 2 is supported for 1x1 layers (every second pixel of a zeroed dx)."""
+    lib = _lib.load()
+    _need(dy, name="dy"); _need(w_dgrad, dy.dtype, "w_dgrad")
+    n, ho, wo, cout = dy.shape
+    cin, kh, kw, cout2 = w_dgrad.shape
+    hi, wi = x_hw
+    if cout2 != cout:
+        raise OsrError(f"w_dgrad cout {cout2} != dy channels {cout}")
+    if mask is not None and add is not None:
+        raise OsrError("conv2d_dgrad takes a mask or an addend, not both")
+    aux, mode = (mask, 3) if mask is not None else ((add, 1) if add is not None else (None, 0))
+    out_dtype = out_dtype or dy.dtype
+    zero_bias = torch.zeros((cin,), dtype=torch.float32, device=dy.device)
+    if stride == 1:
+        if (hi + 2 * pad - kh) + 1 != ho or (wi + 2 * pad - kw) + 1 != wo:
+            raise OsrError("x_hw inconsistent with dy and the kernel geometry")
+        return conv2d(dy, w_dgrad, zero_bias, 1, kh - 1 - pad, False, aux, mode, out_dtype)
+    if not (kh == 1 and kw == 1 and pad == 0):
+        raise OsrError("strided backward-data is implemented for 1x1 layers only (the reference's R-50 strides in the 1x1)")
+    if (hi - 1) // stride + 1 != ho or (wi - 1) // stride + 1 != wo:
+        raise OsrError("x_hw inconsistent with dy and the stride")
+    dx = torch.zeros((n, hi, wi, cin), dtype=out_dtype, device=dy.device)
+    p = _conv_params(n, ho, wo, cout, ho, wo, cin, 1, 1, 1, 0, dy.dtype, out_dtype)
+    p.out_stride_n, p.out_stride_h, p.out_stride_w = hi * wi * cin, stride * wi * cin, stride * cin
+    p.res_mode = mode
+    if aux is not None:
+        _need(aux, dy.dtype, "mask/add")
+        if tuple(aux.shape) != (n, hi, wi, cin):
+            raise OsrError(f"mask/add shape {tuple(aux.shape)} != {(n, hi, wi, cin)}")
+        p.res_stride_n, p.res_stride_h, p.res_stride_w = hi * wi * cin, stride * wi * cin, stride * cin
+    check(lib.osr_conv2d_fwd(C.byref(p), _p(dy), _p(w_dgrad), _p(zero_bias), _p(aux), _p(dx), _stream()), "osr_conv2d_fwd(dgrad)")
+    return dx
+
+
+def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: int = 1, pad: int = 0, dw: Optional[torch.Tensor] = None,
+                 accumulate: bool = False) -> torch.Tensor:
+    """Weight gradient in the packed forward layout (cout,kh,kw,cin), fp32. x (n,hi,wi,cin), dy (n,ho,wo,cout) f16/bf16."""
+    lib = _lib.load()
+    _need(x, name="x"); _need(dy, x.dtype, "dy")
+    n, hi, wi, cin = x.shape
+    n2, ho, wo, cout = dy.shape
+    if n2 != n or (hi + 2 * pad - kh) // stride + 1 != ho or (wi + 2 * pad - kw) // stride + 1 != wo:
+        raise OsrError("dy shape inconsistent with x and the kernel geometry")
+    p = _conv_params(n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, x.dtype, x.dtype)
+    if dw is None:
+        dw = torch.empty((cout, kh, kw, cin), dtype=torch.float32, device=x.device)
+        accumulate = False
+    else:
+        _need(dw, torch.float32, "dw")
+    wsb = lib.osr_conv2d_wgrad_workspace_bytes(C.byref(p))
+    if wsb < 0:
+        check(int(wsb), "osr_conv2d_wgrad_workspace_bytes")
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+    check(lib.osr_conv2d_wgrad(C.byref(p), _p(x), _p(dy), _p(dw), int(accumulate), _p(ws), wsb, _stream()), "osr_conv2d_wgrad")
+    return dw
+
+
+def linear_wgrad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """dW (n_out, k) fp32 of a fully connected layer: x (m,k), dy (m,n_out)."""
+    m, k = x.shape
+    return conv2d_wgrad(x.view(1, m, 1, k), dy.view(1, m, 1, dy.shape[1]), 1, 1).view(dy.shape[1], k)
+
+
+def bias_grad(dy: torch.Tensor, db: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """db[c] = sum over all leading dimensions of dy[..., c] (fp32)."""
+    lib = _lib.load()
+    _need(dy, name="dy")
+    cout = dy.shape[-1]
+    m = dy.numel() // cout
+    if db is None:
+        db = torch.empty((cout,), dtype=torch.float32, device=dy.device)
+        accumulate = False
+    ws = torch.empty((512 * cout * 4,), dtype=torch.uint8, device=dy.device)
+    check(lib.osr_bias_grad(_p(dy), _DT[dy.dtype], m, cout, _p(db), int(accumulate), _p(ws), ws.numel(), _stream()), "osr_bias_grad")
+    return db

@@ -101,3 +101,9 @@ def pack_fc1_weight(w: torch.Tensor, channels: int, pooled: int, dtype: torch.dt
     """fc1 (out, c*p*p) with the reference's (c,ph,pw) flatten order -> (out, p*p*c) matching RoIAlign's (ph,pw,c) output."""
     o = w.shape[0]
     return w.view(o, channels, pooled, pooled).permute(0, 2, 3, 1).reshape(o, pooled * pooled * channels).contiguous().to(dtype)
+
+
+def pack_dgrad_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """(cout,cin,kh,kw) -> (cin,kh,kw,cout), spatially flipped: the backward-data pass of a stride-1 convolution is the
+    forward convolution of dy with these weights and padding k-1-pad; for a 1x1 layer it is the transposed matrix."""
+    return w.flip(2, 3).permute(1, 2, 3, 0).contiguous().to(dtype)

@@ -1,0 +1,75 @@
+"""GPU parity of the dense-layer backward kernels against torch autograd (fp32 on the same fp16-rounded operands).
+Tolerance: fp32 accumulation on both sides, different summation order -> 2e-3 of the tensor's max (weight gradients sum up to
+~10^4 products of fp16-rounded factors); data gradients are stored in fp16 -> one rounding."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops(osr):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: the HIP path has no CPU fallback")
+    osr._lib.load()
+    return osr.ops
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-6))
+
+
+CASES = [  # n, cin, cout, h, w, k, stride, pad
+    (2, 256, 256, 13, 21, 3, 1, 1),
+    (2, 512, 128, 25, 42, 1, 1, 0),
+    (2, 256, 512, 26, 42, 1, 2, 0),
+    (1, 64, 192, 17, 9, 3, 1, 1),      # partial channel tiles
+    (1, 1024, 256, 300, 1, 1, 1, 0),   # fully connected: rows = h
+    (3, 128, 128, 7, 5, 3, 1, 1),      # M = 105: one short step
+]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,k,stride,pad", CASES)
+def test_wgrad_and_dgrad_vs_autograd(ops, osr, n, cin, cout, h, w, k, stride, pad):
+    from openset_rcnn_amd.host.weights import pack_dgrad_weight
+    gg = g(cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=gg).half().float().requires_grad_(True)
+    wt = (torch.randn(cout, cin, k, k, generator=gg) * 0.05).half().float().requires_grad_(True)
+    y = F.conv2d(x, wt, None, stride, pad)
+    dy = torch.randn(y.shape, generator=gg).half().float()
+    y.backward(dy)
+    xd, dyd = nhwc(x.detach()).half().to(DEV), nhwc(dy).half().to(DEV)
+    dw = ops.conv2d_wgrad(xd, dyd, k, k, stride, pad)
+    assert tuple(dw.shape) == (cout, k, k, cin)
+    assert rel(dw.permute(0, 3, 1, 2), wt.grad) < 2e-3, f"wgrad rel err {rel(dw.permute(0, 3, 1, 2), wt.grad)}"
+    dw2 = ops.conv2d_wgrad(xd, dyd, k, k, stride, pad, dw=dw.clone(), accumulate=True)
+    assert rel(dw2, 2 * dw) < 1e-6
+    assert torch.equal(ops.conv2d_wgrad(xd, dyd, k, k, stride, pad), dw), "fixed-order split-K reduction must be bitwise reproducible"
+    db = ops.bias_grad(dyd)
+    assert rel(db, dy.sum(dim=(0, 2, 3))) < 1e-4
+    # data gradient: plain, with the ReLU mask of the layer below, and with a second gradient added
+    wd = pack_dgrad_weight(wt.detach(), torch.float16).to(DEV)
+    dx = ops.conv2d_dgrad(dyd, wd, (h, w), stride, pad, out_dtype=torch.float32)
+    assert rel(dx.permute(0, 3, 1, 2), x.grad) < 2e-3
+    act = torch.randn(n, h, w, cin, generator=gg).half()
+    dxm = ops.conv2d_dgrad(dyd, wd, (h, w), stride, pad, mask=act.to(DEV), out_dtype=torch.float32)
+    assert rel(dxm, nhwc(x.grad) * (act.float() > 0)) < 2e-3
+    other = torch.randn(n, h, w, cin, generator=gg).half()
+    dxa = ops.conv2d_dgrad(dyd, wd, (h, w), stride, pad, add=other.to(DEV), out_dtype=torch.float32)
+    ref = nhwc(x.grad) + other.float()
+    if stride == 2:  # the addend is only read at the pixels the strided layer writes; the rest of dx stays zero
+        keep = torch.zeros_like(ref)
+        keep[:, ::2, ::2] = 1
+        ref = ref * keep
+    assert rel(dxa, ref) < 2e-3
