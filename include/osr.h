@@ -350,6 +350,67 @@ osr_status osr_conv2d_wgrad(const osr_conv_params* p, const void* x, const void*
 osr_status osr_bias_grad(const void* dy, int32_t dtype, int64_t m, int32_t cout, float* db, int32_t accumulate,
                          void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Training step, backward half: losses and per-row stages. Every gradient is d(sum of weighted losses)/d(tensor)
+ * times `loss_scale` (static loss scaling for fp16 gradient tensors; osr_sgd_step divides it out via grad_scale).
+ * --------------------------------------------------------------------------------------------------------- */
+
+/* Gradient of osr_rpn_losses_fwd w.r.t. the head's five pre-activation outputs per anchor: d_out5 (rows, 5) level-major
+ * like the predictions = {d ltrb deltas (through decode + IoU), d centerness logit (through the sigmoid)}. */
+osr_status osr_rpn_losses_bwd(const osr_rpn_levels* levels, const float* cell_anchors, int32_t n,
+                              const float* pred_deltas, const float* pred_ctr, const int8_t* labels_reg,
+                              const int8_t* labels_obj, const float* matched_boxes, const float* ctr_target,
+                              float loc_weight, float ctr_weight, int32_t batch_size_per_image, float loss_scale,
+                              float* d_out5, void* stream);
+
+/* ClsFreeRPNHead tail backward (classification_free_rpn.py:159-161): t (rows,256) is the hidden state after the 3x3 conv's
+ * ReLU; outputs dt (rows,256, same dtype, already masked by t > 0), dw_tail (5,256), db_tail (5). */
+int64_t osr_cfrpn_tail_bwd_workspace_bytes(void);
+osr_status osr_cfrpn_tail_bwd(const void* t, int32_t dtype, int64_t rows, const float* w_tail, const float* d_out5, void* dt,
+                              float* dw_tail, float* db_tail, int32_t accumulate, void* workspace,
+                              int64_t workspace_bytes, void* stream);
+
+/* Gradient of osr_roi_box_losses_fwd w.r.t. the (m,5) predictor output {4 deltas, IoU logit}. workspace 16 bytes. */
+osr_status osr_roi_box_losses_bwd(const float* pred5, const float* proposal_boxes, const float* gt_boxes,
+                                  const int64_t* gt_classes, const float* gt_iou, int64_t m, int32_t num_classes,
+                                  const float reg_weights[4], float box_weight, float iou_weight, float loss_scale,
+                                  float* d_pred5, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Gradient of osr_softmax_ce_loss_fwd w.r.t. the logits (m, num_known+1). workspace 16 bytes. */
+osr_status osr_softmax_ce_loss_bwd(const float* logits, int64_t m, int32_t num_known, const int64_t* gt_classes,
+                                   int32_t num_classes, float loss_weight, float loss_scale, float* d_logits,
+                                   void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Gradient of osr_pln_loss_fwd w.r.t. the embeddings (m,d) and the RAW prototypes (num_known,d) (the forward normalises
+ * them, prototype_learning_network.py:136). */
+int64_t osr_pln_loss_bwd_workspace_bytes(int64_t m);
+osr_status osr_pln_loss_bwd(const float* emb, int64_t m, int32_t d, const float* protos_raw, int32_t num_known,
+                            const int64_t* gt_classes, const float* ious, float iou_thr, float alpha, float beta,
+                            float loss_weight, float loss_scale, float* d_emb, float* d_protos, int32_t accumulate_protos,
+                            void* workspace, int64_t workspace_bytes, void* stream);
+
+/* RoIAlign backward: d feature pyramid (fp32 NHWC per level, zero-initialised by the caller; `dfeat->data` are written)
+ * += scatter of dout (m,P,P,c) with the forward's geometry; fp32 atomic adds. */
+osr_status osr_roi_align_bwd(const osr_pyramid* dfeat, int32_t n, const float* boxes, const int32_t* batch_idx, int64_t m,
+                             int32_t pooled, int32_t canonical_level, int32_t canonical_size, int32_t min_level,
+                             const void* dout, int32_t dout_dtype, void* stream);
+
+/* g[i] = act[i] > 0 ? g[i] : 0, in place (gradient through a ReLU whose output is act). */
+osr_status osr_relu_mask(void* g, int32_t g_dtype, const void* act, int32_t act_dtype, int64_t n, void* stream);
+/* out[i] = (T)(a_f32[i] + b[i]); either addend may be null. */
+osr_status osr_add_cast(const float* a_f32, const void* b, void* out, int32_t dtype, int64_t n, void* stream);
+/* mode 0: FPN nearest-2x upsample-add backward, out (n,ho,wo,c) = base + 2x2 sums of src (n,hs,ws,c), ho = ceil(hs/2);
+ * mode 1: LastLevelMaxPool (p6 = p5[::2,::2]) backward, out (n,ho,wo,c) = base, plus src[y/2][x/2] at even (y,x). */
+osr_status osr_pool_bwd(const void* src, int32_t hs, int32_t ws, const void* base, void* out, int32_t n, int32_t ho,
+                        int32_t wo, int32_t c, int32_t mode, int32_t dtype, void* stream);
+
+/* SGD with momentum and weight decay ([d2] build_optimizer -> torch.optim.SGD): g' = grad*grad_scale*row_scale + wd*param;
+ * buf = momentum*buf + g'; param -= lr*buf; lowp_copy (nullable) = (T)(param*row_scale). row_scale (nullable): folded
+ * FrozenBN scale per leading-dimension row of row_elems elements. */
+osr_status osr_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
+                        float weight_decay, float grad_scale, const float* row_scale, int64_t row_elems, void* lowp_copy,
+                        int32_t lowp_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

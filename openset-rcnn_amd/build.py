@@ -27,6 +27,7 @@ SOURCES = {
     "osr_det_tail.hip": ["-ffp-contract=off"],
     "osr_train_fwd.hip": ["-ffp-contract=off"],
     "osr_conv_bwd.hip": [],
+    "osr_train_bwd.hip": [],
 }
 COMMON = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"] + \
     os.environ.get("OSR_EXTRA_HIPCC_FLAGS", "").split()  # diagnostic builds only (e.g. -DC64_STAMPS)

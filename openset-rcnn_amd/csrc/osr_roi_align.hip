@@ -418,3 +418,145 @@ extern "C" osr_status osr_roi_align_fwd(const osr_pyramid* f, int32_t feat_dtype
         default: return launch_out<bf16_t>(a, out_dtype, st);
     }
 }
+
+// ------------------------------------------------------------------------------------------------------
+// RoIAlign backward: d feature pyramid (fp32, zero-initialised by the caller) += scatter of d out.
+// Same geometry, level assignment and per-axis weight tables as the forward kernel: the gradient of a bin spreads over
+// its footprint pixels with weight wy[j] * wx[i] / count (per-sample 4-tap scatter when the tables overflow). One wave per
+// RoI, 4 channels per lane, fp32 atomic adds (several RoIs overlap on the same pixels; the summation order, and with it the
+// last bits of the result, therefore vary from run to run -- the reference's atomicAdd backward does the same).
+// ------------------------------------------------------------------------------------------------------
+struct RoiAlignBwdArgs {
+    float* data[4];
+    int h[4], w[4];
+    float scale[4];
+    int num_levels, c;
+    const float* boxes;
+    const int* batch_idx;
+    long long m;
+    int pooled, canonical_level, canonical_size, min_level;
+    const void* dout;
+};
+
+template <class TG>
+__global__ __launch_bounds__(256) void roi_align_bwd_kernel(RoiAlignBwdArgs a) {
+    __shared__ RaWaveLds s_all[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long r = (long long)blockIdx.x * 4 + wid;
+    if (r >= a.m) return;
+    RaWaveLds& S = s_all[wid];
+    const int P = a.pooled, C = a.c;
+    const TG* dout = reinterpret_cast<const TG*>(a.dout) + (size_t)r * P * P * C;
+    const int b = a.batch_idx[r];
+    if (b < 0) return;
+    const float bx1 = a.boxes[r * 4 + 0], by1 = a.boxes[r * 4 + 1], bx2 = a.boxes[r * 4 + 2], by2 = a.boxes[r * 4 + 3];
+    float sz = sqrtf((bx2 - bx1) * (by2 - by1));
+    float lvf = floorf((float)a.canonical_level + log2f(sz / (float)a.canonical_size + 1e-8f));
+    float lmin = (float)a.min_level, lmax = (float)(a.min_level + a.num_levels - 1);
+    lvf = fminf(fmaxf(lvf, lmin), lmax);
+    const int lv = __builtin_amdgcn_readfirstlane((int)lvf - a.min_level);
+    const int H = a.h[lv], W = a.w[lv];
+    const float scale = a.scale[lv];
+    float* feat = a.data[lv] + (size_t)b * H * W * C;
+    const float sw = bx1 * scale - 0.5f, sh = by1 * scale - 0.5f;
+    const float ew = bx2 * scale - 0.5f, eh = by2 * scale - 0.5f;
+    const float rw = ew - sw, rh = eh - sh;
+    const float bw = rw / (float)P, bh = rh / (float)P;
+    const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
+    const float count = (float)max(gh * gw, 1);
+    bool overflow = false;
+    for (int e = lane; e < 2 * 7 * RA_MAXC; e += 64) {
+        const int axis = e / (7 * RA_MAXC), bin = (e / RA_MAXC) % 7, col = e % RA_MAXC;
+        if (bin >= P) continue;
+        const float start = axis ? sw : sh, bs = axis ? bw : bh;
+        const int grid = axis ? gw : gh, size = axis ? W : H;
+        int first = -1, last = -1;
+        float acc = 0.f;
+        for (int i = 0; i < grid; ++i) {
+            int lo, hi; float wl, wh;
+            if (!axis_sample(start, bin, bs, i, grid, size, &lo, &hi, &wl, &wh)) continue;
+            if (first < 0) first = lo;
+            last = hi;
+            if (lo - first == col) acc += wl;
+            if (hi - first == col) acc += wh;
+        }
+        S.w[axis][bin][col] = acc;
+        if (col == 0) {
+            const int n = first < 0 ? 0 : last - first + 1;
+            S.lo[axis][bin] = first < 0 ? 0 : first;
+            S.n[axis][bin] = n;
+            overflow |= n > RA_MAXC;
+        }
+    }
+    const bool fallback = __any(overflow);
+    ra_wave_sync();
+    for (int ph = 0; ph < P; ++ph)
+        for (int pw = 0; pw < P; ++pw)
+            for (int c0 = lane * 4; c0 < C; c0 += 256) {
+                float g[4];
+                load4<TG>(dout + (size_t)(ph * P + pw) * C + c0, g);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] = g[k] / count;
+                if (!fallback) {
+                    const int y0 = S.lo[0][ph], ny = S.n[0][ph], x0 = S.lo[1][pw], nx = S.n[1][pw];
+                    for (int j = 0; j < ny; ++j) {
+                        const float wy = S.w[0][ph][j];
+                        float* row = feat + ((size_t)(y0 + j) * W + x0) * C + c0;
+                        for (int i = 0; i < nx; ++i) {
+                            const float wgt = wy * S.w[1][pw][i];
+                            if (wgt == 0.f) continue;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) atomicAdd(row + (size_t)i * C + k, wgt * g[k]);
+                        }
+                    }
+                } else {
+                    for (int iy = 0; iy < gh; ++iy) {
+                        int yl, yh; float hy, ly;
+                        if (!axis_sample(sh, ph, bh, iy, gh, H, &yl, &yh, &hy, &ly)) continue;
+                        for (int ix = 0; ix < gw; ++ix) {
+                            int xl, xh; float hx, lx;
+                            if (!axis_sample(sw, pw, bw, ix, gw, W, &xl, &xh, &hx, &lx)) continue;
+                            const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                atomicAdd(feat + ((size_t)yl * W + xl) * C + c0 + k, w1 * g[k]);
+                                atomicAdd(feat + ((size_t)yl * W + xh) * C + c0 + k, w2 * g[k]);
+                                atomicAdd(feat + ((size_t)yh * W + xl) * C + c0 + k, w3 * g[k]);
+                                atomicAdd(feat + ((size_t)yh * W + xh) * C + c0 + k, w4 * g[k]);
+                            }
+                        }
+                    }
+                }
+            }
+}
+
+extern "C" osr_status osr_roi_align_bwd(const osr_pyramid* dfeat, int32_t n, const float* boxes, const int32_t* batch_idx, int64_t m,
+                                        int32_t pooled, int32_t canonical_level, int32_t canonical_size, int32_t min_level, const void* dout,
+                                        int32_t dout_dtype, void* stream) {
+    OSR_REQUIRE(dfeat && boxes && batch_idx && dout, OSR_ERR_INVALID_ARG, "osr_roi_align_bwd: null pointer");
+    OSR_REQUIRE(dfeat->num_levels >= 1 && dfeat->num_levels <= 4, OSR_ERR_INVALID_ARG, "osr_roi_align_bwd: 1..4 levels, got %d", dfeat->num_levels);
+    OSR_REQUIRE(pooled >= 1 && pooled <= 7, OSR_ERR_UNSUPPORTED, "osr_roi_align_bwd: pooled size 1..7, got %d", pooled);
+    OSR_REQUIRE(dfeat->c > 0 && dfeat->c % 4 == 0, OSR_ERR_UNSUPPORTED, "osr_roi_align_bwd: channels must be a multiple of 4, got %d", dfeat->c);
+    OSR_REQUIRE(osr_dtype_ok(dout_dtype), OSR_ERR_INVALID_ARG, "osr_roi_align_bwd: bad dtype");
+    OSR_REQUIRE(n >= 1 && m >= 0 && m < (1ll << 31) && canonical_size > 0, OSR_ERR_INVALID_ARG, "osr_roi_align_bwd: bad n / m / canonical_size");
+    if (m == 0) return OSR_OK;
+    RoiAlignBwdArgs a;
+    for (int l = 0; l < 4; ++l) {
+        int s = l < dfeat->num_levels ? l : 0;
+        OSR_REQUIRE(dfeat->data[s] && dfeat->h[s] > 0 && dfeat->w[s] > 0, OSR_ERR_INVALID_ARG, "osr_roi_align_bwd: bad level %d", s);
+        a.data[l] = (float*)dfeat->data[s]; a.h[l] = dfeat->h[s]; a.w[l] = dfeat->w[s]; a.scale[l] = dfeat->scale[s];
+    }
+    a.num_levels = dfeat->num_levels; a.c = dfeat->c; a.boxes = boxes; a.batch_idx = batch_idx; a.m = m;
+    a.pooled = pooled; a.canonical_level = canonical_level; a.canonical_size = canonical_size; a.min_level = min_level;
+    a.dout = dout;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((m + 3) / 4)), block(256);
+    switch (dout_dtype) {
+        case OSR_F32: hipLaunchKernelGGL(roi_align_bwd_kernel<float>, grid, block, 0, st, a); break;
+        case OSR_F16: hipLaunchKernelGGL(roi_align_bwd_kernel<f16_t>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(roi_align_bwd_kernel<bf16_t>, grid, block, 0, st, a); break;
+    }
+    OSR_CHECK_LAUNCH("osr_roi_align_bwd");
+    return OSR_OK;
+}

@@ -90,6 +90,18 @@ PROTOTYPES = {
     "osr_conv2d_wgrad_workspace_bytes": (I64, [P]),
     "osr_conv2d_wgrad": (I32, [P, P, P, P, I32, P, I64, P]),
     "osr_bias_grad": (I32, [P, I32, I64, I32, P, I32, P, I64, P]),
+    "osr_rpn_losses_bwd": (I32, [P, P, I32, P, P, P, P, P, P, F32, F32, I32, F32, P, P]),
+    "osr_cfrpn_tail_bwd_workspace_bytes": (I64, []),
+    "osr_cfrpn_tail_bwd": (I32, [P, I32, I64, P, P, P, P, P, I32, P, I64, P]),
+    "osr_roi_box_losses_bwd": (I32, [P, P, P, P, P, I64, I32, P, F32, F32, F32, P, P, I64, P]),
+    "osr_softmax_ce_loss_bwd": (I32, [P, I64, I32, P, I32, F32, F32, P, P, I64, P]),
+    "osr_pln_loss_bwd_workspace_bytes": (I64, [I64]),
+    "osr_pln_loss_bwd": (I32, [P, I64, I32, P, I32, P, P, F32, F32, F32, F32, F32, P, P, I32, P, I64, P]),
+    "osr_roi_align_bwd": (I32, [P, I32, P, P, I64, I32, I32, I32, I32, P, I32, P]),
+    "osr_relu_mask": (I32, [P, I32, P, I32, I64, P]),
+    "osr_add_cast": (I32, [P, P, P, I32, I64, P]),
+    "osr_pool_bwd": (I32, [P, I32, I32, P, P, I32, I32, I32, I32, I32, I32, P]),
+    "osr_sgd_step": (I32, [P, P, P, I64, F32, F32, F32, F32, P, I64, P, I32, P]),
 }
 
 _lib = None

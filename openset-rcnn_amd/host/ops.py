@@ -590,3 +590,130 @@ def bias_grad(dy: torch.Tensor, db: Optional[torch.Tensor] = None, accumulate: b
     ws = torch.empty((512 * cout * 4,), dtype=torch.uint8, device=dy.device)
     check(lib.osr_bias_grad(_p(dy), _DT[dy.dtype], m, cout, _p(db), int(accumulate), _p(ws), ws.numel(), _stream()), "osr_bias_grad")
     return db
+
+
+# ----------------------------------------------------------------------------------------------------------
+# training step, backward half: losses, per-row stages, elementwise, optimiser
+# ----------------------------------------------------------------------------------------------------------
+def rpn_losses_bwd(lv: RpnLevels, cell_anchors, n: int, pred_deltas, pred_ctr, labels_reg, labels_obj, matched_boxes, ctr_target,
+                   loc_weight=0.5, ctr_weight=0.5, batch_size_per_image=256, loss_scale=1.0) -> torch.Tensor:
+    """-> d_out5 (rows, 5) fp32, level-major: gradient w.r.t. the head's {4 deltas, centerness logit}."""
+    lib = _lib.load()
+    out = torch.empty((pred_ctr.numel(), 5), dtype=torch.float32, device=pred_ctr.device)
+    check(lib.osr_rpn_losses_bwd(C.byref(lv), _p(cell_anchors), n, _p(pred_deltas), _p(pred_ctr), _p(labels_reg), _p(labels_obj),
+                                 _p(matched_boxes), _p(ctr_target), loc_weight, ctr_weight, batch_size_per_image, loss_scale, _p(out), _stream()),
+          "osr_rpn_losses_bwd")
+    return out
+
+
+def cfrpn_tail_bwd(t: torch.Tensor, w_tail: torch.Tensor, d_out5: torch.Tensor):
+    """t (rows,256) f16/bf16, w_tail (5,256) fp32, d_out5 (rows,5) fp32 -> dt (rows,256) like t, dw_tail (5,256), db_tail (5)."""
+    lib = _lib.load()
+    _need(t, name="t"); _need(w_tail, torch.float32, "w_tail"); _need(d_out5, torch.float32, "d_out5")
+    rows = t.shape[0]
+    dt = torch.empty_like(t)
+    dw = torch.empty((5, 256), dtype=torch.float32, device=t.device)
+    db = torch.empty((5,), dtype=torch.float32, device=t.device)
+    wsb = lib.osr_cfrpn_tail_bwd_workspace_bytes()
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=t.device)
+    check(lib.osr_cfrpn_tail_bwd(_p(t), _DT[t.dtype], rows, _p(w_tail), _p(d_out5), _p(dt), _p(dw), _p(db), 0, _p(ws), wsb, _stream()),
+          "osr_cfrpn_tail_bwd")
+    return dt, dw, db
+
+
+def roi_box_losses_bwd(pred5, proposal_boxes, gt_boxes, gt_classes, gt_iou, num_classes: int, reg_weights=(10.0, 10.0, 5.0, 5.0),
+                       box_weight=0.5, iou_weight=0.5, loss_scale=1.0) -> torch.Tensor:
+    lib = _lib.load()
+    _need(pred5, torch.float32, "pred5")
+    m = gt_classes.numel()
+    out = torch.empty((m, 5), dtype=torch.float32, device=pred5.device)
+    ws = torch.empty((16,), dtype=torch.uint8, device=pred5.device)
+    rw = (C.c_float * 4)(*reg_weights)
+    check(lib.osr_roi_box_losses_bwd(_p(pred5), _p(proposal_boxes), _p(gt_boxes), _p(gt_classes), _p(gt_iou), m, num_classes, rw, box_weight,
+                                     iou_weight, loss_scale, _p(out), _p(ws), 16, _stream()), "osr_roi_box_losses_bwd")
+    return out
+
+
+def softmax_ce_loss_bwd(logits, gt_classes, num_classes: int, loss_weight: float, loss_scale=1.0) -> torch.Tensor:
+    lib = _lib.load()
+    _need(logits, torch.float32, "logits")
+    m, nk1 = logits.shape
+    out = torch.empty_like(logits)
+    ws = torch.empty((16,), dtype=torch.uint8, device=logits.device)
+    check(lib.osr_softmax_ce_loss_bwd(_p(logits), m, nk1 - 1, _p(gt_classes), num_classes, loss_weight, loss_scale, _p(out), _p(ws), 16, _stream()),
+          "osr_softmax_ce_loss_bwd")
+    return out
+
+
+def pln_loss_bwd(emb, protos_raw, gt_classes, ious, iou_thr: float, alpha: float, beta: float, loss_weight: float, loss_scale=1.0):
+    """-> (d_emb (m,d), d_protos (K,d)) fp32; protos_raw are the un-normalised prototype parameters."""
+    lib = _lib.load()
+    _need(emb, torch.float32, "emb"); _need(protos_raw, torch.float32, "protos_raw")
+    m, d = emb.shape
+    de = torch.empty_like(emb)
+    dp = torch.empty_like(protos_raw)
+    wsb = lib.osr_pln_loss_bwd_workspace_bytes(m)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=emb.device)
+    check(lib.osr_pln_loss_bwd(_p(emb), m, d, _p(protos_raw), protos_raw.shape[0], _p(gt_classes), _p(ious), iou_thr, alpha, beta, loss_weight,
+                               loss_scale, _p(de), _p(dp), 0, _p(ws), wsb, _stream()), "osr_pln_loss_bwd")
+    return de, dp
+
+
+def roi_align_bwd(dout: torch.Tensor, shapes: Sequence[Tuple[int, int]], n: int, scales: Sequence[float], boxes, batch_idx,
+                  canonical_level: int = 4, canonical_size: int = 224, min_level: int = 2) -> List[torch.Tensor]:
+    """dout (m,P,P,c) -> list of fp32 (n,h,w,c) feature gradients, one per level."""
+    lib = _lib.load()
+    _need(dout, name="dout"); _need(boxes, torch.float32, "boxes"); _need(batch_idx, torch.int32, "batch_idx")
+    m, pooled, _, c = dout.shape
+    outs = [torch.zeros((n, h, w, c), dtype=torch.float32, device=dout.device) for h, w in shapes]
+    py = Pyramid()
+    py.num_levels, py.c = len(outs), c
+    for i, (f, s) in enumerate(zip(outs, scales)):
+        py.h[i], py.w[i], py.scale[i], py.data[i] = f.shape[1], f.shape[2], float(s), f.data_ptr()
+    check(lib.osr_roi_align_bwd(C.byref(py), n, _p(boxes), _p(batch_idx), m, pooled, canonical_level, canonical_size, min_level, _p(dout),
+                                _DT[dout.dtype], _stream()), "osr_roi_align_bwd")
+    return outs
+
+
+def relu_mask_(g: torch.Tensor, act: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _need(g, name="g"); _need(act, name="act")
+    if g.numel() != act.numel():
+        raise OsrError("relu_mask_: size mismatch")
+    check(lib.osr_relu_mask(_p(g), _DT[g.dtype], _p(act), _DT[act.dtype], g.numel(), _stream()), "osr_relu_mask")
+    return g
+
+
+def add_cast(a_f32: Optional[torch.Tensor], b: Optional[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
+    lib = _lib.load()
+    ref = a_f32 if a_f32 is not None else b
+    if a_f32 is not None:
+        _need(a_f32, torch.float32, "a_f32")
+    if b is not None:
+        _need(b, dtype, "b")
+    out = torch.empty(ref.shape, dtype=dtype, device=ref.device)
+    check(lib.osr_add_cast(_p(a_f32), _p(b), _p(out), _DT[dtype], out.numel(), _stream()), "osr_add_cast")
+    return out
+
+
+def pool_bwd(src: torch.Tensor, out_hw: Tuple[int, int], base: Optional[torch.Tensor], mode: int) -> torch.Tensor:
+    """mode 0: FPN top-down backward (out = base + 2x2 sums of src); mode 1: p6 subsample backward."""
+    lib = _lib.load()
+    _need(src, name="src")
+    n, hs, ws_, c = src.shape
+    ho, wo = out_hw
+    if base is not None:
+        _need(base, src.dtype, "base")
+    out = torch.empty((n, ho, wo, c), dtype=src.dtype, device=src.device)
+    check(lib.osr_pool_bwd(_p(src), hs, ws_, _p(base), _p(out), n, ho, wo, c, mode, _DT[src.dtype], _stream()), "osr_pool_bwd")
+    return out
+
+
+def sgd_step_(param, grad, buf, lr: float, momentum: float, weight_decay: float, grad_scale: float = 1.0, row_scale=None, lowp=None):
+    lib = _lib.load()
+    _need(param, torch.float32, "param"); _need(grad, torch.float32, "grad"); _need(buf, torch.float32, "buf")
+    if grad.numel() != param.numel() or buf.numel() != param.numel():
+        raise OsrError("sgd_step_: size mismatch")
+    row_elems = param.numel() // param.shape[0] if row_scale is not None else 1
+    check(lib.osr_sgd_step(_p(param), _p(grad), _p(buf), param.numel(), lr, momentum, weight_decay, grad_scale, _p(row_scale), row_elems,
+                           _p(lowp), _DT[lowp.dtype] if lowp is not None else 0, _stream()), "osr_sgd_step")

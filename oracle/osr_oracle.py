@@ -426,6 +426,57 @@ def roi_align_ref(feat: np.ndarray, rois: np.ndarray, scale: float, out_size: in
     return out
 
 
+
+def roi_align_torch(feat: torch.Tensor, rois: torch.Tensor, scale: float, out_size: int = 7) -> torch.Tensor:
+    """The same algorithm as roi_align_ref (aligned=True, sampling_ratio=0) in differentiable torch ops, so that autograd
+    provides the reference for osr_roi_align_bwd. The sample positions do not depend on the features; only the gathers
+    and the weighted sums are traced. Small cases only (python loops)."""
+    n, c, height, width = feat.shape
+    outs = []
+    for r in range(rois.shape[0]):
+        b = int(rois[r, 0])
+        f32 = np.float32
+        sw_ = f32(rois[r, 1]) * f32(scale) - f32(0.5)
+        sh_ = f32(rois[r, 2]) * f32(scale) - f32(0.5)
+        ew_ = f32(rois[r, 3]) * f32(scale) - f32(0.5)
+        eh_ = f32(rois[r, 4]) * f32(scale) - f32(0.5)
+        rw, rh = f32(ew_ - sw_), f32(eh_ - sh_)
+        bh, bw = f32(rh / f32(out_size)), f32(rw / f32(out_size))
+        gh, gw = int(math.ceil(float(rh) / out_size)), int(math.ceil(float(rw) / out_size))
+        count = float(max(gh * gw, 1))
+        ys, xs, ws, bins = [], [], [], []
+        for ph in range(out_size):
+            for pw in range(out_size):
+                for iy in range(gh):
+                    y = f32(sh_ + f32(ph) * bh + f32(f32(iy) + f32(0.5)) * bh / f32(gh))
+                    for ix in range(gw):
+                        x = f32(sw_ + f32(pw) * bw + f32(f32(ix) + f32(0.5)) * bw / f32(gw))
+                        if y < -1.0 or y > height or x < -1.0 or x > width:
+                            continue
+                        yy, xx = max(y, f32(0.0)), max(x, f32(0.0))
+                        yl, xl = int(yy), int(xx)
+                        if yl >= height - 1:
+                            yh = yl = height - 1
+                            yy = f32(yl)
+                        else:
+                            yh = yl + 1
+                        if xl >= width - 1:
+                            xh = xl = width - 1
+                            xx = f32(xl)
+                        else:
+                            xh = xl + 1
+                        ly, lx = f32(yy - f32(yl)), f32(xx - f32(xl))
+                        hy, hx = f32(f32(1.0) - ly), f32(f32(1.0) - lx)
+                        for (py_, px_, wgt) in ((yl, xl, hy * hx), (yl, xh, hy * lx), (yh, xl, ly * hx), (yh, xh, ly * lx)):
+                            ys.append(py_); xs.append(px_); ws.append(float(wgt) / count); bins.append(ph * out_size + pw)
+        o = feat.new_zeros((out_size * out_size, c))
+        if ys:
+            vals = feat[b][:, torch.tensor(ys), torch.tensor(xs)].t() * torch.tensor(ws, dtype=feat.dtype).unsqueeze(1)  # (taps, c)
+            o = o.index_add(0, torch.tensor(bins), vals)
+        outs.append(o.t().reshape(c, out_size, out_size))
+    return torch.stack(outs) if outs else feat.new_zeros((0, c, out_size, out_size))
+
+
 def roi_pooler_ref(feats: List[torch.Tensor], boxes_per_image: List[torch.Tensor],
                    scales=(0.25, 0.125, 0.0625, 0.03125), out_size=7, roi_align_fn=None) -> torch.Tensor:
     """[d2-mem] ROIPooler.forward (ROIAlignV2, sampling_ratio 0): per-level RoIAlign,

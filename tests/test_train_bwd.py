@@ -1,0 +1,192 @@
+"""GPU parity of the loss / per-row backward kernels against torch autograd applied to the oracle's forward functions."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import c_binding as CO
+from oracle import osr_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops(osr):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: the HIP path has no CPU fallback")
+    osr._lib.load()
+    return osr.ops
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
+
+
+def test_rpn_losses_and_tail_backward(ops):
+    import tests.test_train_fwd as TF
+    shapes, strides, sizes = [(24, 40), (12, 20), (6, 10), (3, 5)], (4, 8, 16, 32), (32, 64, 128, 256)
+    c = TF._rpn_case(ops, 61, shapes, strides, sizes, 2, (96, 160), [5, 3])
+    lr, lo, mb, ct = TF._check_rpn_targets(ops, c)
+    n, gg = c["n"], g(62)
+    # hidden state t per level (level-major rows), tail weights
+    rows = [n * h * w for h, w in shapes]
+    t = F.relu(torch.randn(sum(rows), 256, generator=gg)).half()
+    w_tail = torch.randn(5, 256, generator=gg) * 0.5
+    b_tail = torch.tensor([0.4, 0.4, 0.4, 0.4, 0.0])
+    tt = t.float().requires_grad_(True)
+    wt = w_tail.clone().requires_grad_(True)
+    bt = b_tail.clone().requires_grad_(True)
+    u = tt / tt.norm(dim=1, keepdim=True).clamp(min=1e-12)
+    o = u @ wt.t() + bt
+    deltas_lm, ctr_lm = o[:, :4], torch.sigmoid(o[:, 4])
+    # level-major -> image-major (n, R, .)
+    dl, cl, off = [], [], 0
+    for (h, w), r in zip(shapes, rows):
+        dl.append(deltas_lm[off:off + r].view(n, h * w, 4))
+        cl.append(ctr_lm[off:off + r].view(n, h * w))
+        off += r
+    ref = O.rpn_losses(c["anchors"], torch.cat(dl, 1), torch.cat(cl, 1), lr.cpu(), lo.cpu(), mb.cpu(), ct.cpu())
+    loss = ref["loss_rpn_loc"] + ref["loss_rpn_ctr"]
+    loss.backward()
+    scale = 64.0
+    d5 = ops.rpn_losses_bwd(c["lv"], c["cell"], n, deltas_lm.detach().contiguous().to(DEV), ctr_lm.detach().contiguous().to(DEV), lr, lo, mb, ct,
+                            loss_scale=scale)
+    # d o: from autograd through the sigmoid
+    o2 = o.detach().clone().requires_grad_(True)
+    dl2, cl2, off = [], [], 0
+    for (h, w), r in zip(shapes, rows):
+        dl2.append(o2[off:off + r, :4].reshape(n, h * w, 4))
+        cl2.append(torch.sigmoid(o2[off:off + r, 4]).view(n, h * w))
+        off += r
+    ref2 = O.rpn_losses(c["anchors"], torch.cat(dl2, 1), torch.cat(cl2, 1), lr.cpu(), lo.cpu(), mb.cpu(), ct.cpu())
+    (ref2["loss_rpn_loc"] + ref2["loss_rpn_ctr"]).backward()
+    assert rel(d5 / scale, o2.grad) < 1e-4
+    assert int((o2.grad.abs().sum(1) > 0).sum()) > 20
+    dt, dw, db = ops.cfrpn_tail_bwd(t.to(DEV), w_tail.to(DEV), d5)
+    assert rel(dw / scale, wt.grad) < 1e-4 and rel(db / scale, bt.grad) < 1e-4
+    assert rel(dt.float() / scale, tt.grad * (t.float() > 0)) < 2e-3  # stored in fp16
+
+
+def test_roi_head_losses_backward(ops):
+    gg = g(71)
+    m, K, NC, d = 512, 20, 81, 256
+    cls = torch.randint(0, K, (m,), generator=gg)
+    cls[torch.rand(m, generator=gg) < 0.6] = NC
+    cls[m - 20:] = -1  # padding rows
+    prop = torch.rand(m, 4, generator=gg) * 300
+    prop[:, 2:] = prop[:, :2] + 8 + torch.rand(m, 2, generator=gg) * 200
+    gtb = prop + torch.randn(m, 4, generator=gg) * 6
+    gtb[:, 2:] = torch.max(gtb[:, 2:], gtb[:, :2] + 2)
+    gi = torch.rand(m, generator=gg)
+    pred = torch.randn(m, 5, generator=gg)
+    ok = cls >= 0
+    # box / IoU losses
+    p = pred.clone().requires_grad_(True)
+    lb, li = O.roi_box_losses(p[ok][:, :4], torch.sigmoid(p[ok][:, 4]), prop[ok], gtb[ok], cls[ok], gi[ok], NC)
+    (lb + li).backward()
+    dp = ops.roi_box_losses_bwd(pred.to(DEV), prop.to(DEV), gtb.to(DEV), cls.to(DEV), gi.to(DEV), NC, loss_scale=8.0)
+    assert rel(dp / 8.0, p.grad) < 1e-4
+    # cross entropy
+    logits = torch.randn(m, K + 1, generator=gg) * 2
+    lg = logits.clone().requires_grad_(True)
+    O.softmax_ce_loss(lg[ok], cls[ok], NC, K, 0.9).backward()
+    dl = ops.softmax_ce_loss_bwd(logits.to(DEV), cls.to(DEV), NC, 0.9, loss_scale=4.0)
+    assert rel(dl / 4.0, lg.grad) < 1e-4
+    # PLN: gradient w.r.t. the embedding and the raw prototypes (through both normalisations)
+    protos = (torch.randn(K, d, generator=gg) * 1.5).requires_grad_(True)
+    emb = (torch.randn(m, d, generator=gg) + 0.8 * protos.detach()[cls.clamp(0, K - 1)]).requires_grad_(True)
+    new = F.normalize(emb[ok])
+    rep = F.normalize(protos)
+    c_ok, i_ok = cls[ok], gi[ok]
+    fg = torch.nonzero((c_ok >= 0) & (c_ok < K) & (i_ok > 0.5)).squeeze(1)
+    dist = 1.0 - new[fg] @ rep.t()
+    ar = torch.arange(dist.shape[0])
+    intra = dist[ar, c_ok[fg]]
+    d2 = dist.clone()
+    d2[ar, c_ok[fg]] = 1000
+    inter = d2.min(dim=1)[0]
+    cd = (1.0 - rep @ rep.t()).clone()
+    cd[torch.arange(K), torch.arange(K)] = 1000
+    cdist = cd.min(dim=1)[0]
+    alpha, beta = 0.3, 1.1
+    loss = (torch.clamp(intra - alpha, min=0).sum() + torch.clamp(beta - inter, min=0).sum() + torch.clamp(beta + alpha - cdist, min=0).sum()) * 0.5 / int(ok.sum())
+    loss.backward()
+    assert float(torch.clamp(beta + alpha - cdist, min=0).sum()) > 0 and float(torch.clamp(intra - alpha, min=0).sum()) > 0
+    de, dpr = ops.pln_loss_bwd(emb.detach().to(DEV), protos.detach().to(DEV), cls.to(DEV), gi.to(DEV), 0.5, alpha, beta, 0.5, loss_scale=16.0)
+    assert rel(de / 16.0, emb.grad) < 1e-4
+    assert rel(dpr / 16.0, protos.grad) < 1e-4
+    # the forward kernel agrees with this formulation
+    fw = ops.pln_loss_fwd(emb.detach().to(DEV), F.normalize(protos.detach()).to(DEV), cls.to(DEV), gi.to(DEV), 0.5, alpha, beta, 0.5)
+    assert float(fw[0]) == pytest.approx(float(loss), rel=1e-5)
+
+
+def test_roi_align_backward(ops):
+    gg = g(81)
+    n, c = 2, 32
+    shapes = [(32, 48), (16, 24), (8, 12), (4, 6)]
+    m = 60
+    ctr = torch.rand(m, 2, generator=gg) * torch.tensor([192.0, 128.0])
+    size = torch.exp(torch.rand(m, 2, generator=gg) * 5.0 + 0.5)
+    boxes = torch.cat((ctr - size / 2, ctr + size / 2), dim=1)
+    boxes[0] = torch.tensor([-20.0, -10.0, 40.0, 30.0])
+    boxes[1] = torch.tensor([0.0, 0.0, 192.0, 128.0])  # large RoI: table overflow -> per-sample path
+    bidx = torch.randint(0, n, (m,), generator=gg, dtype=torch.int32)
+    bidx[5] = -1
+    dout = torch.randn(m, 7, 7, c, generator=gg)
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+    got = ops.roi_align_bwd(dout.to(DEV), shapes, n, scales, boxes.to(DEV), bidx.to(DEV))
+    # reference: the forward is linear in the features, so d feat = J^T dout with J probed by autograd on the torch restatement
+    lv = O.assign_levels(boxes)
+    for l, (h, w) in enumerate(shapes):
+        feat = torch.zeros(n, c, h, w, requires_grad=True)
+        ids = torch.nonzero((lv == l) & (bidx >= 0)).squeeze(1)
+        if len(ids) == 0:
+            assert float(got[l].abs().max()) == 0.0
+            continue
+        rois = torch.cat((bidx[ids].float().unsqueeze(1), boxes[ids]), dim=1)
+        out = O.roi_align_torch(feat, rois, scales[l])
+        out.backward(dout[ids].permute(0, 3, 1, 2))
+        assert rel(got[l].permute(0, 3, 1, 2), feat.grad) < 1e-4, f"level {l}"
+
+
+def test_elementwise_and_sgd(ops):
+    gg = g(91)
+    a = torch.randn(2, 9, 7, 16, generator=gg)
+    act = torch.randn(2, 9, 7, 16, generator=gg)
+    gt = a.clone().half().to(DEV)
+    ops.relu_mask_(gt, act.half().to(DEV))
+    assert torch.equal(gt.cpu(), (a.half() * (act.half() > 0)))
+    out = ops.add_cast(a.to(DEV), act.half().to(DEV), torch.float16)
+    assert torch.equal(out.cpu(), (a + act.half().float()).half())
+    # FPN top-down backward: fine (9x7) -> coarse (5x4)
+    base = torch.randn(2, 5, 4, 16, generator=gg)
+    got = ops.pool_bwd(a.to(DEV), (5, 4), base.to(DEV), 0).cpu()
+    up = torch.zeros(2, 5, 4, 16, requires_grad=True)
+    fine = up.permute(0, 3, 1, 2).repeat_interleave(2, 2).repeat_interleave(2, 3)[:, :, :9, :7]
+    fine.backward(a.permute(0, 3, 1, 2))
+    assert rel(got, base + up.grad) < 1e-6
+    # p6 = p5[::2, ::2] backward: src (5x4) -> out (9x7)
+    src = torch.randn(2, 5, 4, 16, generator=gg)
+    got = ops.pool_bwd(src.to(DEV), (9, 7), a.to(DEV), 1).cpu()
+    ref = a.clone()
+    ref[:, ::2, ::2] += src
+    assert rel(got, ref) < 1e-6
+    # SGD with momentum, weight decay, loss scale and a folded row scale, two steps, against torch.optim.SGD
+    p0 = torch.randn(6, 10, generator=gg)
+    rs = torch.rand(6, generator=gg) + 0.5
+    tp = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([tp], lr=0.02, momentum=0.9, weight_decay=1e-2)
+    p, buf = p0.clone().to(DEV), torch.zeros(6, 10).to(DEV)
+    lowp = torch.empty(6, 10, dtype=torch.float16, device=DEV)
+    for step in range(2):
+        gfold = torch.randn(6, 10, generator=gg)  # gradient w.r.t. the folded weight w * rs
+        tp.grad = gfold * rs[:, None]
+        opt.step()
+        ops.sgd_step_(p, (gfold * 32.0).to(DEV), buf, 0.02, 0.9, 1e-2, grad_scale=1.0 / 32.0, row_scale=rs.to(DEV), lowp=lowp)
+    assert rel(p, tp.detach()) < 1e-6
+    assert torch.equal(lowp.cpu(), (p.cpu() * rs[:, None]).half())
