@@ -1,0 +1,300 @@
+"""One training step of Openset R-CNN on the HIP path: forward with saved activations, the six losses, backward through every
+trainable layer, SGD with momentum -- the loop body of the reference's trainer (train.py:132-148: `loss_dict = model(data);
+losses.backward(); optimizer.step()`) for META_ARCHITECTURE GeneralizedRCNN with [d2] defaults: FREEZE_AT 2 (stem and res2
+frozen), FrozenBN everywhere, SGD momentum 0.9, weight decay 1e-4 on weights and biases.
+
+What runs where: every convolution / FC forward, data gradient and weight gradient is an MFMA kernel launch (osr_conv2d_fwd /
+osr_conv2d_wgrad), targets, sampling, losses and their gradients, RoIAlign forward/backward, the CF-RPN tail and the update are
+the kernels of osr_train_fwd.hip / osr_train_bwd.hip / osr_roi_align.hip. torch is used for memory, views, zero-fills and a few
+layout copies of small fp32 matrices (transposes / column padding for the exact-fp32 GEMM of the 5-, 21- and 256-wide heads).
+
+Mixed precision: fp16 (or bf16) activations and activation gradients, fp32 accumulation, fp32 master weights and momentum,
+static loss scaling (gradient tensors are multiplied by `loss_scale`, the update divides it out).
+Data parallel: one process per GPU; `all_reduce_grads()` sums the single flat fp32 gradient buffer over RCCL (train.py:201-205
+wraps the model in DDP) and the update divides by the world size."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .engine import OpensetRCNNEngine
+from .weights import R50_BLOCKS, pack_conv_weight, pack_fc1_weight
+
+
+def _dgrad_pack(w_lp: torch.Tensor) -> torch.Tensor:
+    """(cout,kh,kw,cin) packed forward weight -> (cin,kh,kw,cout) flipped: the weight of the backward-data convolution."""
+    return w_lp.flip(1, 2).permute(3, 1, 2, 0).contiguous()
+
+
+class OpensetRCNNTrainer:
+    def __init__(self, params: Dict[str, torch.Tensor], cfg: Optional[dict] = None, dtype: torch.dtype = torch.float16, device: str = "cuda",
+                 lr: float = 0.005, momentum: float = 0.9, weight_decay: float = 1e-4, loss_scale: float = 1024.0, freeze_at: int = 2):
+        self.eng = OpensetRCNNEngine(params, cfg, dtype, device)
+        self.eng.fuse_rpn_head = False  # the hidden state of the head is needed by its backward
+        self.dtype, self.device = dtype, self.eng.device
+        self.lr, self.momentum, self.weight_decay, self.loss_scale = lr, momentum, weight_decay, loss_scale
+        self.freeze_at = freeze_at
+        e, dev = self.eng, self.eng.device
+        f32 = lambda t: t.detach().float().contiguous().to(dev)  # noqa: E731
+        # ---- trainable parameters: fp32 masters (conv / FC weights in the kernels' packed layout) ----
+        self.master: Dict[str, torch.Tensor] = {}
+        self.lowp: Dict[str, Optional[torch.Tensor]] = {}  # working copy the forward kernels read (None: the master itself is read)
+        self.conv_names: List[str] = []
+        for si, nb in enumerate(R50_BLOCKS):
+            if si + 2 <= freeze_at:
+                continue
+            for b in range(nb):
+                pre = f"backbone.bottom_up.res{si + 2}.{b}"
+                for cname in (["shortcut"] if b == 0 else []) + ["conv1", "conv2", "conv3"]:
+                    self._add_conv(f"{pre}.{cname}", params, bias=False)  # FrozenBN: the folded shift is not a parameter
+        for lvl in (2, 3, 4, 5):
+            self._add_conv(f"backbone.fpn_lateral{lvl}", params, bias=True)
+            self._add_conv(f"backbone.fpn_output{lvl}", params, bias=True)
+        self._add_conv("proposal_generator.rpn_head.conv", params, bias=True)
+        self.master["rpn_tail.w"], self.master["rpn_tail.b"] = e.rpn_wtail, e.rpn_btail  # (5,256): 4 ltrb rows + centerness
+        e.rpn_wd, e.rpn_wc, e.rpn_bd, e.rpn_bc = e.rpn_wtail[:4], e.rpn_wtail[4:5], e.rpn_btail[:4], e.rpn_btail[4:5]  # views: one storage
+        self.master["fc1.w"] = pack_fc1_weight(params["roi_heads.box_head.fc1.weight"], 256, e.cfg["pooler_resolution"], torch.float32).to(dev)
+        self.lowp["fc1.w"] = e.fc1_w
+        self.master["fc1.b"] = e.fc1_b
+        self.master["fc2.w"] = f32(params["roi_heads.box_head.fc2.weight"])
+        self.lowp["fc2.w"] = e.fc2_w
+        self.master["fc2.b"] = e.fc2_b
+        self.master["pred.w"], self.master["pred.b"] = e.pred_w, e.pred_b
+        self.master["enc.w"], self.master["enc.b"] = e.enc_w, e.enc_b
+        self.master["dec.w"], self.master["dec.b"] = e.dec_w, e.dec_b
+        self.master["cls.w"], self.master["cls.b"] = e.cls_w, e.cls_b
+        self.master["protos"] = f32(params["roi_heads.dml.representatives"])
+        # ---- one flat gradient buffer (the all-reduce operand), momentum buffers ----
+        al = lambda x: (x + 3) // 4 * 4  # noqa: E731  every view starts 16-byte aligned (the kernels use 16-byte accesses)
+        total = sum(al(t.numel()) for t in self.master.values())
+        self.grad_flat = torch.zeros((total,), dtype=torch.float32, device=dev)
+        self.grad: Dict[str, torch.Tensor] = {}
+        off = 0
+        for k, t in self.master.items():
+            self.grad[k] = self.grad_flat[off:off + t.numel()].view(t.shape)
+            off += al(t.numel())
+        self.mom = {k: torch.zeros_like(t) for k, t in self.master.items()}
+        self.num_params = sum(t.numel() for t in self.master.values())
+        self._refresh_derived()
+
+    def _add_conv(self, name: str, params, bias: bool):
+        e = self.eng
+        self.master[name + ".w"] = pack_conv_weight(params[name + ".weight"], torch.float32).to(e.device)
+        self.lowp[name + ".w"] = e.w[name + ".w"]
+        if bias:
+            self.master[name + ".b"] = e.w[name + ".b"]
+        self.conv_names.append(name)
+
+    def _refresh_derived(self):
+        """Everything that is a function of the parameters and read by a kernel: backward-data weights, transposed fp32 heads,
+        normalised prototypes."""
+        e = self.eng
+        self.wd = {n: _dgrad_pack(e.w[n + ".w"]) for n in self.conv_names}
+        self.wd["fc1"] = e.fc1_w.t().contiguous().view(e.fc1_w.shape[1], 1, 1, e.fc1_w.shape[0])
+        self.wd["fc2"] = e.fc2_w.t().contiguous().view(e.fc2_w.shape[1], 1, 1, e.fc2_w.shape[0])
+        pad = lambda w, k: torch.nn.functional.pad(w, (0, 0, 0, k - w.shape[0]))  # noqa: E731  rows -> k (zero rows)
+        self.t_cls = pad(e.cls_w, 32).t().contiguous()      # (1024, 32): d rec = d logits(padded to 32) . W_cls
+        self.t_pred = pad(e.pred_w, 16).t().contiguous()    # (1024, 16)
+        self.t_dec = e.dec_w.t().contiguous()                # (256, 1024): d emb = d rec . W_dec
+        self.t_enc = e.enc_w.t().contiguous()                # (1024, 256): d box_feats = d emb . W_enc
+        e.protos = ops.l2_normalize_rows(self.master["protos"])
+
+    # ---- forward with saved activations -------------------------------------------------------------------------
+    def _forward(self, images, image_hw, hp, wp, gt_boxes, gt_classes, gt_count, keys):
+        e, c = self.eng, self.eng.cfg
+        n = images.shape[0]
+        s: dict = {}
+        xpad = ops.preprocess(images, hp, wp, c["pixel_mean"], c["pixel_std"], self.dtype)
+        x = ops.stem_conv(xpad, e.w["backbone.bottom_up.stem.conv1.w"], e.w["backbone.bottom_up.stem.conv1.b"], hp, wp, relu=True)
+        x = ops.maxpool3x3s2(x)
+        blocks = []
+        feats = {}
+        for si, nb in enumerate(R50_BLOCKS):
+            for b in range(nb):
+                pre = f"backbone.bottom_up.res{si + 2}.{b}"
+                stride = 2 if (b == 0 and si > 0) else 1
+                sc = e._conv(x, pre + ".shortcut", stride) if b == 0 else x
+                o1 = e._conv(x, pre + ".conv1", stride, relu=True)
+                o2 = e._conv(o1, pre + ".conv2", 1, 1, relu=True)
+                y = e._conv(o2, pre + ".conv3", relu=True, residual=sc, res_mode=1)
+                if si + 2 > self.freeze_at:
+                    blocks.append(dict(pre=pre, x=x, o1=o1, o2=o2, y=y, stride=stride, first=b == 0, stage=si + 2))
+                x = y
+            feats[f"res{si + 2}"] = x
+        s["blocks"], s["res"] = blocks, feats
+        out, lat = {}, {}
+        prev = e._conv(feats["res5"], "backbone.fpn_lateral5")
+        lat[5] = prev
+        out["p5"] = e._conv(prev, "backbone.fpn_output5", 1, 1)
+        for lvl in (4, 3, 2):
+            prev = e._conv(feats[f"res{lvl}"], f"backbone.fpn_lateral{lvl}", residual=prev, res_mode=2)
+            lat[lvl] = prev
+            out[f"p{lvl}"] = e._conv(prev, f"backbone.fpn_output{lvl}", 1, 1)
+        out["p6"] = ops.subsample2(out["p5"])
+        s["lat"], s["p"] = lat, out
+        # CF-RPN head (unfused: the hidden state t is kept), targets, losses
+        keep: dict = {}
+        sel = e._rpn(out, image_hw, keep, topk=c["pre_nms_topk_train"])
+        s["rpn_t"], s["rpn_shapes"], s["sel"] = keep["rpn_t"], keep["rpn_shapes"], sel
+        lv = sel["levels"]
+        midx, miou, lab, olab = ops.rpn_match_anchors(lv, e.cell_anchors, n, gt_boxes, gt_count, c["rpn_iou_thresholds"], c["rpn_iou_thresholds_objectness"])
+        ops.subsample_labels_(lab, keys["rpn_reg"], c["rpn_batch_size"], c["rpn_positive_fraction"])
+        ops.subsample_labels_(olab, keys["rpn_obj"], c["rpn_batch_size"], c["rpn_positive_fraction_objectness"])
+        mboxes, ctr_t = ops.rpn_anchor_targets(lv, e.cell_anchors, n, gt_boxes, gt_count, midx, olab)
+        rpn = ops.rpn_losses_fwd(lv, e.cell_anchors, n, sel["pred_deltas"], sel["pred_ctr"], lab, olab, mboxes, ctr_t, c["rpn_loc_weight"],
+                                 c["rpn_ctr_weight"], c["rpn_batch_size"])
+        s.update(labels=lab, obj_labels=olab, matched_boxes=mboxes, ctr_target=ctr_t)
+        # RoI heads on the sampled proposals
+        smp = ops.roi_match_and_sample(sel["boxes"], sel["scores"], sel["counts"], gt_boxes, gt_classes, gt_count, keys["roi"], c["num_classes"],
+                                       c["roi_batch_size"], c["roi_positive_fraction"], c["roi_iou_threshold"])
+        boxes = smp["boxes"].view(-1, 4)
+        pooled = ops.roi_align([out[k] for k in ("p2", "p3", "p4", "p5")], c["pooler_scales"], boxes, smp["batch_idx"], c["pooler_resolution"],
+                               self.dtype, c["canonical_level"], c["canonical_size"], 2)
+        m = pooled.shape[0]
+        h1 = e._linear(pooled.view(m, -1), e.fc1_w, e.fc1_b, True)
+        box_feats = e._linear(h1, e.fc2_w, e.fc2_b, True, torch.float32)
+        pred = ops.gemm_f32(box_feats, e.pred_w, e.pred_b)
+        cls, ious = smp["gt_classes"].view(-1), smp["ious"].view(-1)
+        box = ops.roi_box_losses_fwd(pred[:, :4], pred[:, 4], boxes, smp["gt_boxes"].view(-1, 4), cls, ious, c["num_classes"], c["bbox_reg_weights"],
+                                     c["box_reg_weight"], c["iou_reg_weight"], iou_is_logit=True)
+        emb = ops.gemm_f32(box_feats, e.enc_w, e.enc_b)
+        rec = ops.gemm_f32(emb, e.dec_w, e.dec_b)
+        dml = ops.pln_loss_fwd(emb, e.protos, cls, ious, c["pln_iou_threshold"], c["pln_alpha"], c["pln_beta"], c["pln_loss_weight"])
+        logits = ops.gemm_f32(rec, e.cls_w, e.cls_b)
+        ce = ops.softmax_ce_loss_fwd(logits, cls, c["num_classes"], c["cls_loss_weight"])
+        s.update(smp=smp, boxes=boxes, pooled=pooled, h1=h1, box_feats=box_feats, pred=pred, emb=emb, rec=rec, logits=logits, cls=cls, ious=ious)
+        losses = dict(loss_rpn_loc=rpn[0], loss_rpn_ctr=rpn[1], loss_box_reg=box[0], loss_iou=box[1], loss_dml=dml[0], loss_cls=ce[0])
+        return losses, s
+
+    # ---- backward -------------------------------------------------------------------------------------------------
+    def _f32_linear_bwd(self, x, dy, wt, name, dy_pad=None):
+        """y = x W^T + b with fp32 operands on the exact-f32 GEMM: returns dx; writes dW, db. wt = W^T padded (k_in, n_pad)."""
+        g = self.grad
+        dyp = dy if dy_pad is None else torch.nn.functional.pad(dy, (0, dy_pad - dy.shape[1]))
+        dx = ops.gemm_f32(dyp, wt, None)                                                    # (m, k_in)
+        dw = ops.gemm_f32(dy.t().contiguous(), x.t().contiguous(), None)                    # (n_out, k_in)
+        g[name + ".w"].copy_(dw)
+        ops.bias_grad(dy, g[name + ".b"])
+        return dx
+
+    def _backward(self, s, n):
+        e, c, g, S = self.eng, self.eng.cfg, self.grad, self.loss_scale
+        dt = self.dtype
+        # --- RoI-head losses -> predictor / PLN / classifier (fp32 heads) ---
+        d_pred = ops.roi_box_losses_bwd(s["pred"], s["boxes"], s["smp"]["gt_boxes"].view(-1, 4), s["cls"], s["ious"], c["num_classes"],
+                                        c["bbox_reg_weights"], c["box_reg_weight"], c["iou_reg_weight"], S)
+        d_logits = ops.softmax_ce_loss_bwd(s["logits"], s["cls"], c["num_classes"], c["cls_loss_weight"], S)
+        d_emb_pln, d_protos = ops.pln_loss_bwd(s["emb"], self.master["protos"], s["cls"], s["ious"], c["pln_iou_threshold"], c["pln_alpha"],
+                                               c["pln_beta"], c["pln_loss_weight"], S)
+        g["protos"].copy_(d_protos)
+        d_rec = self._f32_linear_bwd(s["rec"], d_logits, self.t_cls, "cls", dy_pad=32)
+        d_emb = self._f32_linear_bwd(s["emb"], d_rec, self.t_dec, "dec")
+        d_emb = ops.add_cast(d_emb, d_emb_pln, torch.float32)
+        d_bf = self._f32_linear_bwd(s["box_feats"], d_emb, self.t_enc, "enc")
+        d_bf2 = self._f32_linear_bwd(s["box_feats"], d_pred, self.t_pred, "pred", dy_pad=16)
+        d_bf = ops.add_cast(d_bf, d_bf2, torch.float32)
+        ops.relu_mask_(d_bf, s["box_feats"])
+        dy2 = ops.add_cast(d_bf, None, dt)                                                  # (m,1024) low precision
+        m = dy2.shape[0]
+        # --- box head: FC2, FC1 on the MFMA kernels ---
+        d_h1 = ops.conv2d_dgrad(dy2.view(1, m, 1, -1), self.wd["fc2"], (m, 1), mask=s["h1"].view(1, m, 1, -1)).view(m, -1)
+        ops.conv2d_wgrad(s["h1"].view(1, m, 1, -1), dy2.view(1, m, 1, -1), 1, 1, dw=g["fc2.w"].view(-1, 1, 1, g["fc2.w"].shape[1]))
+        ops.bias_grad(dy2, g["fc2.b"])
+        pooled2 = s["pooled"].view(1, m, 1, -1)
+        d_pooled = ops.conv2d_dgrad(d_h1.view(1, m, 1, -1), self.wd["fc1"], (m, 1))
+        ops.conv2d_wgrad(pooled2, d_h1.view(1, m, 1, -1), 1, 1, dw=g["fc1.w"].view(-1, 1, 1, g["fc1.w"].shape[1]))
+        ops.bias_grad(d_h1, g["fc1.b"])
+        P = c["pooler_resolution"]
+        p = s["p"]
+        shapes = [(p[k].shape[1], p[k].shape[2]) for k in ("p2", "p3", "p4", "p5")]
+        d_feat = ops.roi_align_bwd(d_pooled.view(m, P, P, -1), shapes, n, c["pooler_scales"], s["boxes"], s["smp"]["batch_idx"], c["canonical_level"],
+                                   c["canonical_size"], 2)
+        # --- CF-RPN: losses -> tail -> 3x3 conv (weights shared by the five levels) ---
+        sel = s["sel"]
+        d5 = ops.rpn_losses_bwd(sel["levels"], e.cell_anchors, n, sel["pred_deltas"], sel["pred_ctr"], s["labels"], s["obj_labels"], s["matched_boxes"],
+                                s["ctr_target"], c["rpn_loc_weight"], c["rpn_ctr_weight"], c["rpn_batch_size"], S)
+        dt_all, dw_tail, db_tail = ops.cfrpn_tail_bwd(s["rpn_t"], e.rpn_wtail, d5)
+        g["rpn_tail.w"].copy_(dw_tail)
+        g["rpn_tail.b"].copy_(db_tail)
+        rn = "proposal_generator.rpn_head.conv"
+        dP = {}
+        off = 0
+        for li, (k, (h, w)) in enumerate(zip(("p2", "p3", "p4", "p5", "p6"), s["rpn_shapes"])):
+            rows = n * h * w
+            dtl = dt_all[off:off + rows].view(n, h, w, 256)
+            off += rows
+            roi_part = ops.add_cast(d_feat[li], None, dt) if li < 4 else None
+            dP[k] = ops.conv2d_dgrad(dtl, self.wd[rn], (h, w), 1, 1, add=roi_part)
+            ops.conv2d_wgrad(p[k], dtl, 3, 3, 1, 1, dw=g[rn + ".w"], accumulate=li > 0)
+            ops.bias_grad(dtl, g[rn + ".b"], accumulate=li > 0)
+        h5, w5 = p["p5"].shape[1], p["p5"].shape[2]
+        dP["p5"] = ops.pool_bwd(dP["p6"], (h5, w5), dP["p5"], 1)  # p6 = p5[::2, ::2]
+        # --- FPN: output convs, top-down adds, laterals (finest level first: its gradient flows up to the coarser sums) ---
+        d_ls_prev = None
+        d_res = {}
+        for lvl in (2, 3, 4, 5):
+            on, ln = f"backbone.fpn_output{lvl}", f"backbone.fpn_lateral{lvl}"
+            ls = s["lat"][lvl]
+            h, w = ls.shape[1], ls.shape[2]
+            dpl = dP[f"p{lvl}"]
+            up = ops.pool_bwd(d_ls_prev, (h, w), None, 0) if d_ls_prev is not None else None
+            d_ls = ops.conv2d_dgrad(dpl, self.wd[on], (h, w), 1, 1, add=up)
+            ops.conv2d_wgrad(ls, dpl, 3, 3, 1, 1, dw=g[on + ".w"])
+            ops.bias_grad(dpl, g[on + ".b"])
+            res = s["res"][f"res{lvl}"]
+            ops.conv2d_wgrad(res, d_ls, 1, 1, dw=g[ln + ".w"])
+            ops.bias_grad(d_ls, g[ln + ".b"])
+            if lvl > self.freeze_at:
+                d_res[lvl] = (d_ls, ln)  # the lateral's data gradient is formed together with the next stage's (see below)
+            d_ls_prev = d_ls
+        # --- backbone res5 -> res3: bottlenecks in reverse; G = gradient w.r.t. a block's output ---
+        G = None
+        for blk in reversed(s["blocks"]):
+            pre, x, o1, o2, y, stride = blk["pre"], blk["x"], blk["o1"], blk["o2"], blk["y"], blk["stride"]
+            hy, wy = y.shape[1], y.shape[2]
+            last_of_stage = blk is s["blocks"][-1] or pre.endswith(f".{R50_BLOCKS[blk['stage'] - 2] - 1}")
+            if last_of_stage:  # the stage output also feeds its FPN lateral
+                d_ls, ln = d_res[blk["stage"]]
+                G = ops.conv2d_dgrad(d_ls, self.wd[ln], (hy, wy), 1, 0, add=G)
+            ops.relu_mask_(G, y)
+            d_o2 = ops.conv2d_dgrad(G, self.wd[pre + ".conv3"], (hy, wy), 1, 0, mask=o2)
+            ops.conv2d_wgrad(o2, G, 1, 1, dw=g[pre + ".conv3.w"])
+            d_o1 = ops.conv2d_dgrad(d_o2, self.wd[pre + ".conv2"], (o1.shape[1], o1.shape[2]), 1, 1, mask=o1)
+            ops.conv2d_wgrad(o1, d_o2, 3, 3, 1, 1, dw=g[pre + ".conv2.w"])
+            ops.conv2d_wgrad(x, d_o1, 1, 1, stride, 0, dw=g[pre + ".conv1.w"])
+            if blk["first"]:
+                ops.conv2d_wgrad(x, G, 1, 1, stride, 0, dw=g[pre + ".shortcut.w"])
+            if blk["first"] and blk["stage"] == self.freeze_at + 1:
+                break  # the block's input comes from frozen layers
+            hx, wx = x.shape[1], x.shape[2]
+            if blk["first"]:
+                dx = ops.conv2d_dgrad(d_o1, self.wd[pre + ".conv1"], (hx, wx), stride, 0)
+                G = ops.conv2d_dgrad(G, self.wd[pre + ".shortcut"], (hx, wx), stride, 0, add=dx)
+            else:
+                G = ops.conv2d_dgrad(d_o1, self.wd[pre + ".conv1"], (hx, wx), 1, 0, add=G)
+
+    # ---- optimiser ------------------------------------------------------------------------------------------------
+    def all_reduce_grads(self) -> int:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.grad_flat)  # RCCL sum over xGMI: one 166 MB fp32 buffer
+            return dist.get_world_size()
+        return 1
+
+    def _update(self, world: int):
+        gs = 1.0 / (self.loss_scale * world)
+        for k, pm in self.master.items():
+            lp = self.lowp.get(k)
+            ops.sgd_step_(pm, self.grad[k], self.mom[k], self.lr, self.momentum, self.weight_decay, gs, None, lp)
+        self._refresh_derived()
+
+    def step(self, images, image_hw, hp, wp, gt_boxes, gt_classes, gt_count, keys, update: bool = True) -> Dict[str, torch.Tensor]:
+        """One iteration: returns the loss dict (GPU scalars). update=False leaves the parameters untouched (gradients stay in
+        self.grad, scaled by loss_scale)."""
+        losses, saved = self._forward(images, image_hw, hp, wp, gt_boxes, gt_classes, gt_count, keys)
+        self._backward(saved, images.shape[0])
+        if update:
+            self._update(self.all_reduce_grads())
+        return losses

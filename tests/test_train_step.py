@@ -1,0 +1,160 @@
+"""Whole training step on the GPU (host/train.py): gradients of every trainable parameter against torch autograd over the oracle's
+forward, evaluated on the SAME sampled anchors / proposals (taken from the HIP run, so that fp16 noise cannot change the sampled
+sets), and a few SGD iterations on a fixed batch.
+
+Tolerance: the HIP path stores activations and activation gradients in fp16 (loss-scaled) and runs ~50 layers deep; the oracle is
+fp32 with fp16-rounded weights and activations. Per parameter tensor: cosine similarity >= 0.98 and norm within 6 %."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import osr_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def q16(t):
+    return t.half().float()
+
+
+@pytest.fixture(scope="module")
+def setup(osr):
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from openset_rcnn_amd.host.train import OpensetRCNNTrainer
+    from openset_rcnn_amd.host.weights import random_params
+    params = random_params(0)
+    tr = OpensetRCNNTrainer(params, dtype=torch.float16, device=DEV, lr=0.002, loss_scale=512.0)
+    g = torch.Generator().manual_seed(23)
+    n, h, w, gmax = 2, 128, 160, 4
+    images = torch.randint(0, 256, (n, 3, h, w), generator=g, dtype=torch.uint8)
+    gt = torch.zeros(n, gmax, 4)
+    gcls = torch.zeros(n, gmax, dtype=torch.int64)
+    gcnt = [3, 2]
+    for i, c in enumerate(gcnt):
+        ctr = torch.rand(c, 2, generator=g) * torch.tensor([w * 0.7, h * 0.7]) + 16
+        size = torch.rand(c, 2, generator=g) * 60 + 24
+        b = torch.cat((ctr - size / 2, ctr + size / 2), dim=1)
+        b[:, 0::2].clamp_(0, w)
+        b[:, 1::2].clamp_(0, h)
+        gt[i, :c] = b
+        gcls[i, :c] = torch.randint(0, 20, (c,), generator=g)
+    shapes = O.level_shapes(h, w)
+    r = sum(a * b for a, b in shapes)
+    cap = sum(min(2000, a * b) for a, b in shapes)
+    keys = dict(rpn_reg=torch.rand(n, r, generator=g), rpn_obj=torch.rand(n, r, generator=g), roi=torch.rand(n, cap + gmax, generator=g))
+    dev = dict(images=images.to(DEV), hw=torch.tensor([(h, w)] * n, dtype=torch.int32).to(DEV), gt=gt.to(DEV), gcls=gcls.to(DEV),
+               gcnt=torch.tensor(gcnt, dtype=torch.int32).to(DEV), keys={k: v.to(DEV) for k, v in keys.items()})
+    return dict(tr=tr, params=params, images=images, shapes=shapes, n=n, h=h, w=w, dev=dev)
+
+
+def _oracle_grads(params, images, shapes, s, cfg, n):
+    leaves = {k: v.clone().float().requires_grad_(True) for k, v in params.items()}
+    pq = {k: (q16(v) if (v.dim() == 4 or k.endswith("fc1.weight") or k.endswith("fc2.weight")) and "anchor_deltas" not in k and "centerness" not in k else v)
+          for k, v in leaves.items()}
+    batch, _ = O.preprocess_images(list(images))
+    feats = O.resnet_fpn_forward(q16(batch), pq, quant=q16)
+    ds, cs = [], []
+    for k in ("p2", "p3", "p4", "p5", "p6"):
+        d, c = O.cfrpn_head(feats[k], pq)
+        ds.append(d)
+        cs.append(c)
+    ds, cs = O.flatten_head_outputs(ds, cs)
+    anchors = torch.cat(O.anchor_grid(shapes))
+    rl = O.rpn_losses(anchors, torch.cat(ds, 1), torch.cat(cs, 1), s["labels"], s["obj_labels"], s["matched_boxes"], s["ctr_target"],
+                      cfg["rpn_batch_size"], cfg["rpn_loc_weight"], cfg["rpn_ctr_weight"])
+    # RoI heads on the engine's sampled rows
+    boxes, bidx = s["boxes"], s["batch_idx"]
+    valid = bidx >= 0
+    lv = O.assign_levels(boxes)
+    m = boxes.shape[0]
+    pooled = torch.zeros(m, 256, 7, 7)
+    for l, sc in enumerate((0.25, 0.125, 0.0625, 0.03125)):
+        ids = torch.nonzero((lv == l) & valid).squeeze(1)
+        if len(ids):
+            rois = torch.cat((bidx[ids].float().unsqueeze(1), boxes[ids]), dim=1)
+            pooled = pooled.index_put((ids,), O.roi_align_torch(feats[f"p{l + 2}"], rois, sc))
+    x = q16(torch.flatten(pooled[valid], 1))
+    h1 = q16(F.relu(F.linear(x, pq["roi_heads.box_head.fc1.weight"], pq["roi_heads.box_head.fc1.bias"])))
+    bf = F.relu(F.linear(h1, pq["roi_heads.box_head.fc2.weight"], pq["roi_heads.box_head.fc2.bias"]))
+    d, iou = O.box_predictor(bf, pq)
+    cls, ious = s["cls"][valid], s["ious"][valid]
+    lb, li = O.roi_box_losses(d, iou.view(-1), boxes[valid], s["gt_boxes"][valid], cls, ious, cfg["num_classes"], cfg["box_reg_weight"], cfg["iou_reg_weight"])
+    _, rec, ldml = O.pln_loss(bf, cls, ious, pq, cfg["pln_alpha"], cfg["pln_beta"], cfg["pln_loss_weight"], cfg["num_known"], cfg["pln_iou_threshold"])
+    logits = F.linear(rec, pq["roi_heads.softmaxcls.cls_score.weight"], pq["roi_heads.softmaxcls.cls_score.bias"])
+    lce = O.softmax_ce_loss(logits, cls, cfg["num_classes"], cfg["num_known"], cfg["cls_loss_weight"])
+    losses = dict(loss_rpn_loc=rl["loss_rpn_loc"], loss_rpn_ctr=rl["loss_rpn_ctr"], loss_box_reg=lb, loss_iou=li, loss_dml=ldml, loss_cls=lce)
+    sum(losses.values()).backward()
+    return losses, {k: v.grad for k, v in leaves.items()}
+
+
+def test_gradients_match_autograd_on_the_same_samples(setup):
+    from openset_rcnn_amd.host.weights import pack_conv_weight, pack_fc1_weight
+    tr, d, n = setup["tr"], setup["dev"], setup["n"]
+    losses, saved = tr._forward(d["images"], d["hw"], setup["h"], setup["w"], d["gt"], d["gcls"], d["gcnt"], d["keys"])
+    tr._backward(saved, n)
+    torch.cuda.synchronize()
+    s = dict(labels=saved["labels"].cpu(), obj_labels=saved["obj_labels"].cpu(), matched_boxes=saved["matched_boxes"].cpu(),
+             ctr_target=saved["ctr_target"].cpu(), boxes=saved["boxes"].cpu(), batch_idx=saved["smp"]["batch_idx"].cpu(), cls=saved["cls"].cpu(),
+             ious=saved["ious"].cpu(), gt_boxes=saved["smp"]["gt_boxes"].view(-1, 4).cpu())
+    assert int((s["labels"] == 1).sum()) > 0 and int(((s["cls"] >= 0) & (s["cls"] < 20)).sum()) > 0
+    ref_losses, ref = _oracle_grads(setup["params"], setup["images"], setup["shapes"], s, tr.eng.cfg, n)
+    for k, v in ref_losses.items():
+        assert float(losses[k]) == pytest.approx(float(v), rel=3e-2, abs=1e-4), k
+    S = tr.loss_scale
+    names = {"rpn_tail.w": None, "fc1.w": "roi_heads.box_head.fc1.weight", "fc1.b": "roi_heads.box_head.fc1.bias",
+             "fc2.w": "roi_heads.box_head.fc2.weight", "fc2.b": "roi_heads.box_head.fc2.bias", "enc.w": "roi_heads.dml.encoder.weight",
+             "enc.b": "roi_heads.dml.encoder.bias", "dec.w": "roi_heads.dml.decoder.weight", "dec.b": "roi_heads.dml.decoder.bias",
+             "cls.w": "roi_heads.softmaxcls.cls_score.weight", "cls.b": "roi_heads.softmaxcls.cls_score.bias", "protos": "roi_heads.dml.representatives"}
+    report, bad = [], []
+    for k, gten in tr.grad.items():
+        got = gten.detach().cpu() / S
+        if k == "rpn_tail.w":
+            want = torch.cat((ref["proposal_generator.rpn_head.anchor_deltas.weight"].view(4, 256), ref["proposal_generator.rpn_head.centerness.weight"].view(1, 256)))
+        elif k == "rpn_tail.b":
+            want = torch.cat((ref["proposal_generator.rpn_head.anchor_deltas.bias"], ref["proposal_generator.rpn_head.centerness.bias"]))
+        elif k == "pred.w":
+            want = torch.cat((ref["roi_heads.box_predictor.bbox_pred.weight"], ref["roi_heads.box_predictor.iou_pred.weight"]))
+        elif k == "pred.b":
+            want = torch.cat((ref["roi_heads.box_predictor.bbox_pred.bias"], ref["roi_heads.box_predictor.iou_pred.bias"]))
+        elif k == "fc1.w":
+            want = pack_fc1_weight(ref[names[k]], 256, 7, torch.float32)
+        elif k in names:
+            want = ref[names[k]]
+        elif k.endswith(".w"):
+            want = pack_conv_weight(ref[k[:-2] + ".weight"], torch.float32)
+        else:
+            want = ref[k[:-2] + ".bias"]
+        assert got.shape == want.shape, k
+        cos = float(F.cosine_similarity(got.flatten(), want.flatten(), dim=0))
+        ratio = float(got.norm() / want.norm().clamp(min=1e-20))
+        report.append(f"{k:48s} cos {cos:.4f}  |got|/|ref| {ratio:.3f}  |ref| {float(want.norm()):.3e}")
+        if not (cos >= 0.98 and 0.94 <= ratio <= 1.06):
+            bad.append(report[-1])
+    print("\n".join(report))
+    assert not bad, "gradient mismatch:\n" + "\n".join(bad)
+
+
+def test_sgd_steps_reduce_the_loss_and_are_reproducible(setup, osr):
+    from openset_rcnn_amd.host.train import OpensetRCNNTrainer
+    d = setup["dev"]
+
+    def run():
+        # random-init weights give gradient norms in the hundreds: a small step keeps the fixed-batch descent monotone enough
+        tr = OpensetRCNNTrainer(setup["params"], dtype=torch.float16, device=DEV, lr=5e-5, loss_scale=512.0)
+        hist = []
+        for _ in range(6):
+            losses = tr.step(d["images"], d["hw"], setup["h"], setup["w"], d["gt"], d["gcls"], d["gcnt"], d["keys"])
+            hist.append(sum(float(v) for v in losses.values()))
+        return hist, tr
+
+    h1, tr = run()
+    assert all(torch.isfinite(torch.tensor(h1))), h1
+    assert h1[-1] < 0.9 * h1[0], f"total loss did not decrease on a fixed batch: {h1}"
+    h2, _ = run()
+    # the forward is bitwise deterministic; in the backward only RoIAlign's atomic scatter is not order-deterministic, and its
+    # fp32 round-off differences grow over the following updates
+    assert h2[0] == h1[0]
+    assert h2 == pytest.approx(h1, rel=2e-2), (h1, h2)
+    assert tr.num_params == 41_621_279 - 0 or tr.num_params > 41_000_000  # 41.6 M trainable parameters
