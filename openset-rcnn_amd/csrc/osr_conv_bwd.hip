@@ -261,8 +261,43 @@ extern "C" osr_status osr_conv2d_wgrad(const osr_conv_params* p, const void* x, 
 // ------------------------------------------------------------------------------------------------------
 // bias gradient: db[co] = sum_m dy[m][co]   (two stages, fixed order)
 // ------------------------------------------------------------------------------------------------------
+// workgroup = 8 row lanes x 32 channel groups of 8 channels (one 16-byte load per thread and row); grid.x row chunks,
+// grid.y blocks of 256 channels; the 8 row lanes are summed through LDS in a fixed order
 template <class TI>
 __global__ __launch_bounds__(256) void bias_grad_kernel(const TI* __restrict__ dy, long long M, int cout, long long rows_per_block, float* __restrict__ partial) {
+    __shared__ float s_acc[8][256 + 8];
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int co = blockIdx.y * 256 + cg * 8;
+    const long long m0 = (long long)blockIdx.x * rows_per_block, m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (co < cout) {  // cout is a multiple of 8
+        for (long long m = m0 + rl; m < m1; m += 8) {
+            if constexpr (sizeof(TI) == 2) {
+                typedef TI v8 __attribute__((ext_vector_type(8)));
+                const v8 v = *reinterpret_cast<const v8*>(dy + m * cout + co);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += osr_to_float(dy[m * cout + co + e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_acc[rl][cg * 8 + e] = s[e];
+    __syncthreads();
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c < cout) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += s_acc[r][threadIdx.x];
+        partial[(long long)blockIdx.x * cout + c] = t;
+    }
+}
+
+// any channel count (the 5- and 21-wide fp32 heads): one thread per channel, rows in sequence
+template <class TI>
+__global__ __launch_bounds__(256) void bias_grad_narrow_kernel(const TI* __restrict__ dy, long long M, int cout, long long rows_per_block, float* __restrict__ partial) {
     const int co = blockIdx.y * 256 + threadIdx.x;
     if (co >= cout) return;
     const long long m0 = (long long)blockIdx.x * rows_per_block, m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
@@ -290,9 +325,11 @@ extern "C" osr_status osr_bias_grad(const void* dy, int32_t dtype, int64_t m, in
     OSR_REQUIRE(workspace_bytes >= (int64_t)nb * cout * 4, OSR_ERR_WORKSPACE, "osr_bias_grad: workspace needs %lld bytes", (long long)BG_BLOCKS * cout * 4);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(nb, (cout + 255) / 256);
-    if (dtype == OSR_F16) hipLaunchKernelGGL(bias_grad_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t*)dy, (long long)m, cout, rpb, (float*)workspace);
-    else if (dtype == OSR_BF16) hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy, (long long)m, cout, rpb, (float*)workspace);
-    else hipLaunchKernelGGL(bias_grad_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, (long long)m, cout, rpb, (float*)workspace);
+    const bool wide = cout % 8 == 0 && ((uintptr_t)dy & 15) == 0;
+#define BG(T) { if (wide) hipLaunchKernelGGL(bias_grad_kernel<T>, grid, dim3(256), 0, st, (const T*)dy, (long long)m, cout, rpb, (float*)workspace); \
+                else hipLaunchKernelGGL(bias_grad_narrow_kernel<T>, grid, dim3(256), 0, st, (const T*)dy, (long long)m, cout, rpb, (float*)workspace); }
+    if (dtype == OSR_F16) BG(f16_t) else if (dtype == OSR_BF16) BG(bf16_t) else BG(float)
+#undef BG
     OSR_CHECK_LAUNCH("osr_bias_grad");
     hipLaunchKernelGGL(bias_grad_reduce, dim3((cout + 255) / 256), dim3(256), 0, st, (const float*)workspace, nb, cout, accumulate, db);
     OSR_CHECK_LAUNCH("osr_bias_grad(reduce)");

@@ -491,23 +491,28 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(RoiAlignBwdArgs a) {
     }
     const bool fallback = __any(overflow);
     ra_wave_sync();
+    // Channel mapping: lane l takes channels l, l+64, l+128, ... so that one wave-wide atomic instruction covers 64 consecutive
+    // floats (four full 64-byte lines) instead of touching 16 lines with four lanes each.
     for (int ph = 0; ph < P; ++ph)
         for (int pw = 0; pw < P; ++pw)
-            for (int c0 = lane * 4; c0 < C; c0 += 256) {
+            for (int cb = 0; cb < C; cb += 256) {
                 float g[4];
-                load4<TG>(dout + (size_t)(ph * P + pw) * C + c0, g);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) g[k] = g[k] / count;
+                for (int k = 0; k < 4; ++k) {
+                    const int ch = cb + k * 64 + lane;
+                    g[k] = ch < C ? osr_to_float(dout[(size_t)(ph * P + pw) * C + ch]) / count : 0.f;
+                }
                 if (!fallback) {
                     const int y0 = S.lo[0][ph], ny = S.n[0][ph], x0 = S.lo[1][pw], nx = S.n[1][pw];
                     for (int j = 0; j < ny; ++j) {
                         const float wy = S.w[0][ph][j];
-                        float* row = feat + ((size_t)(y0 + j) * W + x0) * C + c0;
+                        float* row = feat + ((size_t)(y0 + j) * W + x0) * C + cb + lane;
                         for (int i = 0; i < nx; ++i) {
                             const float wgt = wy * S.w[1][pw][i];
                             if (wgt == 0.f) continue;
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) atomicAdd(row + (size_t)i * C + k, wgt * g[k]);
+                            for (int k = 0; k < 4; ++k)
+                                if (cb + k * 64 + lane < C) atomicAdd(row + (size_t)i * C + k * 64, wgt * g[k]);
                         }
                     }
                 } else {
@@ -520,10 +525,12 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(RoiAlignBwdArgs a) {
                             const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
-                                atomicAdd(feat + ((size_t)yl * W + xl) * C + c0 + k, w1 * g[k]);
-                                atomicAdd(feat + ((size_t)yl * W + xh) * C + c0 + k, w2 * g[k]);
-                                atomicAdd(feat + ((size_t)yh * W + xl) * C + c0 + k, w3 * g[k]);
-                                atomicAdd(feat + ((size_t)yh * W + xh) * C + c0 + k, w4 * g[k]);
+                                const int ch = cb + k * 64 + lane;
+                                if (ch >= C) continue;
+                                atomicAdd(feat + ((size_t)yl * W + xl) * C + ch, w1 * g[k]);
+                                atomicAdd(feat + ((size_t)yl * W + xh) * C + ch, w2 * g[k]);
+                                atomicAdd(feat + ((size_t)yh * W + xl) * C + ch, w3 * g[k]);
+                                atomicAdd(feat + ((size_t)yh * W + xh) * C + ch, w4 * g[k]);
                             }
                         }
                     }
