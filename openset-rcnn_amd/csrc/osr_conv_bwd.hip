@@ -306,12 +306,22 @@ __global__ __launch_bounds__(256) void bias_grad_narrow_kernel(const TI* __restr
     partial[(long long)blockIdx.x * cout + co] = s;
 }
 
+// 8 partial lanes x 32 channels per workgroup; lanes are combined through LDS in a fixed order
 __global__ __launch_bounds__(256) void bias_grad_reduce(const float* __restrict__ partial, int nblocks, int cout, int accumulate, float* __restrict__ db) {
-    const int co = blockIdx.x * 256 + threadIdx.x;
-    if (co >= cout) return;
-    float s = accumulate ? db[co] : 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partial[(long long)b * cout + co];
-    db[co] = s;
+    __shared__ float s_acc[8][33];
+    const int c = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int co = blockIdx.x * 32 + c;
+    float s = 0.f;
+    if (co < cout)
+        for (int b = rl; b < nblocks; b += 8) s += partial[(long long)b * cout + co];
+    s_acc[rl][c] = s;
+    __syncthreads();
+    if (rl == 0 && co < cout) {
+        float t = accumulate ? db[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += s_acc[r][c];
+        db[co] = t;
+    }
 }
 
 #define BG_BLOCKS 512
@@ -331,7 +341,7 @@ extern "C" osr_status osr_bias_grad(const void* dy, int32_t dtype, int64_t m, in
     if (dtype == OSR_F16) BG(f16_t) else if (dtype == OSR_BF16) BG(bf16_t) else BG(float)
 #undef BG
     OSR_CHECK_LAUNCH("osr_bias_grad");
-    hipLaunchKernelGGL(bias_grad_reduce, dim3((cout + 255) / 256), dim3(256), 0, st, (const float*)workspace, nb, cout, accumulate, db);
+    hipLaunchKernelGGL(bias_grad_reduce, dim3((cout + 31) / 32), dim3(256), 0, st, (const float*)workspace, nb, cout, accumulate, db);
     OSR_CHECK_LAUNCH("osr_bias_grad(reduce)");
     return OSR_OK;
 }

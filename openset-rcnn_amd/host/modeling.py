@@ -475,6 +475,29 @@ class GeneralizedRCNN(_EngineOwner):
             raise NotImplementedError(_TRAIN_MSG)
         return self.inference(batched_inputs)
 
+    def make_trainer(self, lr: float = 0.005, momentum: float = 0.9, weight_decay: float = 1e-4, loss_scale: float = 1024.0):
+        """The training loop body of train.py:132-148 as one object: `losses = trainer.step(...)` replaces
+        `loss_dict = model(data); losses.backward(); optimizer.step()` (there is no autograd graph on the HIP path). The trainer
+        owns fp32 master copies of this model's trainable parameters (res3+ weights un-folded from their FrozenBN, FPN, heads);
+        `load_trainer_state(trainer)` writes them back into the module for evaluation / checkpointing."""
+        from .train import OpensetRCNNTrainer
+        sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
+        bn = {}
+        for k in sd:
+            if k.endswith(".norm.weight"):
+                pre = k[: -len(".norm.weight")]
+                scale = sd[pre + ".norm.weight"] * (sd[pre + ".norm.running_var"] + 1e-5).rsqrt()
+                bn[pre] = (sd[pre + ".weight"], scale)
+        return OpensetRCNNTrainer(fold_frozen_bn(sd), self._eng_cfg, self.kernel_dtype, str(self.device), lr=lr, momentum=momentum,
+                                  weight_decay=weight_decay, loss_scale=loss_scale, frozen_bn=bn)
+
+    def load_trainer_state(self, trainer) -> None:
+        sd = dict(self.state_dict())
+        for k, v in trainer.export_state_dict().items():
+            assert k in sd and tuple(sd[k].shape) == tuple(v.shape), k
+            sd[k] = v
+        self.load_state_dict(sd)
+
     @torch.no_grad()
     def losses_forward(self, batched_inputs: List[dict], generator: Optional[torch.Generator] = None) -> Dict[str, torch.Tensor]:
         """The loss dict GeneralizedRCNN.forward returns in training mode ([d2]; train.py:189 trainer loop), forward values

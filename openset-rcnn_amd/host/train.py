@@ -18,7 +18,7 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
-from . import ops
+from . import ops, parallel
 from .engine import OpensetRCNNEngine
 from .weights import R50_BLOCKS, pack_conv_weight, pack_fc1_weight
 
@@ -30,7 +30,13 @@ def _dgrad_pack(w_lp: torch.Tensor) -> torch.Tensor:
 
 class OpensetRCNNTrainer:
     def __init__(self, params: Dict[str, torch.Tensor], cfg: Optional[dict] = None, dtype: torch.dtype = torch.float16, device: str = "cuda",
-                 lr: float = 0.005, momentum: float = 0.9, weight_decay: float = 1e-4, loss_scale: float = 1024.0, freeze_at: int = 2):
+                 lr: float = 0.005, momentum: float = 0.9, weight_decay: float = 1e-4, loss_scale: float = 1024.0, freeze_at: int = 2,
+                 frozen_bn: Optional[Dict[str, Tuple[torch.Tensor, torch.Tensor]]] = None):
+        """params: BN-folded parameters under detectron2 names (what the engine reads). frozen_bn (optional): for convs followed by
+        FrozenBatchNorm, name -> (un-folded weight (cout,cin,kh,kw), per-channel scale gamma/sqrt(var+eps)): the trainable parameter
+        is the un-folded weight (weight decay acts on it, the chain rule multiplies the kernel's gradient by the scale)."""
+        self.frozen_bn = frozen_bn or {}
+        self.row_scale: Dict[str, torch.Tensor] = {}
         self.eng = OpensetRCNNEngine(params, cfg, dtype, device)
         self.eng.fuse_rpn_head = False  # the hidden state of the head is needed by its backward
         self.dtype, self.device = dtype, self.eng.device
@@ -81,7 +87,12 @@ class OpensetRCNNTrainer:
 
     def _add_conv(self, name: str, params, bias: bool):
         e = self.eng
-        self.master[name + ".w"] = pack_conv_weight(params[name + ".weight"], torch.float32).to(e.device)
+        if name in self.frozen_bn:
+            w_unfolded, scale = self.frozen_bn[name]
+            self.master[name + ".w"] = pack_conv_weight(w_unfolded, torch.float32).to(e.device)
+            self.row_scale[name + ".w"] = scale.detach().float().contiguous().to(e.device)
+        else:
+            self.master[name + ".w"] = pack_conv_weight(params[name + ".weight"], torch.float32).to(e.device)
         self.lowp[name + ".w"] = e.w[name + ".w"]
         if bias:
             self.master[name + ".b"] = e.w[name + ".b"]
@@ -277,17 +288,14 @@ class OpensetRCNNTrainer:
 
     # ---- optimiser ------------------------------------------------------------------------------------------------
     def all_reduce_grads(self) -> int:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.grad_flat)  # RCCL sum over xGMI: one 166 MB fp32 buffer
-            return dist.get_world_size()
-        return 1
+        """Sum the flat gradient buffer over the data-parallel ranks (RCCL over xGMI); returns the world size."""
+        return parallel.all_reduce_sum_(self.grad_flat)
 
     def _update(self, world: int):
         gs = 1.0 / (self.loss_scale * world)
         for k, pm in self.master.items():
             lp = self.lowp.get(k)
-            ops.sgd_step_(pm, self.grad[k], self.mom[k], self.lr, self.momentum, self.weight_decay, gs, None, lp)
+            ops.sgd_step_(pm, self.grad[k], self.mom[k], self.lr, self.momentum, self.weight_decay, gs, self.row_scale.get(k), lp)
         self._refresh_derived()
 
     def step(self, images, image_hw, hp, wp, gt_boxes, gt_classes, gt_count, keys, update: bool = True) -> Dict[str, torch.Tensor]:
@@ -298,3 +306,31 @@ class OpensetRCNNTrainer:
         if update:
             self._update(self.all_reduce_grads())
         return losses
+
+    def export_state_dict(self) -> Dict[str, torch.Tensor]:
+        """The trainable parameters under detectron2 names and layouts (un-folded conv weights), for load_state_dict /
+        checkpointing ([d2] DetectionCheckpointer writes these keys under "model")."""
+        e = self.eng
+        out: Dict[str, torch.Tensor] = {}
+        for n in self.conv_names:
+            out[n + ".weight"] = self.master[n + ".w"].permute(0, 3, 1, 2).contiguous().cpu()
+            if n + ".b" in self.master:
+                out[n + ".bias"] = self.master[n + ".b"].cpu().clone()
+        pr = e.cfg["pooler_resolution"]
+        fc1 = self.master["fc1.w"]  # (out, ph, pw, c) flattened -> the reference's (out, c*ph*pw)
+        out["roi_heads.box_head.fc1.weight"] = fc1.view(fc1.shape[0], pr, pr, -1).permute(0, 3, 1, 2).reshape(fc1.shape[0], -1).contiguous().cpu()
+        out["roi_heads.box_head.fc1.bias"] = self.master["fc1.b"].cpu().clone()
+        out["roi_heads.box_head.fc2.weight"] = self.master["fc2.w"].cpu().clone()
+        out["roi_heads.box_head.fc2.bias"] = self.master["fc2.b"].cpu().clone()
+        t_w, t_b = self.master["rpn_tail.w"].cpu(), self.master["rpn_tail.b"].cpu()
+        out["proposal_generator.rpn_head.anchor_deltas.weight"] = t_w[:4].reshape(4, -1, 1, 1).clone()
+        out["proposal_generator.rpn_head.anchor_deltas.bias"] = t_b[:4].clone()
+        out["proposal_generator.rpn_head.centerness.weight"] = t_w[4:5].reshape(1, -1, 1, 1).clone()
+        out["proposal_generator.rpn_head.centerness.bias"] = t_b[4:5].clone()
+        p_w, p_b = self.master["pred.w"].cpu(), self.master["pred.b"].cpu()
+        out["roi_heads.box_predictor.bbox_pred.weight"], out["roi_heads.box_predictor.bbox_pred.bias"] = p_w[:4].clone(), p_b[:4].clone()
+        out["roi_heads.box_predictor.iou_pred.weight"], out["roi_heads.box_predictor.iou_pred.bias"] = p_w[4:5].clone(), p_b[4:5].clone()
+        for short, long in (("enc", "roi_heads.dml.encoder"), ("dec", "roi_heads.dml.decoder"), ("cls", "roi_heads.softmaxcls.cls_score")):
+            out[long + ".weight"], out[long + ".bias"] = self.master[short + ".w"].cpu().clone(), self.master[short + ".b"].cpu().clone()
+        out["roi_heads.dml.representatives"] = self.master["protos"].cpu().clone()
+        return out

@@ -206,3 +206,39 @@ def test_losses_forward_through_the_mirror(osr, tmp_path):
     assert set(l1) == {"loss_rpn_loc", "loss_rpn_ctr", "loss_box_reg", "loss_iou", "loss_dml", "loss_cls"}
     for k in l1:
         assert torch.isfinite(l1[k]).all() and float(l1[k]) > 0 and torch.equal(l1[k], l2[k]), k  # reproducible bit for bit
+
+
+@pytest.mark.gpu
+def test_trainer_from_the_mirror_roundtrip(osr, tmp_path):
+    """model.make_trainer(): FrozenBN-aware masters, one SGD step, parameters written back into the module."""
+    from openset_rcnn_amd.host import modeling as M
+    cfg = _cfg(osr, tmp_path)
+    model = M.build_model(cfg)
+    g = torch.Generator().manual_seed(11)
+    sd = model.state_dict()
+    for k in sd:  # non-trivial FrozenBN scales on a trained layer
+        if k.endswith("res4.1.conv2.norm.weight"):
+            sd[k] = torch.rand(sd[k].shape, generator=g) + 0.5
+    model.load_state_dict(sd)
+    tr = model.make_trainer(lr=1e-5, loss_scale=256.0)
+    before = {k: v.clone() for k, v in tr.export_state_dict().items()}
+    name = "backbone.bottom_up.res4.1.conv2"
+    assert torch.allclose(before[name + ".weight"], model.state_dict()[name + ".weight"].cpu())  # the master is the UN-folded weight
+    assert name + ".w" in tr.row_scale
+    n, h, w = 1, 128, 160
+    images = torch.randint(0, 256, (n, 3, h, w), generator=g, dtype=torch.uint8).cuda()
+    hw = torch.tensor([(h, w)], dtype=torch.int32).cuda()
+    gt = torch.tensor([[[20.0, 30.0, 90.0, 100.0], [70.0, 20.0, 150.0, 110.0]]]).cuda()
+    gcls = torch.tensor([[3, 7]]).cuda()
+    gcnt = torch.tensor([2], dtype=torch.int32).cuda()
+    shapes = [(32, 40), (16, 20), (8, 10), (4, 5), (2, 3)]
+    r = sum(a * b for a, b in shapes)
+    cap = sum(min(cfg.MODEL.RPN.PRE_NMS_TOPK_TRAIN, a * b) for a, b in shapes)
+    keys = {k: torch.rand(s, generator=g).cuda() for k, s in (("rpn_reg", (n, r)), ("rpn_obj", (n, r)), ("roi", (n, cap + 2)))}
+    losses = tr.step(images, hw, h, w, gt, gcls, gcnt, keys)
+    assert all(torch.isfinite(v).all() for v in losses.values())
+    after = tr.export_state_dict()
+    assert not torch.equal(after[name + ".weight"], before[name + ".weight"])
+    model.load_trainer_state(tr)
+    assert torch.equal(model.state_dict()[name + ".weight"].cpu(), after[name + ".weight"])
+    assert torch.equal(model.state_dict()["roi_heads.box_head.fc1.weight"].cpu(), after["roi_heads.box_head.fc1.weight"])

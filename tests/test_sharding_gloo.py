@@ -118,3 +118,34 @@ def test_two_rank_evaluation(tmp_path):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res["AP@K"] == 100.0 and res["R@K"] == 100.0 and res["AOSE"] == 0.0  # all four images counted exactly once
+
+
+def _grad_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as ge
+    ge.load_package()
+    from openset_rcnn_amd.host import parallel as P
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # the trainer's exchange step: one flat fp32 gradient buffer per rank, summed in place; the update divides by the world size
+    flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    w = P.all_reduce_sum_(flat)
+    if rank == 0:
+        q.put((w, flat))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_all_reduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    w, flat = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert w == 2 and torch.equal(flat, torch.arange(1000, dtype=torch.float32) * 3)
