@@ -61,17 +61,30 @@ struct WgradArgs {
 };
 
 #define WG_OOB 0x80000000u
-#define WG_BM 64            // rows (m) per pipeline step
-#define WG_STAGE (2 * WG_BM * 256)  // dy tile + x tile, 256-B rows
+#define WG_BM 64  // rows (m) per pipeline step
 
-template <class TI>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
+// Tile TCO (output channels) x TCI (input channels) of one tap, WM x WN waves. Per step of 64 pixel rows the dy tile
+// [64][TCO] and the x tile [64][TCI] are staged row-major (LDS-DMA pieces of 1 KiB = 512/T rows); the 16-byte chunk c of row r
+// lands in slot c ^ sw(r), sw(r) = (r & 3) | ((r >> 3) & 1) << 2: the eight rows one half-wave touches in a transposing read
+// (r = 8g + 4h + q, g in {0,1} or {2,3}) get eight different swizzles, so the reads are bank-conflict free.
+// The pieces of step s+1 are issued between the MFMAs of step s (as in the forward kernel).
+template <class TI, int TCO, int TCI, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(WgradArgs a) {
+    constexpr int NW = WM * WN;
+    constexpr int SA = TCO / WM / 16, SB = TCI / WN / 16;       // 16-wide sub-tiles per wave
+    constexpr int YB = TCO * 2, XB = TCI * 2;                   // bytes per staged row
+    constexpr int STAGE = WG_BM * (YB + XB);
+    constexpr int YP = WG_BM * YB / 1024, XP = WG_BM * XB / 1024;  // pieces per step
+    constexpr int PPW = (YP + XP) / NW;                         // pieces per wave and step
+    static_assert((YP + XP) % NW == 0 && YP % NW == 0, "pieces must divide over the waves, dy pieces first");
+    constexpr int YPW = YP / NW, XPW = XP / NW;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // 2 stages
     typedef typename FragW<TI>::type frag_t;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
     const osr_conv_params& p = a.p;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 1, wc = wid & 1;  // wave's 64 output channels / 64 input channels inside the 128 x 128 tile
+    const int wr = wid / WN, wc = wid % WN;
 
     // tile decode: consecutive workgroups share the M chunk (same dy / x rows in L2), then the dy columns
     const int ntiles = a.tiles_co * a.tiles_ci * a.taps;
@@ -81,33 +94,37 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     const int tap = t % a.taps;
     const int tile_co = t / a.taps;
     const int kh = tap / p.kw, kw = tap - kh * p.kw;
-    const int co0 = tile_co * 128, ci0 = tile_ci * 128;
+    const int co0 = tile_co * TCO, ci0 = tile_ci * TCI;
     const long long m_begin = (long long)split * a.rows_per_split;
     const long long m_end = m_begin + a.rows_per_split < a.M ? m_begin + a.rows_per_split : a.M;
     const int nsteps = (int)((m_end - m_begin + WG_BM - 1) / WG_BM);
 
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, a.dy_bytes, 0x00020000);
-
-    // staging: a 1-KiB piece = 4 rows x 16 chunks; this lane serves row (piece*4 + lane/16), LDS slot lane%16 and fetches the
-    // logical chunk slot ^ (row & 7). Per step 16 pieces per operand, 4 per wave and operand.
-    const int prow = lane >> 4, slot = lane & 15;
     const bool plain = p.kh == 1 && p.kw == 1 && p.stride_h == 1 && p.stride_w == 1 && p.pad_h == 0 && p.pad_w == 0 &&
                        p.in_stride_h == (long long)p.wi * p.in_stride_w && p.in_stride_n == (long long)p.hi * p.in_stride_h;  // x rows are linear in m
-#define WG_ISSUE(stage, step)                                                                                                   \
+
+    // one staging piece: q < YPW -> dy rows, else x rows (gathered through the conv geometry)
+#define WG_SW(r) (((r) & 3) | ((((r) >> 3) & 1) << 2))
+#define WG_PIECE(stage, step, q)                                                                                                \
     {                                                                                                                           \
-        unsigned char* sy_ = lds + (stage) * WG_STAGE;                                                                          \
-        unsigned char* sx_ = sy_ + WG_BM * 256;                                                                                 \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                         \
-            const int row_ = (wid * 4 + j) * 4 + prow;                                                                          \
+        unsigned char* sy_ = lds + (stage) * STAGE;                                                                             \
+        if ((q) < YPW) {                                                                                                        \
+            constexpr int CPR = YB / 16, RPP = 1024 / YB; /* chunks per row, rows per piece */                                  \
+            const int pc_ = wid * YPW + ((q) < YPW ? (q) : 0);                                                                  \
+            const int row_ = pc_ * RPP + lane / CPR;                                                                            \
             const long long m_ = m_begin + (long long)(step) * WG_BM + row_;                                                    \
-            const int chunk_ = slot ^ (row_ & 7);                                                                               \
-            const bool mok_ = m_ < m_end;                                                                                       \
-            const long long yo_ = (m_ * p.cout + co0 + chunk_ * 8) * 2;                                                         \
-            const unsigned yoff_ = (mok_ && co0 + chunk_ * 8 < p.cout) ? (unsigned)yo_ : WG_OOB;                                \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_t*)(sy_ + (wid * 4 + j) * 1024), 16, yoff_, 0, 0, 0);       \
+            const int chunk_ = (lane % CPR) ^ WG_SW(row_);                                                                      \
+            const unsigned yoff_ = (m_ < m_end && co0 + chunk_ * 8 < p.cout) ? (unsigned)((m_ * p.cout + co0 + chunk_ * 8) * 2) : WG_OOB; \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_t*)(sy_ + pc_ * 1024), 16, yoff_, 0, 0, 0);                  \
+        } else {                                                                                                                \
+            constexpr int CPR = XB / 16, RPP = 1024 / XB;                                                                       \
+            const int pc_ = wid * XPW + ((q) >= YPW ? (q) - YPW : 0);                                                           \
+            const int row_ = pc_ * RPP + lane / CPR;                                                                            \
+            const long long m_ = m_begin + (long long)(step) * WG_BM + row_;                                                    \
+            const int chunk_ = (lane % CPR) ^ WG_SW(row_);                                                                      \
             unsigned xoff_ = WG_OOB;                                                                                            \
-            if (mok_ && ci0 + chunk_ * 8 < p.cin) {                                                                             \
+            if (m_ < m_end && ci0 + chunk_ * 8 < p.cin) {                                                                       \
                 if (plain) {                                                                                                    \
                     xoff_ = (unsigned)((m_ * p.in_stride_w + ci0 + chunk_ * 8) * 2);                                             \
                 } else {                                                                                                        \
@@ -119,66 +136,83 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
                         xoff_ = (unsigned)(((long long)ni_ * p.in_stride_n + (long long)ih_ * p.in_stride_h + (long long)iw_ * p.in_stride_w + ci0 + chunk_ * 8) * 2); \
                 }                                                                                                               \
             }                                                                                                                   \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(sx_ + (wid * 4 + j) * 1024), 16, xoff_, 0, 0, 0);       \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(sy_ + WG_BM * YB + pc_ * 1024), 16, xoff_, 0, 0, 0);    \
         }                                                                                                                       \
     }
 
-    f32x4 acc[4][4];  // [co sub-tile][ci sub-tile]: rows = output channels, columns = input channels
+    f32x4 acc[SA][SB];  // [co sub-tile][ci sub-tile]: rows = output channels, columns = input channels
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < SA; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < SB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // transposing fragment read: lane (g, q, pp) of a 16-lane group supplies the address of row 8g+4h+q, 4 elements at
-    // column 16*sub + 4*pp of the wave's 64 channels; it receives column (lane & 15) of the four rows.
-    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    if (nsteps > 0) WG_ISSUE(0, 0);
+    // column 16*sub + 4*pp of the wave's channels; it receives column (lane & 15) of the four rows.
+    const int g = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
+    constexpr int NMF = 2 * SA * SB, PSTEP = (NMF / 2) / PPW > 0 ? (NMF / 2) / PPW : 1;  // pieces go out during the first half of a step
+    if (nsteps > 0) {
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) WG_PIECE(0, 0, q);
+    }
     for (int s = 0; s < nsteps; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (s + 1 < nsteps) WG_ISSUE((s + 1) & 1, s + 1);
-        const unsigned char* sy = lds + (s & 1) * WG_STAGE;
-        const unsigned char* sx = sy + WG_BM * 256;
+        const bool more = s + 1 < nsteps;
+        const unsigned char* sy = lds + (s & 1) * STAGE;
+        const unsigned char* sx = sy + WG_BM * YB;
+        const int nst = (s + 1) & 1;
 #pragma unroll
         for (int kk = 0; kk < WG_BM / 32; ++kk) {
-            typedef short s16x8 __attribute__((ext_vector_type(8)));
-            s16x4 va[2][4], vb[2][4];
+            s16x4 va[2][SA], vb[2][SB];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int row = kk * 32 + g * 8 + h * 4 + q;
-                const int sw = row & 7;
+                const int row = kk * 32 + g * 8 + h * 4 + q4;
+                const int sw = WG_SW(row);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int chunk_a = (wr * 8 + i * 2 + (pp >> 1)) ^ sw;
-                    const int chunk_b = (wc * 8 + i * 2 + (pp >> 1)) ^ sw;
-                    va[h][i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(sy + row * 256 + chunk_a * 16 + (pp & 1) * 8));
-                    vb[h][i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(sx + row * 256 + chunk_b * 16 + (pp & 1) * 8));
+                for (int i = 0; i < SA; ++i) {
+                    const int chunk = ((wr * SA + i) * 2 + (pp >> 1)) ^ sw;
+                    va[h][i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(sy + row * YB + chunk * 16 + (pp & 1) * 8));
+                }
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    const int chunk = ((wc * SB + j) * 2 + (pp >> 1)) ^ sw;
+                    vb[h][j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(sx + row * XB + chunk * 16 + (pp & 1) * 8));
                 }
             }
-            frag_t fa[4], fb[4];
+            frag_t fa[SA], fb[SB];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < SA; ++i) {
                 const s16x8 ta = {va[0][i][0], va[0][i][1], va[0][i][2], va[0][i][3], va[1][i][0], va[1][i][1], va[1][i][2], va[1][i][3]};
-                const s16x8 tb = {vb[0][i][0], vb[0][i][1], vb[0][i][2], vb[0][i][3], vb[1][i][0], vb[1][i][1], vb[1][i][2], vb[1][i][3]};
                 fa[i] = __builtin_bit_cast(frag_t, ta);
-                fb[i] = __builtin_bit_cast(frag_t, tb);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < SB; ++j) {
+                const s16x8 tb = {vb[0][j][0], vb[0][j][1], vb[0][j][2], vb[0][j][3], vb[1][j][0], vb[1][j][1], vb[1][j][2], vb[1][j][3]};
+                fb[j] = __builtin_bit_cast(frag_t, tb);
+            }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = FragW<TI>::mfma(fa[i], fb[j], acc[i][j]);
+            for (int i = 0; i < SA; ++i)
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    acc[i][j] = FragW<TI>::mfma(fa[i], fb[j], acc[i][j]);
+                    const int done = (kk * SA + i) * SB + j + 1;
+                    if (done % PSTEP == 0 && done / PSTEP <= PPW) {
+                        if (more) WG_PIECE(nst, s + 1, done / PSTEP - 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
         }
     }
     // partial[split][co][tap][ci]: C/D layout col = lane&15 (ci), row = (lane>>4)*4 + r (co)
     float* out = a.partial + (long long)split * p.cout * a.taps * p.cin;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < SA; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ci = ci0 + wc * 64 + j * 16 + (lane & 15);
+        for (int j = 0; j < SB; ++j) {
+            const int ci = ci0 + (wc * SB + j) * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = co0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
+                const int co = co0 + (wr * SA + i) * 16 + (lane >> 4) * 4 + r;
                 if (co < p.cout && ci < p.cin) out[((long long)co * a.taps + tap) * p.cin + ci] = acc[i][j][r];
             }
         }
@@ -190,6 +224,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 >= n) return;
     float4 s = accumulate ? *reinterpret_cast<const float4*>(dw + i4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
     for (int k = 0; k < splits; ++k) {
         const float4 v = *reinterpret_cast<const float4*>(partial + (long long)k * n + i4);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
@@ -197,10 +232,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     *reinterpret_cast<float4*>(dw + i4) = s;
 }
 
+static bool wgrad_big(const osr_conv_params* p) { return p->cout % 256 == 0 && p->cin % 256 == 0; }
+
 static int wgrad_splits(const osr_conv_params* p) {
     const long long M = (long long)p->n * p->ho * p->wo;
-    const long long ntiles = (long long)((p->cout + 127) / 128) * ((p->cin + 127) / 128) * p->kh * p->kw;
-    long long splits = (1024 + ntiles - 1) / ntiles;  // enough workgroups for 256 CUs x 2 x 2
+    const int tt = wgrad_big(p) ? 256 : 128;
+    const long long ntiles = (long long)((p->cout + tt - 1) / tt) * ((p->cin + tt - 1) / tt) * p->kh * p->kw;
+    const long long target = wgrad_big(p) ? 512 : 1024;  // workgroups wanted: 256 CUs x 2 (x 2 for the 4-wave tiles)
+    long long splits = (target + ntiles - 1) / ntiles;
     const long long max_splits = (M + 255) / 256;     // at least 256 rows per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -241,7 +280,9 @@ extern "C" osr_status osr_conv2d_wgrad(const osr_conv_params* p, const void* x, 
     a.splits = wgrad_splits(p);
     a.rows_per_split = ((a.M + a.splits - 1) / a.splits + WG_BM - 1) / WG_BM * WG_BM;
     a.splits = (int)((a.M + a.rows_per_split - 1) / a.rows_per_split);
-    a.tiles_co = (p->cout + 127) / 128; a.tiles_ci = (p->cin + 127) / 128; a.taps = p->kh * p->kw;
+    const bool big = wgrad_big(p);
+    const int tt = big ? 256 : 128;
+    a.tiles_co = (p->cout + tt - 1) / tt; a.tiles_ci = (p->cin + tt - 1) / tt; a.taps = p->kh * p->kw;
     a.div_howo = wdiv_make((unsigned)(p->ho * p->wo));
     a.div_wo = wdiv_make((unsigned)p->wo);
     const long long wn = (long long)p->cout * a.taps * p->cin;
@@ -250,8 +291,21 @@ extern "C" osr_status osr_conv2d_wgrad(const osr_conv_params* p, const void* x, 
     const long long grid = (long long)a.tiles_co * a.tiles_ci * a.taps * a.splits;
     OSR_REQUIRE(grid < (1ll << 31), OSR_ERR_UNSUPPORTED, "osr_conv2d_wgrad: grid too large");
     hipStream_t st = (hipStream_t)stream;
-    if (p->in_dtype == OSR_F16) hipLaunchKernelGGL(conv_wgrad_kernel<f16_t>, dim3((unsigned)grid), dim3(256), 2 * WG_STAGE, st, a);
-    else hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 2 * WG_STAGE, st, a);
+    if (big) {
+        const size_t ldsb = 2 * WG_BM * (256 + 256) * 2;  // 128 KiB
+        static thread_local bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<f16_t, 256, 256, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<bf16_t, 256, 256, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr = true;
+        }
+        if (p->in_dtype == OSR_F16) hipLaunchKernelGGL((conv_wgrad_kernel<f16_t, 256, 256, 2, 4>), dim3((unsigned)grid), dim3(512), ldsb, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 256, 256, 2, 4>), dim3((unsigned)grid), dim3(512), ldsb, st, a);
+    } else {
+        const size_t ldsb = 2 * WG_BM * (128 + 128) * 2;  // 64 KiB
+        if (p->in_dtype == OSR_F16) hipLaunchKernelGGL((conv_wgrad_kernel<f16_t, 128, 128, 2, 2>), dim3((unsigned)grid), dim3(256), ldsb, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 128, 128, 2, 2>), dim3((unsigned)grid), dim3(256), ldsb, st, a);
+    }
     OSR_CHECK_LAUNCH("osr_conv2d_wgrad");
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((wn / 4 + 255) / 256)), dim3(256), 0, st, (const float*)workspace, wn, a.splits, accumulate, dw);
     OSR_CHECK_LAUNCH("osr_conv2d_wgrad(reduce)");
