@@ -64,6 +64,15 @@ class OpensetRCNNEngine:
         self.has_roi = "roi_heads.box_head.fc1.weight" in params
         self.w = w
         self.class_map = None if class_map is None else class_map.to(torch.int64).to(dev)
+        # training-side id_map of the GraspNet configuration (prototype_learning_network.py:80-95, softmax_classifier.py:214-229):
+        # dataset class id -> index in the sorted known list, background (NUM_CLASSES) -> NUM_KNOWN, anything else -> -1
+        self.id_map = None
+        if class_map is not None:
+            nc = self.cfg["num_classes"]
+            idm = torch.full((nc + 2,), -1, dtype=torch.int64)
+            idm[class_map.to(torch.int64)] = torch.arange(len(class_map))
+            idm[nc] = self.cfg["num_known"]
+            self.id_map = idm.to(dev)  # the extra last slot (-1) is where padding rows (class -1) index
         self._lv_cache = {}
         self._streams = []
         self.profile = None  # set to a list to collect (name, algorithmic flops, start event, end event) per MFMA launch
@@ -304,6 +313,13 @@ class OpensetRCNNEngine:
             out = self.forward_device_streams(images, image_hw, hp, wp, nstreams)
         return graph, out
 
+    def known_class_targets(self, cls: torch.Tensor):
+        """Classes as the PLN / classifier losses see them: (classes, background id). VOC-COCO: unchanged, background =
+        NUM_CLASSES. GraspNet: id_map[cls] (index in the sorted known list, background -> NUM_KNOWN, others and padding -> -1)."""
+        if self.id_map is None:
+            return cls, self.cfg["num_classes"]
+        return self.id_map[cls].contiguous(), self.cfg["num_known"]  # a gather: cls == -1 reads the last slot (-1)
+
     # ---- training step, forward half ----------------------------------------------------------------------
     def forward_losses(self, images: torch.Tensor, image_hw: torch.Tensor, hp: int, wp: int, gt_boxes: torch.Tensor,
                        gt_classes: torch.Tensor, gt_count: torch.Tensor, keys: Dict[str, torch.Tensor], keep: Optional[dict] = None):
@@ -340,11 +356,12 @@ class OpensetRCNNEngine:
         cls, ious = smp["gt_classes"].view(-1), smp["ious"].view(-1)
         box = ops.roi_box_losses_fwd(pred[:, :4], pred[:, 4], boxes, smp["gt_boxes"].view(-1, 4), cls, ious, c["num_classes"],
                                      c["bbox_reg_weights"], c["box_reg_weight"], c["iou_reg_weight"], iou_is_logit=True)
+        cls_k, nck = self.known_class_targets(cls)
         emb = ops.gemm_f32(box_feats, self.enc_w, self.enc_b)
         rec = ops.gemm_f32(emb, self.dec_w, self.dec_b)
-        dml = ops.pln_loss_fwd(emb, self.protos, cls, ious, c["pln_iou_threshold"], c["pln_alpha"], c["pln_beta"], c["pln_loss_weight"])
+        dml = ops.pln_loss_fwd(emb, self.protos, cls_k, ious, c["pln_iou_threshold"], c["pln_alpha"], c["pln_beta"], c["pln_loss_weight"])
         logits = ops.gemm_f32(rec, self.cls_w, self.cls_b)
-        ce = ops.softmax_ce_loss_fwd(logits, cls, c["num_classes"], c["cls_loss_weight"])
+        ce = ops.softmax_ce_loss_fwd(logits, cls_k, nck, c["cls_loss_weight"])
         if keep is not None:
             keep.update(labels=lab, obj_labels=olab, matched_boxes=mboxes, ctr_target=ctr_t, sampled=smp, pooled=pooled, box_feats=box_feats,
                         pred=pred, emb=emb, rec=rec, logits=logits)

@@ -31,13 +31,13 @@ def _dgrad_pack(w_lp: torch.Tensor) -> torch.Tensor:
 class OpensetRCNNTrainer:
     def __init__(self, params: Dict[str, torch.Tensor], cfg: Optional[dict] = None, dtype: torch.dtype = torch.float16, device: str = "cuda",
                  lr: float = 0.005, momentum: float = 0.9, weight_decay: float = 1e-4, loss_scale: float = 1024.0, freeze_at: int = 2,
-                 frozen_bn: Optional[Dict[str, Tuple[torch.Tensor, torch.Tensor]]] = None):
+                 frozen_bn: Optional[Dict[str, Tuple[torch.Tensor, torch.Tensor]]] = None, class_map: Optional[torch.Tensor] = None):
         """params: BN-folded parameters under detectron2 names (what the engine reads). frozen_bn (optional): for convs followed by
         FrozenBatchNorm, name -> (un-folded weight (cout,cin,kh,kw), per-channel scale gamma/sqrt(var+eps)): the trainable parameter
         is the un-folded weight (weight decay acts on it, the chain rule multiplies the kernel's gradient by the scale)."""
         self.frozen_bn = frozen_bn or {}
         self.row_scale: Dict[str, torch.Tensor] = {}
-        self.eng = OpensetRCNNEngine(params, cfg, dtype, device)
+        self.eng = OpensetRCNNEngine(params, cfg, dtype, device, class_map)
         self.eng.fuse_rpn_head = False  # the hidden state of the head is needed by its backward
         self.dtype, self.device = dtype, self.eng.device
         self.lr, self.momentum, self.weight_decay, self.loss_scale = lr, momentum, weight_decay, loss_scale
@@ -172,10 +172,12 @@ class OpensetRCNNTrainer:
                                      c["box_reg_weight"], c["iou_reg_weight"], iou_is_logit=True)
         emb = ops.gemm_f32(box_feats, e.enc_w, e.enc_b)
         rec = ops.gemm_f32(emb, e.dec_w, e.dec_b)
-        dml = ops.pln_loss_fwd(emb, e.protos, cls, ious, c["pln_iou_threshold"], c["pln_alpha"], c["pln_beta"], c["pln_loss_weight"])
+        cls_k, nck = e.known_class_targets(cls)
+        dml = ops.pln_loss_fwd(emb, e.protos, cls_k, ious, c["pln_iou_threshold"], c["pln_alpha"], c["pln_beta"], c["pln_loss_weight"])
         logits = ops.gemm_f32(rec, e.cls_w, e.cls_b)
-        ce = ops.softmax_ce_loss_fwd(logits, cls, c["num_classes"], c["cls_loss_weight"])
-        s.update(smp=smp, boxes=boxes, pooled=pooled, h1=h1, box_feats=box_feats, pred=pred, emb=emb, rec=rec, logits=logits, cls=cls, ious=ious)
+        ce = ops.softmax_ce_loss_fwd(logits, cls_k, nck, c["cls_loss_weight"])
+        s.update(smp=smp, boxes=boxes, pooled=pooled, h1=h1, box_feats=box_feats, pred=pred, emb=emb, rec=rec, logits=logits, cls=cls, ious=ious,
+                 cls_k=cls_k, nck=nck)
         losses = dict(loss_rpn_loc=rpn[0], loss_rpn_ctr=rpn[1], loss_box_reg=box[0], loss_iou=box[1], loss_dml=dml[0], loss_cls=ce[0])
         return losses, s
 
@@ -196,8 +198,8 @@ class OpensetRCNNTrainer:
         # --- RoI-head losses -> predictor / PLN / classifier (fp32 heads) ---
         d_pred = ops.roi_box_losses_bwd(s["pred"], s["boxes"], s["smp"]["gt_boxes"].view(-1, 4), s["cls"], s["ious"], c["num_classes"],
                                         c["bbox_reg_weights"], c["box_reg_weight"], c["iou_reg_weight"], S)
-        d_logits = ops.softmax_ce_loss_bwd(s["logits"], s["cls"], c["num_classes"], c["cls_loss_weight"], S)
-        d_emb_pln, d_protos = ops.pln_loss_bwd(s["emb"], self.master["protos"], s["cls"], s["ious"], c["pln_iou_threshold"], c["pln_alpha"],
+        d_logits = ops.softmax_ce_loss_bwd(s["logits"], s["cls_k"], s["nck"], c["cls_loss_weight"], S)
+        d_emb_pln, d_protos = ops.pln_loss_bwd(s["emb"], self.master["protos"], s["cls_k"], s["ious"], c["pln_iou_threshold"], c["pln_alpha"],
                                                c["pln_beta"], c["pln_loss_weight"], S)
         g["protos"].copy_(d_protos)
         d_rec = self._f32_linear_bwd(s["rec"], d_logits, self.t_cls, "cls", dy_pad=32)

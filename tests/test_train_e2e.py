@@ -134,3 +134,40 @@ def test_roi_sampling_and_losses(run):
     assert float(out["loss_cls"]) == pytest.approx(float(ce), rel=1e-5)
     for k in ("loss_rpn_loc", "loss_rpn_ctr", "loss_box_reg", "loss_iou", "loss_dml", "loss_cls"):
         assert torch.isfinite(out[k]).all() and float(out[k]) > 0.0
+
+
+def test_graspnet_id_map_losses(osr):
+    """GraspNet configuration: known classes are a sorted subset of the dataset ids (class_map); PLN / classifier losses see
+    id_map[gt_classes] (prototype_learning_network.py:146-147, softmax_classifier.py:224-229)."""
+    from openset_rcnn_amd.host.engine import OpensetRCNNEngine
+    from openset_rcnn_amd.host.weights import random_params
+    K, NC = 28, 88
+    g = torch.Generator().manual_seed(5)
+    class_map = torch.sort(torch.randperm(NC, generator=g)[:K])[0]
+    params = random_params(0, num_known=K)
+    eng = OpensetRCNNEngine(params, dict(num_classes=NC, num_known=K, unknown_id=1000, unk_thr=0.09), dtype=torch.float16, device=DEV, class_map=class_map)
+    n, h, w, gmax = 1, 128, 160, 3
+    images = torch.randint(0, 256, (n, 3, h, w), generator=g, dtype=torch.uint8)
+    gt = torch.tensor([[[10.0, 20.0, 90.0, 100.0], [60.0, 30.0, 150.0, 120.0], [30.0, 60.0, 70.0, 110.0]]])
+    gcls = class_map[torch.tensor([[0, 13, 27]])]
+    shapes = O.level_shapes(h, w)
+    r = sum(a * b for a, b in shapes)
+    cap = sum(min(2000, a * b) for a, b in shapes)
+    keys = dict(rpn_reg=torch.rand(n, r, generator=g), rpn_obj=torch.rand(n, r, generator=g), roi=torch.rand(n, cap + gmax, generator=g))
+    keep = {}
+    out = eng.forward_losses(images.to(DEV), torch.tensor([(h, w)], dtype=torch.int32).to(DEV), h, w, gt.to(DEV), gcls.to(DEV),
+                             torch.tensor([3], dtype=torch.int32).to(DEV), {k: v.to(DEV) for k, v in keys.items()}, keep=keep)
+    smp = keep["sampled"]
+    m = int(smp["counts"][0, 0])
+    cls, ious = smp["gt_classes"].view(-1).cpu()[:m], smp["ious"].view(-1).cpu()[:m]
+    assert int(((cls != NC)).sum()) > 0
+    idm = torch.full((NC + 1,), -1, dtype=torch.int64)
+    idm[class_map] = torch.arange(K)
+    idm[NC] = K
+    bf = keep["box_feats"].cpu()[:m]
+    c = eng.cfg
+    _, rec, dml = O.pln_loss(bf, idm[cls], ious, params, c["pln_alpha"], c["pln_beta"], c["pln_loss_weight"], K, c["pln_iou_threshold"])
+    assert float(out["loss_dml"]) == pytest.approx(float(dml), rel=1e-4)
+    logits = keep["logits"].cpu()[:m]
+    ce = O.softmax_ce_loss(logits, idm[cls], K, K, c["cls_loss_weight"])  # after the remap the background id is K
+    assert float(out["loss_cls"]) == pytest.approx(float(ce), rel=1e-5)
