@@ -236,6 +236,13 @@ osr_status osr_assemble_detections(const float* k_boxes, const float* k_scores, 
                                    int64_t unknown_id, const int64_t* class_map, float* out_boxes, float* out_scores,
                                    int64_t* out_classes, int32_t* out_count, void* stream);
 
+/* [d2] detector_postprocess on the device (the step after the path): per image, boxes * (scale_x, scale_y),
+ * clip to (out_h, out_w), drop boxes without positive width and height, keep the order. In/out: padded (n, cap, .) + counts;
+ * scale_xy (n,2) = {out_w / w, out_h / h}; out_hw (n,2) = {out_h, out_w}. Not in place. */
+osr_status osr_detector_postprocess(const float* boxes, const float* scores, const int64_t* classes, const int32_t* count,
+                                    int32_t n, int32_t cap, const float* scale_xy, const int32_t* out_hw, float* out_boxes,
+                                    float* out_scores, int64_t* out_classes, int32_t* out_count, void* stream);
+
 /* =========================================================================================================
  * Training step, forward half: targets and losses. Gradients are not
  * produced by this library yet; every function below is a forward kernel whose outputs equal the reference's

@@ -559,6 +559,8 @@ static int one_stage_max_nk() { static const int v = env_int("OSR_CONV_1STAGE_MA
 static int big_tile_min_nk() { static const int v = env_int("OSR_CONV_BIG_MIN_NK", 8); return v; }
 static int big_tile_min_tiles() { static const int v = env_int("OSR_CONV_BIG_MIN_TILES", 768); return v; }
 static int small_grid_blocks() { static const int v = env_int("OSR_CONV_SMALL_GRID", 768); return v; }
+static int wide_any_min_nk() { static const int v = env_int("OSR_CONV_WIDE_ANY_MIN_NK", 0); return v; }
+static int wide_any_max_nk() { static const int v = env_int("OSR_CONV_WIDE_ANY_MAX_NK", 1000); return v; }
 static int wide_n_min_m() { static const int v = env_int("OSR_CONV_WIDE_MIN_M", 200000); return v; }
 
 template <class K>
@@ -598,7 +600,8 @@ static osr_status conv64_launch(Conv64Args& a, hipStream_t st) {
         else
             hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 128, 64, 4, 1, 0, 0>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(256),
                                conv64_lds_bytes(128, 64, 0), st, a);
-    } else if (a.p.cout == 256 && a.p.res_mode == 0 && nk >= 8 && !a.two_stage && a.M >= wide_n_min_m()) {
+    } else if ((a.p.cout == 256 && a.p.res_mode == 0 && nk >= 8 && !a.two_stage && a.M >= wide_n_min_m()) ||
+               (wide_any_min_nk() > 0 && a.p.cout % 256 == 0 && !a.two_stage && nk >= wide_any_min_nk() && nk <= wide_any_max_nk())) {
         // 128 x 256 tiles for the big 256-channel layers (FPN output convs): the gathered activation rows are fetched once
         a.tiles_n = a.p.cout / 256;
         static thread_local bool attr = false;

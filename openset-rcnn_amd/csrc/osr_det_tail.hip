@@ -545,3 +545,60 @@ extern "C" osr_status osr_assemble_detections(const float* k_boxes, const float*
     OSR_CHECK_LAUNCH("osr_assemble_detections");
     return OSR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// [d2] detector_postprocess: rescale to the requested output resolution, clip, drop empty boxes (order kept)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                          const long long* __restrict__ classes, const int* __restrict__ count, int cap,
+                                                          const float* __restrict__ scale_xy, const int* __restrict__ out_hw, float* __restrict__ o_boxes,
+                                                          float* __restrict__ o_scores, long long* __restrict__ o_classes, int* __restrict__ o_count) {
+    __shared__ int s_scan[32];
+    const int img = blockIdx.x;
+    const int n = min(count[img], cap);
+    const float sx = scale_xy[img * 2], sy = scale_xy[img * 2 + 1];
+    const float W = (float)out_hw[img * 2 + 1], H = (float)out_hw[img * 2];
+    int base = 0;
+    for (int i0 = 0; i0 < cap; i0 += blockDim.x) {
+        const int i = i0 + threadIdx.x;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool keep = false;
+        if (i < n) {
+            b = *reinterpret_cast<const float4*>(boxes + ((long long)img * cap + i) * 4);
+            // Boxes.scale then Boxes.clip: x in [0, W], y in [0, H]; nonempty: w > 0 and h > 0
+            b.x = fminf(fmaxf(b.x * sx, 0.f), W); b.z = fminf(fmaxf(b.z * sx, 0.f), W);
+            b.y = fminf(fmaxf(b.y * sy, 0.f), H); b.w = fminf(fmaxf(b.w * sy, 0.f), H);
+            keep = (b.z - b.x) > 0.f && (b.w - b.y) > 0.f;
+        }
+        int tot;
+        const int pos = base + osr_block_excl_scan(keep ? 1 : 0, s_scan, &tot);
+        if (keep) {
+            const long long o = (long long)img * cap + pos, q = (long long)img * cap + i;
+            *reinterpret_cast<float4*>(o_boxes + o * 4) = b;
+            o_scores[o] = scores[q];
+            o_classes[o] = classes[q];
+        }
+        base += tot;
+        __syncthreads();
+    }
+    for (int i = base + threadIdx.x; i < cap; i += blockDim.x) {
+        const long long o = (long long)img * cap + i;
+        *reinterpret_cast<float4*>(o_boxes + o * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        o_scores[o] = 0.f;
+        o_classes[o] = -1;
+    }
+    if (threadIdx.x == 0) o_count[img] = base;
+}
+
+extern "C" osr_status osr_detector_postprocess(const float* boxes, const float* scores, const int64_t* classes, const int32_t* count, int32_t n,
+                                               int32_t cap, const float* scale_xy, const int32_t* out_hw, float* out_boxes, float* out_scores,
+                                               int64_t* out_classes, int32_t* out_count, void* stream) {
+    OSR_REQUIRE(boxes && scores && classes && count && scale_xy && out_hw && out_boxes && out_scores && out_classes && out_count, OSR_ERR_INVALID_ARG,
+                "osr_detector_postprocess: null pointer");
+    OSR_REQUIRE(n >= 1 && cap >= 1, OSR_ERR_INVALID_ARG, "osr_detector_postprocess: bad n / cap");
+    OSR_REQUIRE(boxes != out_boxes, OSR_ERR_INVALID_ARG, "osr_detector_postprocess: in-place operation is not supported");
+    hipLaunchKernelGGL(postprocess_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, boxes, scores, (const long long*)classes, count, cap, scale_xy, out_hw,
+                       out_boxes, out_scores, (long long*)out_classes, out_count);
+    OSR_CHECK_LAUNCH("osr_detector_postprocess");
+    return OSR_OK;
+}

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "osr_pln_tail": (I32, [P, I64, I32, P, I32, I32, F32, I64, P, P, I32, P, P, P]),
     "osr_softmax_candidates": (I32, [P, I32, P, P, P, P, I32, I32, I64, F32, F32, P, P, P, P, P, P, P, P, P, P]),
     "osr_assemble_detections": (I32, [P, P, P, P, P, I64, I32, P, P, P, P, I64, I32, I32, I64, P, P, P, P, P, P]),
+    "osr_detector_postprocess": (I32, [P, P, P, P, I32, I32, P, P, P, P, P, P, P]),
     # training step, forward half
     "osr_rpn_match_anchors": (I32, [P, P, I32, P, P, I32, F32, F32, F32, F32, P, P, P, P, P, I64, P]),
     "osr_subsample_labels": (I32, [P, P, I32, I64, I32, F32, P, P, P]),

@@ -547,14 +547,15 @@ class GeneralizedRCNN(_EngineOwner):
             for k, im in enumerate(imgs):
                 batch[k, :, : sizes[k][0], : sizes[k][1]] = im.to(self.device).float()
             res = eng.forward(batch, sizes)
+        if do_postprocess:  # [d2] detector_postprocess on the device: rescale, clip, drop empties
+            outs = [(int(inp.get("height", s[0])), int(inp.get("width", s[1]))) for inp, s in zip(batched_inputs, sizes)]
+            scale = torch.tensor([[ow / s[1], oh / s[0]] for (oh, ow), s in zip(outs, sizes)], dtype=torch.float32, device=self.device)
+            res = ops.detector_postprocess(res[0], res[1], res[2], res[3], scale, torch.tensor(outs, dtype=torch.int32, device=self.device))
+        else:
+            outs = sizes
         insts = OpensetRCNNEngine.to_instances(res, len(imgs))
-        out = []
-        for r, inp, size in zip(insts, batched_inputs, sizes):
-            inst = Instances(size, pred_boxes=Boxes(r["pred_boxes"]), scores=r["scores"], pred_classes=r["pred_classes"])
-            if do_postprocess:
-                inst = detector_postprocess(inst, inp.get("height", size[0]), inp.get("width", size[1]))
-            out.append({"instances": inst})
-        return out
+        return [{"instances": Instances(o, pred_boxes=Boxes(r["pred_boxes"]), scores=r["scores"], pred_classes=r["pred_classes"])}
+                for r, o in zip(insts, outs)]
 
 
 def build_model(cfg: CfgNode, class_id: Optional[torch.Tensor] = None) -> nn.Module:

@@ -355,6 +355,19 @@ def assemble_detections(cands, k_keep, k_keep_count, u_keep, u_keep_count, n, un
     return ob, os_, oc, on
 
 
+def detector_postprocess(boxes, scores, classes, count, scale_xy, out_hw):
+    """Padded (n,cap,.) detections -> rescaled, clipped, empties dropped (order kept); scale_xy (n,2) fp32, out_hw (n,2) int32."""
+    lib = _lib.load()
+    _need(boxes, torch.float32, "boxes"); _need(scores, torch.float32, "scores"); _need(classes, torch.int64, "classes")
+    _need(count, torch.int32, "count"); _need(scale_xy, torch.float32, "scale_xy"); _need(out_hw, torch.int32, "out_hw")
+    n, cap = scores.shape
+    ob, os_, oc = torch.empty_like(boxes), torch.empty_like(scores), torch.empty_like(classes)
+    on = torch.empty_like(count)
+    check(lib.osr_detector_postprocess(_p(boxes), _p(scores), _p(classes), _p(count), n, cap, _p(scale_xy), _p(out_hw), _p(ob), _p(os_), _p(oc),
+                                       _p(on), _stream()), "osr_detector_postprocess")
+    return ob, os_, oc, on
+
+
 # ----------------------------------------------------------------------------------------------------------
 # training step, forward half (targets + losses)
 # ----------------------------------------------------------------------------------------------------------

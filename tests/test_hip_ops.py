@@ -479,3 +479,30 @@ def test_cfrpn_head_fused_matches_two_step_and_oracle(ops):
     dr, cr = O.cfrpn_head_tail(tq.permute(0, 2, 3, 1).reshape(-1, 256), pq)
     assert_close(d_f, dr, rtol=2e-3, atol=2e-3, name="fused vs oracle deltas")  # 1 fp16 ulp flips of t before the normalise
     assert_close(c_f, cr, rtol=2e-3, atol=1e-3, name="fused vs oracle ctr")
+
+
+def test_detector_postprocess(ops):
+    gg = g(77)
+    n, cap = 3, 100
+    xy = torch.rand(n, cap, 2, generator=gg) * 300 - 20
+    boxes = torch.cat((xy, xy + torch.rand(n, cap, 2, generator=gg) * 80), dim=2)
+    boxes[0, 3] = torch.tensor([500.0, 10.0, 520.0, 30.0])  # fully outside after clipping -> dropped
+    boxes[1, 0, 2] = boxes[1, 0, 0]                          # zero width -> dropped
+    scores = torch.rand(n, cap, generator=gg)
+    classes = torch.randint(0, 21, (n, cap), generator=gg)
+    count = torch.tensor([100, 37, 0], dtype=torch.int32)
+    sizes, outs = [(240, 320)] * n, [(480, 500), (120, 160), (240, 320)]
+    scale = torch.tensor([[ow / s[1], oh / s[0]] for (oh, ow), s in zip(outs, sizes)], dtype=torch.float32)
+    ob, os_, oc, on = [t.cpu() for t in ops.detector_postprocess(boxes.to(DEV), scores.to(DEV), classes.to(DEV), count.to(DEV), scale.to(DEV),
+                                                                 torch.tensor(outs, dtype=torch.int32).to(DEV))]
+    for i in range(n):
+        c = int(count[i])
+        b = boxes[i, :c] * torch.tensor([scale[i, 0], scale[i, 1], scale[i, 0], scale[i, 1]])
+        b[:, 0::2] = b[:, 0::2].clamp(0, outs[i][1])
+        b[:, 1::2] = b[:, 1::2].clamp(0, outs[i][0])
+        keep = ((b[:, 2] - b[:, 0]) > 0) & ((b[:, 3] - b[:, 1]) > 0)
+        m = int(keep.sum())
+        assert int(on[i]) == m
+        assert torch.equal(ob[i, :m], b[keep]) and torch.equal(os_[i, :m], scores[i, :c][keep]) and torch.equal(oc[i, :m], classes[i, :c][keep])
+        assert bool((oc[i, m:] == -1).all())
+    assert int(on[0]) < 100 and int(on[1]) < 37
