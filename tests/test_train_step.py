@@ -158,3 +158,16 @@ def test_sgd_steps_reduce_the_loss_and_are_reproducible(setup, osr):
     assert h2[0] == h1[0]
     assert h2 == pytest.approx(h1, rel=2e-2), (h1, h2)
     assert tr.num_params == 41_621_279 - 0 or tr.num_params > 41_000_000  # 41.6 M trainable parameters
+
+
+def test_bf16_training_step(setup):
+    """The same step with bf16 activations / gradients and no loss scaling (bf16 has fp32's exponent range)."""
+    from openset_rcnn_amd.host.train import OpensetRCNNTrainer
+    d = setup["dev"]
+    tr = OpensetRCNNTrainer(setup["params"], dtype=torch.bfloat16, device=DEV, lr=5e-5, loss_scale=1.0)
+    hist = []
+    for _ in range(5):
+        losses = tr.step(d["images"], d["hw"], setup["h"], setup["w"], d["gt"], d["gcls"], d["gcnt"], d["keys"])
+        hist.append(sum(float(v) for v in losses.values()))
+    assert all(torch.isfinite(torch.tensor(hist))), hist
+    assert hist[-1] < 0.9 * hist[0], hist
