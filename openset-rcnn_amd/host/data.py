@@ -1,0 +1,119 @@
+"""Input side of the path: what [d2] DatasetMapper / build_detection_{test,train}_loader do for the
+reference (train.py:84-104 builds them through DefaultTrainer): read an image file to BGR uint8, ResizeShortestEdge
+(MIN_SIZE_TEST 800 / MAX_SIZE_TEST 1333; training: a random choice of MIN_SIZE_TRAIN + horizontal flip), carry the annotations
+through the same transform, and hand `list[dict{image (3,H,W) uint8 BGR, height, width, image_id, instances?}]` batches to the
+model. Host code, as in the reference (PIL); normalisation, padding and batching happen on the GPU (osr_preprocess).
+
+Sharding: the test loader gives rank r the contiguous slice shard_range(N, r, world) ([d2] InferenceSampler); the train loader
+draws an infinite seeded permutation stream and gives rank r every world-th element ([d2] TrainingSampler)."""
+from __future__ import annotations
+
+from typing import Callable, Dict, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .parallel import shard_range, world_info
+from .structures import Boxes, Instances
+
+
+def read_image(file_name: str, format: str = "BGR") -> np.ndarray:
+    """[d2] detection_utils.read_image: PIL decode, EXIF orientation applied, RGB -> BGR; (H, W, 3) uint8."""
+    from PIL import Image, ImageOps
+    with Image.open(file_name) as im:
+        im = ImageOps.exif_transpose(im).convert("RGB")
+        a = np.asarray(im)
+    return a[:, :, ::-1].copy() if format == "BGR" else a.copy()
+
+
+def shortest_edge_size(h: int, w: int, size: int, max_size: int) -> Tuple[int, int]:
+    """[d2] ResizeShortestEdge.get_output_shape."""
+    scale = size * 1.0 / min(h, w)
+    newh, neww = (size, scale * w) if h < w else (scale * h, size)
+    if max(newh, neww) > max_size:
+        s = max_size * 1.0 / max(newh, neww)
+        newh, neww = newh * s, neww * s
+    return int(newh + 0.5), int(neww + 0.5)
+
+
+def resize_image(img: np.ndarray, new_hw: Tuple[int, int]) -> np.ndarray:
+    """[d2] ResizeTransform.apply_image for uint8: PIL bilinear."""
+    from PIL import Image
+    if img.shape[:2] == tuple(new_hw):
+        return img
+    return np.asarray(Image.fromarray(img).resize((new_hw[1], new_hw[0]), Image.BILINEAR))
+
+
+class DatasetMapper:
+    """dataset dict -> model input dict ([d2] DatasetMapper with the default augmentations of cfg.INPUT)."""
+
+    def __init__(self, cfg, is_train: bool, seed: int = 0):
+        self.is_train = is_train
+        self.format = cfg.INPUT.FORMAT
+        if is_train:
+            self.min_sizes, self.max_size = tuple(cfg.INPUT.MIN_SIZE_TRAIN), cfg.INPUT.MAX_SIZE_TRAIN
+            self.flip = cfg.INPUT.RANDOM_FLIP == "horizontal"
+        else:
+            self.min_sizes, self.max_size, self.flip = (cfg.INPUT.MIN_SIZE_TEST,), cfg.INPUT.MAX_SIZE_TEST, False
+        self.rng = np.random.RandomState(seed)
+
+    def __call__(self, d: dict) -> dict:
+        img = read_image(d["file_name"], self.format)
+        h, w = img.shape[:2]
+        out = {k: v for k, v in d.items() if k != "annotations"}
+        out.setdefault("height", h)
+        out.setdefault("width", w)
+        do_flip = self.flip and self.rng.rand() < 0.5
+        if do_flip:
+            img = img[:, ::-1]
+        size = int(self.min_sizes[self.rng.randint(len(self.min_sizes))]) if self.is_train else int(self.min_sizes[0])
+        nh, nw = shortest_edge_size(h, w, size, self.max_size) if size > 0 else (h, w)
+        img = resize_image(np.ascontiguousarray(img), (nh, nw))
+        out["image"] = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1)))
+        if self.is_train and "annotations" in d:
+            boxes = np.array([a["bbox"] for a in d["annotations"] if not a.get("iscrowd", 0)], dtype=np.float32).reshape(-1, 4)
+            classes = [a["category_id"] for a in d["annotations"] if not a.get("iscrowd", 0)]
+            if do_flip:
+                boxes = np.stack((w - boxes[:, 2], boxes[:, 1], w - boxes[:, 0], boxes[:, 3]), axis=1) if len(boxes) else boxes
+            boxes = boxes * np.array([nw / w, nh / h, nw / w, nh / h], dtype=np.float32)
+            boxes[:, 0::2] = boxes[:, 0::2].clip(0, nw)
+            boxes[:, 1::2] = boxes[:, 1::2].clip(0, nh)
+            inst = Instances((nh, nw))
+            inst.gt_boxes = Boxes(torch.from_numpy(boxes))
+            inst.gt_classes = torch.tensor(classes, dtype=torch.int64)
+            keep = inst.gt_boxes.nonempty()
+            out["instances"] = inst[keep]
+        return out
+
+
+def build_detection_test_loader(dataset_dicts: Sequence[dict], mapper: Callable[[dict], dict], batch_size: int = 1,
+                                rank: Optional[int] = None, world: Optional[int] = None) -> Iterator[List[dict]]:
+    """This rank's contiguous shard of the dataset in batches ([d2] build_detection_test_loader + InferenceSampler)."""
+    if rank is None or world is None:
+        rank, world = world_info()
+    lo, hi = shard_range(len(dataset_dicts), rank, world)
+    for i in range(lo, hi, batch_size):
+        yield [mapper(dataset_dicts[j]) for j in range(i, min(i + batch_size, hi))]
+
+
+def build_detection_train_loader(dataset_dicts: Sequence[dict], mapper: Callable[[dict], dict], images_per_batch: int, seed: int = 0,
+                                 rank: Optional[int] = None, world: Optional[int] = None, filter_empty: bool = True) -> Iterator[List[dict]]:
+    """Infinite stream of per-rank batches (images_per_batch is the GLOBAL batch, SOLVER.IMS_PER_BATCH): a seeded permutation per
+    epoch shared by all ranks, rank r takes elements r, r+world, ... ([d2] TrainingSampler); images without annotations are dropped
+    first (DATALOADER.FILTER_EMPTY_ANNOTATIONS)."""
+    if rank is None or world is None:
+        rank, world = world_info()
+    assert images_per_batch % world == 0, "IMS_PER_BATCH must be divisible by the number of ranks"
+    per_rank = images_per_batch // world
+    dicts = [d for d in dataset_dicts if not filter_empty or len(d.get("annotations", [])) > 0]
+    g = torch.Generator().manual_seed(seed)
+    batch: List[dict] = []
+    pos = 0
+    while True:
+        for idx in torch.randperm(len(dicts), generator=g).tolist():
+            if pos % world == rank:
+                batch.append(mapper(dicts[idx]))
+                if len(batch) == per_rank:
+                    yield batch
+                    batch = []
+            pos += 1

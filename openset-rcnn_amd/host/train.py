@@ -23,6 +23,17 @@ from .engine import OpensetRCNNEngine
 from .weights import R50_BLOCKS, pack_conv_weight, pack_fc1_weight
 
 
+def warmup_multistep_lr(iteration: int, base_lr: float, steps: Tuple[int, ...], gamma: float = 0.1, warmup_iters: int = 1000,
+                        warmup_factor: float = 1.0 / 1000) -> float:
+    """[d2] WarmupMultiStepLR (SOLVER.LR_SCHEDULER_NAME default; VOC-COCO yaml: BASE_LR 0.005, STEPS (84000, 116000),
+    WARMUP_ITERS 400): linear warm-up of the factor from warmup_factor to 1, then x gamma at every milestone passed."""
+    lr = base_lr * gamma ** sum(1 for s in steps if iteration >= s)
+    if iteration < warmup_iters:
+        alpha = iteration / warmup_iters
+        lr *= warmup_factor * (1 - alpha) + alpha
+    return lr
+
+
 def _dgrad_pack(w_lp: torch.Tensor) -> torch.Tensor:
     """(cout,kh,kw,cin) packed forward weight -> (cin,kh,kw,cout) flipped: the weight of the backward-data convolution."""
     return w_lp.flip(1, 2).permute(3, 1, 2, 0).contiguous()

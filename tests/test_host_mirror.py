@@ -242,3 +242,12 @@ def test_trainer_from_the_mirror_roundtrip(osr, tmp_path):
     model.load_trainer_state(tr)
     assert torch.equal(model.state_dict()[name + ".weight"].cpu(), after[name + ".weight"])
     assert torch.equal(model.state_dict()["roi_heads.box_head.fc1.weight"].cpu(), after["roi_heads.box_head.fc1.weight"])
+
+
+def test_warmup_multistep_lr(osr):
+    from openset_rcnn_amd.host.train import warmup_multistep_lr as lr
+    kw = dict(base_lr=0.005, steps=(84000, 116000), gamma=0.1, warmup_iters=400, warmup_factor=0.001)
+    assert lr(0, **kw) == pytest.approx(0.005 * 0.001)
+    assert lr(200, **kw) == pytest.approx(0.005 * (0.001 * 0.5 + 0.5))
+    assert lr(400, **kw) == pytest.approx(0.005) and lr(83999, **kw) == pytest.approx(0.005)
+    assert lr(84000, **kw) == pytest.approx(0.0005) and lr(116000, **kw) == pytest.approx(0.00005)
