@@ -8,7 +8,7 @@ from __future__ import annotations
 import os
 import xml.etree.ElementTree as ET
 from types import SimpleNamespace
-from typing import Callable, Dict, List, Sequence
+from typing import Callable, Dict, List, Optional, Sequence
 
 # the 20 VOC classes, the 60 remaining COCO classes in the order of the 20-40 / 40-60 / 60-80 splits, then "unknown"
 VOC_COCO_CATEGORIES = [
@@ -78,10 +78,75 @@ def register_opendet_voc_coco(root: str) -> None:
         register_voc_coco(split, os.path.join(root, "voc_coco"), split, 2007 if "2007" in split else 2012)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# GraspNet open-set splits (COCO-format json): openset_rcnn/data/graspnet.py, graspnet_meta.py, custom.py:9-30
+# ---------------------------------------------------------------------------------------------------------------
+# the 28 known object categories of the benchmark (graspnet_meta.py:92-98); the full 88-entry category table is read from the
+# annotation json itself
+GRASPNET_KNOWN_CATEGORIES = [
+    "cracker_box", "tomato_soup_can", "banana", "mug", "power_drill", "scissors", "strawberry", "peach", "plum", "knife", "flat_screwdriver",
+    "racquetball", "b_cups", "d_toy_airplane", "f_toy_airplane", "i_toy_airplane", "j_toy_airplane", "dabao_sod", "darlie_toothpaste", "camel",
+    "large_elephant", "rhinocero", "darlie_box", "black_mouse", "dabao_facewash", "pantene", "head_shoulders_supreme", "head_shoulders_care",
+]
+GRASPNET_SPLITS = {"graspnet_train": "graspnet_os_train.json", **{f"graspnet_test_{i}": f"graspnet_os_test_{i}.json" for i in range(1, 7)}}
+
+
+def load_coco_json(json_file: str, image_root: str, dataset_name: Optional[str] = None) -> List[dict]:
+    """[d2] load_coco_json without pycocotools: one dict per image with file_name, height, width, image_id and annotations
+    [{bbox XYWH_ABS, category_id (contiguous), iscrowd}]; records the category tables in the dataset's metadata."""
+    import json
+    with open(json_file) as f:
+        data = json.load(f)
+    cats = sorted(data["categories"], key=lambda c: c["id"])
+    id_map = {c["id"]: i for i, c in enumerate(cats)}
+    if dataset_name is not None:
+        meta = MetadataCatalog.get(dataset_name)
+        meta.thing_classes = [c["name"] for c in cats]
+        meta.thing_dataset_id_to_contiguous_id = id_map
+    by_img: Dict[int, List[dict]] = {}
+    for a in data["annotations"]:
+        by_img.setdefault(a["image_id"], []).append(a)
+    out = []
+    for im in sorted(data["images"], key=lambda r: r["id"]):
+        rec = dict(file_name=os.path.join(image_root, im["file_name"]), height=im["height"], width=im["width"], image_id=im["id"], annotations=[])
+        for a in by_img.get(im["id"], []):
+            if a.get("ignore", 0):
+                continue
+            x, y, w, h = a["bbox"]
+            rec["annotations"].append(dict(bbox=[x, y, x + w, y + h], bbox_mode="XYXY_ABS", category_id=id_map[a["category_id"]],
+                                           iscrowd=a.get("iscrowd", 0)))
+        out.append(rec)
+    return out
+
+
+def register_graspnet_instances(name: str, json_file: str, image_root: str) -> None:
+    DatasetCatalog.register(name, lambda: load_coco_json(json_file, image_root, name))
+    meta = MetadataCatalog.get(name)
+    meta.json_file, meta.image_root, meta.evaluator_type = json_file, image_root, "coco"
+
+
+def register_graspnet_os(root: str) -> None:
+    for name, jf in GRASPNET_SPLITS.items():
+        register_graspnet_instances(name, os.path.join(root, "graspnet_os", "annotations", jf), os.path.join(root, "graspnet_os", "images"))
+
+
+def graspnet_class_map(thing_classes: Sequence[str]):
+    """Sorted contiguous ids of the known categories: the `class_id` tensor PLN / SoftMaxClassifier build
+    (prototype_learning_network.py:80-86); pass it as `class_id` to build_model / OpensetRCNNEngine(class_map=...)."""
+    import torch
+    return torch.tensor(sorted(thing_classes.index(n) for n in GRASPNET_KNOWN_CATEGORIES if n in thing_classes), dtype=torch.int64)
+
+
 def get_evaluator(cfg, dataset_name: str, output_folder=None):
-    """train.py:57-78 for the pascal_voc evaluator type."""
+    """train.py:57-78: "pascal_voc" -> open-set VOC evaluator, "coco" -> open-set COCO-style evaluator (GraspNet)."""
     from .evaluation import PascalVOCDetectionEvaluator
     meta = MetadataCatalog.get(dataset_name)
+    if getattr(meta, "evaluator_type", None) == "coco":
+        from .os_coco_evaluation import OpensetCOCOEvaluator
+        if not hasattr(meta, "thing_dataset_id_to_contiguous_id"):
+            DatasetCatalog[dataset_name]()  # loading the json fills the category tables
+        rev = {v: k for k, v in meta.thing_dataset_id_to_contiguous_id.items()}
+        return OpensetCOCOEvaluator(meta.json_file, GRASPNET_KNOWN_CATEGORIES, rev, max_dets_per_image=[10, 20, 30, 50, 100])
     if getattr(meta, "evaluator_type", None) != "pascal_voc":
         raise NotImplementedError(f"no Evaluator for the dataset {dataset_name} with the type {getattr(meta, 'evaluator_type', None)}")
     return PascalVOCDetectionEvaluator(meta.dirname, meta.split, meta.thing_classes, cfg.MODEL.ROI_HEADS.NUM_KNOWN_CLASSES,
