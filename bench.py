@@ -91,11 +91,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # rehearsal knobs (never set by the driver): OSR_DIST_BACKEND=gloo lets several ranks share one GPU on a 1-GPU box
+    backend = os.environ.get("OSR_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend=backend)
 
     pkg = ge.load_package()
     pkg._lib.load()
