@@ -561,6 +561,7 @@ static int big_tile_min_tiles() { static const int v = env_int("OSR_CONV_BIG_MIN
 static int small_grid_blocks() { static const int v = env_int("OSR_CONV_SMALL_GRID", 768); return v; }
 static int wide_any_min_nk() { static const int v = env_int("OSR_CONV_WIDE_ANY_MIN_NK", 0); return v; }
 static int wide_any_max_nk() { static const int v = env_int("OSR_CONV_WIDE_ANY_MAX_NK", 1000); return v; }
+static int n64_max_tiles() { static const int v = env_int("OSR_CONV_N64_MAX_TILES", 0); return v; }
 static int wide_n_min_m() { static const int v = env_int("OSR_CONV_WIDE_MIN_M", 200000); return v; }
 
 template <class K>
@@ -592,7 +593,8 @@ static osr_status conv64_launch(Conv64Args& a, hipStream_t st) {
         if (!attr) { allow_big_lds(conv_igemm64_kernel<TI, TO, 256, 256, 2, 4, 0, 1>); attr = true; }
         hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 256, 256, 2, 4, 0, 1>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(512),
                            conv64_lds_bytes(256, 256, 1, 8), st, a);
-    } else if (a.p.cout <= 64) {
+    } else if (a.p.cout <= 64 || (long long)a.tiles_m * ((a.p.cout + 127) / 128) <= n64_max_tiles()) {
+        // narrow tiles also for grids too small to load 256 CUs evenly with 128 x 128 tiles (finer quantisation, 5 workgroups per CU)
         a.tiles_n = (a.p.cout + 63) / 64;
         if (a.two_stage)
             hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 128, 64, 4, 1, 0, 1>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(256),
