@@ -7,8 +7,9 @@ registered names the yaml files select --
 
 -- with the same constructor configuration keys, forward signatures, output field names and state-dict key names.
 The modules own fp32 parameters under detectron2's names (checkpoint compatible); their inference forwards run on
-the HIP library through `OpensetRCNNEngine` (no eager path). Training: the forward half (targets + loss values) is
-`GeneralizedRCNN.losses_forward`; module forwards in training mode raise until the backward kernels exist.
+the HIP library through `OpensetRCNNEngine` (no eager path). Training: `GeneralizedRCNN.make_trainer()` returns the object whose
+`step()` is the trainer loop body (forward, explicit backward, SGD); `losses_forward` evaluates the loss dict only; module
+forwards in training mode raise, because they cannot return losses that carry autograd gradients.
 Feature maps cross these signatures as logical (N,C,H,W) tensors in channels_last memory (= the kernels' NHWC)."""
 from __future__ import annotations
 
@@ -59,8 +60,8 @@ RPN_HEAD_REGISTRY = Registry("RPN_HEAD")
 ROI_HEADS_REGISTRY = Registry("ROI_HEADS")
 ROI_BOX_HEAD_REGISTRY = Registry("ROI_BOX_HEAD")
 
-_TRAIN_MSG = ("model(batched_inputs) in training mode must return losses that carry gradients; the HIP path has the forward half only "
-              "(targets + loss values: GeneralizedRCNN.losses_forward), the backward kernels are the next scope row (DESIGN.md section 7)")
+_TRAIN_MSG = ("model(batched_inputs) in training mode must return losses that carry autograd gradients; the HIP path has no autograd graph. "
+              "Use GeneralizedRCNN.make_trainer().step(...) (forward + explicit backward + SGD) or .losses_forward(...) (loss values only)")
 
 
 def _to_nhwc(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:

@@ -763,7 +763,7 @@ def detector_inference(images: Sequence[torch.Tensor], bb_params, head_params, c
 
 
 # --------------------------------------------------------------------------------------
-# Training-side pieces (targets + losses) -- oracle only this round
+# Training-side pieces (targets + losses); their gradients are checked through torch autograd over these functions
 # --------------------------------------------------------------------------------------
 
 
