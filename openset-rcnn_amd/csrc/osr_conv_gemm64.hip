@@ -90,6 +90,7 @@ struct Conv64Args {
     unsigned in_bytes, w_bytes;  // buffer sizes for the bounds check (< 2 GiB)
     int stem;              // 1: cin == 32 view, two taps per K slice
     int two_stage;         // 1: double-buffered staging (K-heavy layers); 0: one staging buffer, more workgroups per CU
+    int tap_minor;         // 1: K runs channel-slice-major / tap-minor (L2-friendly for KH*KW > 1), 0: tap-major
     // fused CF-RPN tail (EPI == 1): 1x1 weights [5][256] (rows 0-3 ltrb deltas, row 4 centerness), biases, outputs
     const float* tail_w;
     const float* tail_b;
@@ -226,11 +227,20 @@ __global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI !=
     {                                                                                     \
         _Pragma("unroll") for (int q_ = 0; q_ < A_PIECES + B_PIECES; ++q_) C64_ISSUE_PIECE(stage, q_); \
     }
+    // K order of a KH x KW conv: channel slice outermost, taps innermost (a.tap_minor). Consecutive K steps then re-read the
+    // same 64 channels of neighbouring pixels, so eight of the nine tap loads of a 3x3 conv hit the XCD's L2 instead of
+    // the Infinity Cache (tap-major order re-reads a pixel only after a full sweep of the channels, ~4 MB of other traffic
+    // per XCD later). The weight rows stay [kh][kw][cin]: only the scalar offset sequence of the B loads changes.
 #define C64_ADVANCE()                                                                                 \
     {                                                                                                 \
-        kbyte += 128;                                                                                 \
-        if (a.stem) { kh += 2; tap_off = (unsigned)(kh * p.in_stride_h * 2); }                        \
-        else {                                                                                        \
+        if (a.stem) { kbyte += 128; kh += 2; tap_off = (unsigned)(kh * p.in_stride_h * 2); }          \
+        else if (a.tap_minor) {                                                                       \
+            if (++kw >= p.kw) { kw = 0; if (++kh >= p.kh) { kh = 0; c0 += 64; } }                     \
+            tap = kh * p.kw + kw;                                                                     \
+            tap_off = (unsigned)((kh * p.in_stride_h + kw * p.in_stride_w + c0) * 2);                 \
+            kbyte = (tap * p.cin + c0) * 2;                                                           \
+        } else {                                                                                      \
+            kbyte += 128;                                                                             \
             c0 += 64;                                                                                 \
             if (c0 >= p.cin) { c0 = 0; if (++kw >= p.kw) { kw = 0; ++kh; } }                          \
             tap = kh * p.kw + kw;                                                                     \
@@ -555,69 +565,101 @@ static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
 }
-static int one_stage_max_nk() { static const int v = env_int("OSR_CONV_1STAGE_MAXNK", 40); return v; }
-static int big_tile_min_nk() { static const int v = env_int("OSR_CONV_BIG_MIN_NK", 8); return v; }
-static int big_tile_min_tiles() { static const int v = env_int("OSR_CONV_BIG_MIN_TILES", 768); return v; }
-static int small_grid_blocks() { static const int v = env_int("OSR_CONV_SMALL_GRID", 768); return v; }
-static int wide_any_min_nk() { static const int v = env_int("OSR_CONV_WIDE_ANY_MIN_NK", 0); return v; }
-static int wide_any_max_nk() { static const int v = env_int("OSR_CONV_WIDE_ANY_MAX_NK", 1000); return v; }
-static int n64_max_tiles() { static const int v = env_int("OSR_CONV_N64_MAX_TILES", 0); return v; }
-static int wide_n_min_m() { static const int v = env_int("OSR_CONV_WIDE_MIN_M", 200000); return v; }
+static int rpn_big_min_tiles() { static const int v = env_int("OSR_RPN_BIG_MIN_TILES", 512); return v; }  // fused CF-RPN head: 256-row tiles from this many tiles on
+static int tap_minor_default() { static const int v = env_int("OSR_CONV_TAP_MINOR", 1); return v; }
 
 template <class K>
 static void allow_big_lds(K kernel) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
+// Tile configurations of the plain conv / FC kernel.
+enum Conv64Tile { T128x128_1 = 1, T128x128_2, T256x256_2, T128x256_1, T256x128_1, T256x128_2, T128x64_1, T128x64_2 };
+static int force_tile() { static const int v = env_int("OSR_CONV_FORCE_TILE", 0); return v; }  // diagnostic: one configuration for every layer it fits
+
+template <class TI, class TO, int BM, int BN, int WM, int WN, int TWO>
+static void conv64_launch_tile(Conv64Args& a, hipStream_t st) {
+    constexpr int NW = WM * WN;
+    a.two_stage = TWO;
+    a.tiles_m = (int)((a.M + BM - 1) / BM);
+    a.tiles_n = (a.p.cout + BN - 1) / BN;
+    const size_t lds = conv64_lds_bytes(BM, BN, TWO, NW);
+    if (lds > 64 * 1024) {
+        static thread_local bool attr = false;
+        if (!attr) { allow_big_lds(conv_igemm64_kernel<TI, TO, BM, BN, WM, WN, 0, TWO>); attr = true; }
+    }
+    hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, BM, BN, WM, WN, 0, TWO>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(NW * 64), lds, st, a);
+}
+
+// Tile choice by a small cost model instead of per-layer thresholds. Measured on MI355X (scripts/ab_tiles.sh): with the
+// staging pieces interleaved into the MFMA stream every configuration saturates at the same ~4.45 TFLOP/s per CU once a CU
+// holds its full complement of workgroups, so what separates them is (i) how many dispatch rounds the grid needs at
+// `occ` workgroups per CU (VGPR / LDS limited) and how empty the last round is, and (ii) whether a K slice is bound by
+// the matrix pipe (r residents x w) or by the L2 -> LDS latency (single buffer: L + w, double buffer: max(L, r x w)).
+//   time = full_rounds x tile(occ) + tile(residents of the last partial round),  tile(r) = fixed + nk x slice(r)
+// The 256-wide tiles read the residual in the epilogue (no prefetch under the K loop), which measured 1.6x slower on the
+// HBM-bound residual layers: they are not offered when there is a residual.
+struct TileCfg { int id, bm, bn, two, occ, pre_res; };
+static const TileCfg kTileCfgs[] = {
+    {T128x128_1, 128, 128, 0, 3, 1}, {T128x128_2, 128, 128, 1, 2, 1}, {T256x256_2, 256, 256, 1, 1, 0}, {T128x256_1, 128, 256, 0, 2, 0},
+    {T256x128_1, 256, 128, 0, 2, 0}, {T128x64_1, 128, 64, 0, 4, 1},   {T128x64_2, 128, 64, 1, 3, 1},
+};
+
+static double conv64_tile_us(const TileCfg& c, int nk, int residents, bool res) {
+    const double kCapFlopPerUs = 4.45e6, kLat = 1.0;  // per-CU MFMA rate under load; L2 -> LDS latency of one staged slice (us)
+    const double w = (double)c.bm * c.bn * 128.0 / kCapFlopPerUs;
+    const double busy = residents * w;
+    const double slice = c.two ? (busy > kLat + 0.1 ? busy : kLat + 0.1) : (busy > kLat + w ? busy : kLat + w);
+    const double fixed = 1.5 + (c.two ? kLat : 0.0) + (double)c.bm * c.bn / 16384.0 * 1.3 * (res ? 1.5 : 1.0);
+    return fixed + nk * slice;
+}
+
+// The modelled time of the 256 x 256 tile is scaled by 0.65 (OSR_CONV_MODEL_BIG, percent): the pass runs as two micro-batch
+// streams, so the empty part of a one-workgroup-per-CU round is filled by the other stream's launches, and the big tile
+// moves half the L2 -> LDS and LDS -> register bytes per FLOP of the 128 x 128 tile, which is what counts once both streams
+// compete for a CU (same-box end-to-end A/B: 1.00 -> 1127, 0.85 -> 1138, 0.70 -> 1172-1193, 0.60 -> 1200, 0.50 -> 1184 img/s).
+static double model_big_scale() {
+    static const double v = [] { const char* e = getenv("OSR_CONV_MODEL_BIG"); return e ? atof(e) / 100.0 : 0.65; }();
+    return v;
+}
+
+static int conv64_pick_tile(const Conv64Args& a) {
+    const int nk = a.K / 64, cout = a.p.cout;
+    const bool res = a.p.res_mode != 0;
+    const int f = force_tile();
+    if (f != 0) {
+        const bool fits = (f == T256x256_2 || f == T128x256_1) ? cout % 256 == 0 : (f == T256x128_1 || f == T256x128_2) ? cout % 128 == 0 : true;
+        if (fits && !((f == T128x128_2 || f == T256x128_2 || f == T128x64_2 || f == T256x256_2) && nk < 2)) return f;
+    }
+    int best = T128x128_1;
+    double best_us = 1e30;
+    for (const TileCfg& c : kTileCfgs) {
+        if (c.bn == 256 && cout % 256 != 0) continue;
+        if (cout <= 64 && c.bn != 64) continue;          // narrow layers: no half-empty N tiles
+        if (res && !c.pre_res) continue;
+        if (c.two && nk < 2) continue;
+        const long long tiles = (a.M + c.bm - 1) / c.bm * ((cout + c.bn - 1) / c.bn), slots = 256ll * c.occ;
+        const long long full = tiles / slots, rem = tiles % slots;
+        double us = (double)full * conv64_tile_us(c, nk, c.occ, res);
+        if (rem) us += conv64_tile_us(c, nk, (int)((rem + 255) / 256), res);
+        if (c.id == T256x256_2) us *= model_big_scale();
+        if (us < best_us) { best_us = us; best = c.id; }
+    }
+    return best;
+}
+
 template <class TI, class TO>
 static osr_status conv64_launch(Conv64Args& a, hipStream_t st) {
-    const int nk = a.K / 64;
-    // Few K steps: the layer is bound by memory latency and its epilogue traffic, so trade the second staging buffer
-    // for more resident workgroups per CU. Many K steps: double buffer.
-    a.two_stage = nk > one_stage_max_nk() ? 1 : 0;
     a.tail_lds_off = 0;
-    a.tiles_m = (int)((a.M + 127) / 128);
-    {
-        // a grid too small to put 3-4 workgroups on every CU cannot hide the staging latency by occupancy:
-        // overlap it inside the workgroup instead (double buffer)
-        const long long nblk = (long long)a.tiles_m * ((a.p.cout + 127) / 128);
-        if (nk >= 2 && nblk < small_grid_blocks()) a.two_stage = 1;
-    }
-    if (a.p.cout % 256 == 0 && a.p.res_mode == 0 && nk >= big_tile_min_nk() && (a.M + 255) / 256 * (a.p.cout / 256) >= big_tile_min_tiles()) {
-        // 256 x 256 tiles, 8 waves, double buffer (128 KB LDS, one workgroup per CU): 175 FLOP per staged byte, needed
-        // because the L2 -> LDS fill rate (~70 GB/s per CU), not the matrix pipe, bounds the 128 x 128 tiles
-        a.two_stage = 1;
-        a.tiles_m = (int)((a.M + 255) / 256);
-        a.tiles_n = a.p.cout / 256;
-        static thread_local bool attr = false;
-        if (!attr) { allow_big_lds(conv_igemm64_kernel<TI, TO, 256, 256, 2, 4, 0, 1>); attr = true; }
-        hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 256, 256, 2, 4, 0, 1>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(512),
-                           conv64_lds_bytes(256, 256, 1, 8), st, a);
-    } else if (a.p.cout <= 64 || (long long)a.tiles_m * ((a.p.cout + 127) / 128) <= n64_max_tiles()) {
-        // narrow tiles also for grids too small to load 256 CUs evenly with 128 x 128 tiles (finer quantisation, 5 workgroups per CU)
-        a.tiles_n = (a.p.cout + 63) / 64;
-        if (a.two_stage)
-            hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 128, 64, 4, 1, 0, 1>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(256),
-                               conv64_lds_bytes(128, 64, 1), st, a);
-        else
-            hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 128, 64, 4, 1, 0, 0>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(256),
-                               conv64_lds_bytes(128, 64, 0), st, a);
-    } else if ((a.p.cout == 256 && a.p.res_mode == 0 && nk >= 8 && !a.two_stage && a.M >= wide_n_min_m()) ||
-               (wide_any_min_nk() > 0 && a.p.cout % 256 == 0 && !a.two_stage && nk >= wide_any_min_nk() && nk <= wide_any_max_nk())) {
-        // 128 x 256 tiles for the big 256-channel layers (FPN output convs): the gathered activation rows are fetched once
-        a.tiles_n = a.p.cout / 256;
-        static thread_local bool attr = false;
-        if (!attr) { allow_big_lds(conv_igemm64_kernel<TI, TO, 128, 256, 2, 2, 0, 0>); attr = true; }
-        hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 128, 256, 2, 2, 0, 0>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(256),
-                           conv64_lds_bytes(128, 256, 0), st, a);
-    } else {
-        a.tiles_n = (a.p.cout + 127) / 128;
-        if (a.two_stage)
-            hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 128, 128, 2, 2, 0, 1>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(256),
-                               conv64_lds_bytes(128, 128, 1), st, a);
-        else
-            hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, 128, 128, 2, 2, 0, 0>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(256),
-                               conv64_lds_bytes(128, 128, 0), st, a);
+    switch (conv64_pick_tile(a)) {
+        case T128x128_1: conv64_launch_tile<TI, TO, 128, 128, 2, 2, 0>(a, st); break;
+        case T128x128_2: conv64_launch_tile<TI, TO, 128, 128, 2, 2, 1>(a, st); break;
+        case T256x256_2: conv64_launch_tile<TI, TO, 256, 256, 2, 4, 1>(a, st); break;
+        case T128x256_1: conv64_launch_tile<TI, TO, 128, 256, 2, 2, 0>(a, st); break;
+        case T256x128_1: conv64_launch_tile<TI, TO, 256, 128, 2, 2, 0>(a, st); break;
+        case T256x128_2: conv64_launch_tile<TI, TO, 256, 128, 2, 2, 1>(a, st); break;
+        case T128x64_1: conv64_launch_tile<TI, TO, 128, 64, 4, 1, 0>(a, st); break;
+        default: conv64_launch_tile<TI, TO, 128, 64, 4, 1, 1>(a, st); break;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { osr_set_error("osr_conv2d_fwd(bk64): launch failed: %s", hipGetErrorString(e)); return OSR_ERR_LAUNCH; }
@@ -627,7 +669,7 @@ static osr_status conv64_launch(Conv64Args& a, hipStream_t st) {
 template <class TI>
 static osr_status cfrpn_fused_launch(Conv64Args& a, hipStream_t st) {
     a.tiles_n = 1;
-    if ((a.M + 255) / 256 >= big_tile_min_tiles() && a.K / 64 >= big_tile_min_nk()) {
+    if ((a.M + 255) / 256 >= rpn_big_min_tiles() && a.K / 64 >= 8) {
         a.two_stage = 1;
         a.tiles_m = (int)((a.M + 255) / 256);
         const size_t t_bytes = (size_t)256 * (256 + 8) * 2, stages = (size_t)2 * (256 + 256) * 128;
@@ -673,6 +715,7 @@ osr_status osr_conv64_run(const osr_conv_params* p, const void* in, const void* 
     a.div_wo = fastdiv_make((unsigned)p->wo);
     a.in_bytes = (unsigned)in_bytes; a.w_bytes = (unsigned)w_bytes;
     a.stem = (p->pad_mode == 1 && p->cin == 32) ? 1 : 0;
+    a.tap_minor = (!a.stem && p->kh * p->kw > 1) ? tap_minor_default() : 0;
     a.tiles_m = a.tiles_n = 0;
     a.tail_w = a.tail_b = nullptr; a.tail_deltas = a.tail_ctr = nullptr;
 #ifdef C64_STAMPS
@@ -716,6 +759,7 @@ extern "C" osr_status osr_cfrpn_head_fwd(const osr_conv_params* p, const void* i
     a.div_wo = fastdiv_make((unsigned)p->wo);
     a.in_bytes = (unsigned)in_bytes; a.w_bytes = (unsigned)w_bytes;
     a.stem = 0;
+    a.tap_minor = p->kh * p->kw > 1 ? tap_minor_default() : 0;
     a.tail_w = w_tail; a.tail_b = b_tail; a.tail_deltas = deltas; a.tail_ctr = ctr;
 #ifdef C64_STAMPS
     a.dbg = nullptr;

@@ -13,5 +13,5 @@ CMD="bench.py --steps 5 --warmup 2 --no-cpu-baseline --streams 1 --no-graph"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 $CMD > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o run -- python3 $CMD > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o run -- python3 $CMD > $OUT/pmc_write.log 2>&1
-python3 scripts/pmc_summary.py $OUT 8 > $OUT/traffic.json
+python3 scripts/pmc_summary.py $OUT ${PASSES:-9} > $OUT/traffic.json
 tail -2 $OUT/stats.log
