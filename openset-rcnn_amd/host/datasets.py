@@ -78,6 +78,20 @@ def register_opendet_voc_coco(root: str) -> None:
         register_voc_coco(split, os.path.join(root, "voc_coco"), split, 2007 if "2007" in split else 2012)
 
 
+def register_builtin_pascal_voc(root: str) -> None:
+    """The PASCAL VOC names the VOC-COCO yaml trains on and tests first ('voc_2007_train', 'voc_2012_trainval', 'voc_2007_test'):
+    detectron2 pre-registers them ([d2] data/datasets/builtin.py register_all_pascal_voc) as <root>/VOC{2007,2012} with the 20
+    VOC class names, which are the first 20 entries of VOC_COCO_CATEGORIES."""
+    names = list(VOC_COCO_CATEGORIES[:20])
+    for year, splits in ((2007, ("trainval", "train", "val", "test")), (2012, ("trainval", "train", "val"))):
+        for split in splits:
+            name, dirname = f"voc_{year}_{split}", os.path.join(root, f"VOC{year}")
+            DatasetCatalog.register(name, lambda d=dirname, s=split: load_voc_instances(d, s, names))
+            meta = MetadataCatalog.get(name)
+            meta.thing_classes, meta.dirname, meta.year, meta.split, meta.evaluator_type = list(names), dirname, year, split, "pascal_voc"
+            meta.thing_dataset_id_to_contiguous_id = {i: i for i in range(len(names))}
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # GraspNet open-set splits (COCO-format json): openset_rcnn/data/graspnet.py, graspnet_meta.py, custom.py:9-30
 # ---------------------------------------------------------------------------------------------------------------
@@ -146,7 +160,7 @@ def get_evaluator(cfg, dataset_name: str, output_folder=None):
         if not hasattr(meta, "thing_dataset_id_to_contiguous_id"):
             DatasetCatalog[dataset_name]()  # loading the json fills the category tables
         rev = {v: k for k, v in meta.thing_dataset_id_to_contiguous_id.items()}
-        return OpensetCOCOEvaluator(meta.json_file, GRASPNET_KNOWN_CATEGORIES, rev, max_dets_per_image=[10, 20, 30, 50, 100])
+        return OpensetCOCOEvaluator(meta.json_file, GRASPNET_KNOWN_CATEGORIES, rev, max_dets_per_image=[10, 20, 30, 50, 100], output_dir=output_folder)
     if getattr(meta, "evaluator_type", None) != "pascal_voc":
         raise NotImplementedError(f"no Evaluator for the dataset {dataset_name} with the type {getattr(meta, 'evaluator_type', None)}")
     return PascalVOCDetectionEvaluator(meta.dirname, meta.split, meta.thing_classes, cfg.MODEL.ROI_HEADS.NUM_KNOWN_CLASSES,

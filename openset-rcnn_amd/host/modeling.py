@@ -499,19 +499,25 @@ class GeneralizedRCNN(_EngineOwner):
             sd[k] = v
         self.load_state_dict(sd)
 
-    @torch.no_grad()
-    def losses_forward(self, batched_inputs: List[dict], generator: Optional[torch.Generator] = None) -> Dict[str, torch.Tensor]:
-        """The loss dict GeneralizedRCNN.forward returns in training mode ([d2]; train.py:189 trainer loop), forward values
-        only: loss_rpn_loc, loss_rpn_ctr, loss_box_reg, loss_iou, loss_dml, loss_cls. Each input dict carries "image" and
-        "instances" (gt_boxes: Boxes, gt_classes). Images must share one size (the trainer's batches are padded by the
-        caller). `generator` seeds the uniform keys that replace torch.randperm in the two samplers."""
-        eng = self.engine()
-        imgs = [x["image"] for x in batched_inputs]
+    def _stack_images(self, imgs: List[torch.Tensor]):
+        """One (N,3,H,W) device tensor for a list of CHW images: same-size uint8/float32 images are stacked as they are (the
+        fused normalise+pad kernel takes both); a ragged batch is padded bottom/right with the pixel mean, so that the
+        normalised padding is exactly zero, as ImageList.from_tensors does after normalisation ([d2])."""
         sizes = [(int(i.shape[-2]), int(i.shape[-1])) for i in imgs]
-        if len(set(sizes)) != 1:
-            raise ValueError("losses_forward needs images of one size; pad the batch first")
-        n, dev = len(imgs), self.device
-        batch = torch.stack([i.to(dev) for i in imgs])
+        if len(set(sizes)) == 1 and len(set(i.dtype for i in imgs)) == 1 and imgs[0].dtype in (torch.uint8, torch.float32):
+            return torch.stack([i.to(self.device) for i in imgs]), sizes
+        hm, wm = max(s[0] for s in sizes), max(s[1] for s in sizes)
+        batch = self.pixel_mean.to(self.device).float().expand(3, hm, wm).unsqueeze(0).repeat(len(imgs), 1, 1, 1)
+        for k, im in enumerate(imgs):
+            batch[k, :, : sizes[k][0], : sizes[k][1]] = im.to(self.device).float()
+        return batch, sizes
+
+    def _train_tensors(self, batched_inputs: List[dict], generator: Optional[torch.Generator] = None):
+        """The tensors a training iteration consumes: stacked images, their true sizes, the padded size, ground truth padded to
+        the batch maximum, and the uniform keys that replace torch.randperm in the two samplers (seeded by `generator`)."""
+        eng = self.engine()
+        batch, sizes = self._stack_images([x["image"] for x in batched_inputs])
+        n, dev = len(sizes), self.device
         gmax = max(1, max(len(x["instances"]) for x in batched_inputs))
         gt = torch.zeros((n, gmax, 4), dtype=torch.float32)
         gcls = torch.zeros((n, gmax), dtype=torch.int64)
@@ -523,7 +529,8 @@ class GeneralizedRCNN(_EngineOwner):
                 gt[i, :k] = x["instances"].gt_boxes.tensor.float().cpu()
                 gcls[i, :k] = x["instances"].gt_classes.cpu()
         d = eng.cfg["size_divisibility"]
-        hp, wp = (sizes[0][0] + d - 1) // d * d, (sizes[0][1] + d - 1) // d * d
+        hm, wm = int(batch.shape[-2]), int(batch.shape[-1])
+        hp, wp = (hm + d - 1) // d * d, (wm + d - 1) // d * d
         shapes = [((hp // s), (wp // s)) for s in eng.cfg["fpn_strides"][:4]]
         shapes.append(((shapes[-1][0] - 1) // 2 + 1, (shapes[-1][1] - 1) // 2 + 1))
         r = sum(a * b for a, b in shapes)
@@ -531,30 +538,36 @@ class GeneralizedRCNN(_EngineOwner):
         keys = {k: torch.rand(shape, generator=generator).to(dev) for k, shape in
                 (("rpn_reg", (n, r)), ("rpn_obj", (n, r)), ("roi", (n, cap + gmax)))}
         hw = torch.tensor(sizes, dtype=torch.int32, device=dev)
-        out = eng.forward_losses(batch, hw, hp, wp, gt.to(dev), gcls.to(dev), gcnt.to(dev), keys)
+        return batch, hw, hp, wp, gt.to(dev), gcls.to(dev), gcnt.to(dev), keys
+
+    @torch.no_grad()
+    def losses_forward(self, batched_inputs: List[dict], generator: Optional[torch.Generator] = None) -> Dict[str, torch.Tensor]:
+        """The loss dict GeneralizedRCNN.forward returns in training mode ([d2]; train.py:189 trainer loop), forward values
+        only: loss_rpn_loc, loss_rpn_ctr, loss_box_reg, loss_iou, loss_dml, loss_cls. Each input dict carries "image" and
+        "instances" (gt_boxes: Boxes, gt_classes); a ragged batch is padded to its largest image. `generator` seeds the
+        uniform keys that replace torch.randperm in the two samplers."""
+        out = self.engine().forward_losses(*self._train_tensors(batched_inputs, generator))
+        return {k: v for k, v in out.items() if k.startswith("loss_")}
+
+    @torch.no_grad()
+    def train_step(self, trainer, batched_inputs: List[dict], generator: Optional[torch.Generator] = None) -> Dict[str, torch.Tensor]:
+        """One iteration of train.py:132-148 on the trainer made by make_trainer(): forward, explicit backward, gradient
+        all-reduce over the ranks and the SGD update; returns the loss dict (GPU scalars, this rank's values)."""
+        out = trainer.step(*self._train_tensors(batched_inputs, generator))
         return {k: v for k, v in out.items() if k.startswith("loss_")}
 
     @torch.no_grad()
     def inference(self, batched_inputs: List[dict], do_postprocess: bool = True):
         eng = self.engine()
-        imgs = [x["image"] for x in batched_inputs]
-        sizes = [(int(i.shape[-2]), int(i.shape[-1])) for i in imgs]
-        if len(set(sizes)) == 1 and len(set(i.dtype for i in imgs)) == 1 and imgs[0].dtype in (torch.uint8, torch.float32):
-            batch = torch.stack([i.to(self.device) for i in imgs])  # fused normalise+pad on the device
-            res = eng.forward(batch, sizes)
-        else:  # ragged batch: pad with the pixel mean so that the normalised padding is exactly zero
-            hm, wm = max(s[0] for s in sizes), max(s[1] for s in sizes)
-            batch = self.pixel_mean.to(self.device).float().expand(3, hm, wm).unsqueeze(0).repeat(len(imgs), 1, 1, 1)
-            for k, im in enumerate(imgs):
-                batch[k, :, : sizes[k][0], : sizes[k][1]] = im.to(self.device).float()
-            res = eng.forward(batch, sizes)
+        batch, sizes = self._stack_images([x["image"] for x in batched_inputs])
+        res = eng.forward(batch, sizes)
         if do_postprocess:  # [d2] detector_postprocess on the device: rescale, clip, drop empties
             outs = [(int(inp.get("height", s[0])), int(inp.get("width", s[1]))) for inp, s in zip(batched_inputs, sizes)]
             scale = torch.tensor([[ow / s[1], oh / s[0]] for (oh, ow), s in zip(outs, sizes)], dtype=torch.float32, device=self.device)
             res = ops.detector_postprocess(res[0], res[1], res[2], res[3], scale, torch.tensor(outs, dtype=torch.int32, device=self.device))
         else:
             outs = sizes
-        insts = OpensetRCNNEngine.to_instances(res, len(imgs))
+        insts = OpensetRCNNEngine.to_instances(res, len(sizes))
         return [{"instances": Instances(o, pred_boxes=Boxes(r["pred_boxes"]), scores=r["scores"], pred_classes=r["pred_classes"])}
                 for r, o in zip(insts, outs)]
 

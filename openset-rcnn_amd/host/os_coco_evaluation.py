@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import copy
 import json
+import os
 from collections import defaultdict
 from typing import Dict, List, Optional, Sequence
 
@@ -323,7 +324,7 @@ class OpensetCOCOEvaluator:
     json; known_names select the known categories, everything else is "unknown"."""
 
     def __init__(self, gt_json, known_names: Sequence[str], contiguous_to_dataset_id: Optional[Dict[int, int]] = None,
-                 max_dets_per_image: Sequence[int] = (10, 20, 30, 50, 100)):
+                 max_dets_per_image: Sequence[int] = (10, 20, 30, 50, 100), output_dir: Optional[str] = None):
         if isinstance(gt_json, str):
             with open(gt_json) as f:
                 gt_json = json.load(f)
@@ -332,6 +333,7 @@ class OpensetCOCOEvaluator:
         self.known_ids = sorted(c["id"] for c in gt_json["categories"] if c["name"] in names)
         self.reverse_id_map = contiguous_to_dataset_id
         self.max_dets = list(max_dets_per_image)
+        self.output_dir = output_dir
         self.reset()
 
     def reset(self):
@@ -341,14 +343,36 @@ class OpensetCOCOEvaluator:
         for inp, out in zip(inputs, outputs):
             self._predictions += instances_to_coco_json(out["instances"], inp["image_id"], self.reverse_id_map)
 
-    def evaluate(self, img_ids=None):
-        gathered = parallel.gather_to_rank0(self._predictions)
-        if gathered is None:
-            return None
-        dets = [d for part in gathered for d in part]
+    RESULTS_FILE = "coco_instances_results.json"
+
+    def evaluate(self, img_ids=None, resume: bool = False):
+        """Rank 0 gathers every rank's detections, writes them to <output_dir>/coco_instances_results.json
+        (os_coco_evaluation.py:259-263) and scores them; `resume=True` scores that file instead of new detections
+        (train.py --resume_test, os_coco_evaluation.py:156-190). The known / unknown precision and recall arrays are saved
+        next to it (:428-431)."""
+        if resume:
+            if self.output_dir is None:
+                raise ValueError("resume=True needs output_dir (where a previous run wrote its detections)")
+            if parallel.world_info()[0] != 0:
+                return None
+            with open(os.path.join(self.output_dir, self.RESULTS_FILE)) as f:
+                dets = json.load(f)
+        else:
+            gathered = parallel.gather_to_rank0(self._predictions)
+            if gathered is None:
+                return None
+            dets = [d for part in gathered for d in part]
+            if self.output_dir:
+                os.makedirs(self.output_dir, exist_ok=True)
+                with open(os.path.join(self.output_dir, self.RESULTS_FILE), "w") as f:
+                    json.dump(dets, f)
         if not dets:
             return {"bbox": {m: float("nan") for m in METRICS}}
         ev = OpensetCOCOEval(copy.deepcopy(self.gt), dets, self.known_ids, self.max_dets, img_ids)
         ev.evaluate()
         ev.accumulate()
+        if self.output_dir:
+            for tag, e in (("known", ev.eval_kdt), ("unknown", ev.eval_unkdt)):
+                np.save(os.path.join(self.output_dir, f"{tag}_precision_bbox.npy"), e["precision"])
+                np.save(os.path.join(self.output_dir, f"{tag}_recall_bbox.npy"), e["recall"])
         return derive_results(ev.summarize())

@@ -320,6 +320,16 @@ class OpensetRCNNTrainer:
             self._update(self.all_reduce_grads())
         return losses
 
+    def export_optimizer_state(self) -> Dict[str, torch.Tensor]:
+        """Momentum buffers (CPU copies) for a checkpoint that is resumed exactly ([d2] checkpoints carry the optimizer state)."""
+        return {k: v.detach().cpu().clone() for k, v in self.mom.items()}
+
+    def load_optimizer_state(self, state: Dict[str, torch.Tensor]) -> None:
+        for k, v in state.items():
+            if k not in self.mom or tuple(self.mom[k].shape) != tuple(v.shape):
+                raise KeyError(f"optimizer state {k}: not a momentum buffer of this trainer")
+            self.mom[k].copy_(v.to(self.mom[k].device))
+
     def export_state_dict(self) -> Dict[str, torch.Tensor]:
         """The trainable parameters under detectron2 names and layouts (un-folded conv weights), for load_state_dict /
         checkpointing ([d2] DetectionCheckpointer writes these keys under "model")."""
