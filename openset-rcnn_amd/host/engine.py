@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from . import ops
@@ -279,9 +281,15 @@ class OpensetRCNNEngine:
         start.record(cur)
         outs = []
         base, extra = divmod(n, ns)
+        sizes = [base + (1 if i < extra else 0) for i in range(ns)]
+        split = os.environ.get("OSR_MB_SPLIT")  # experiment knob: explicit micro-batch sizes, e.g. "10,6"
+        if split:
+            req = [int(x) for x in split.split(",")]
+            if len(req) == ns and sum(req) == n and min(req) > 0:
+                sizes = req
         lo = 0
         for i in range(ns):
-            hi = lo + base + (1 if i < extra else 0)
+            hi = lo + sizes[i]
             st = self._streams[i]
             st.wait_event(start)
             with torch.cuda.stream(st):
