@@ -18,8 +18,8 @@
 // loop, and table overflow (bins wider than 13 px) the per-sample 4-tap loop.
 #include "osr_common.h"
 
-#define RA_MAXC 16  // table columns per bin
-#define RA_MAXX 64  // columns of the whole RoI footprint handled by the column-sum path
+#define RA_MAXC 64  // table columns per bin (a 1333 px wide box on p2: 336 / 7 + 2 columns per bin)
+#define RA_MAXX 352 // columns of the whole RoI footprint handled by the column-sum path (p2 of a 1344 px wide batch: 336)
 
 struct RoiAlignArgs {
     const void* data[4];
@@ -167,17 +167,149 @@ struct RaWaveLds {
     float colw[3][RA_MAXX];  // weight of the column in bins colb, colb+1, colb+2
 };
 
-// One wave per RoI (4 RoIs per 256-thread workgroup, no workgroup barriers). The wave builds the per-axis weight
-// tables in its private LDS slice, then walks the 7 bin rows; per bin row it streams the footprint columns left to
-// right, both half-waves taking alternate feature rows, RA_G columns (= up to 3*RA_G 16-byte loads per lane) in
-// flight at a time, and keeps a 3-bin sliding window of accumulators in registers.
-#define RA_G 2
+#ifndef RA_WPB
+#define RA_WPB 4  // waves (= RoIs) per workgroup (1, 2 and 4 measured within 1.5 % end to end: RoI cost varies ~10x with
+                  // the footprint, but the slots a finished wave leaves idle inside a workgroup turned out not to matter)
+#endif
+#ifndef RA_PG
+#define RA_PG 1    // columns per pipelined step
+#endif
+
+// One bin of the inner axis of one RoI for this lane's 4 channels, streamed along the outer axis, software pipelined: while the RA_PG steps of one
+// step are reduced, the loads of the next step are already in flight (two register sets, used alternately). NY (rows of the
+// bin row's footprint, wave-uniform) is a template parameter so that every step issues the same number of loads and the
+// compiler can place counted waits; columns past the footprint re-read its last column (a cache hit) instead of branching.
+// Same arithmetic, in the same order, as the un-pipelined loop.
+template <int NY, class TI, class TO>
+__device__ __forceinline__ void ra_bin_row(const TI* __restrict__ rp, size_t rowstride, size_t sstride, int ncol, const RaWaveLds& S,
+                                           const float (&wy)[6], float inv_count, TO* __restrict__ outrow, size_t ostride, bool cok, int P) {
+    float a0[4], a1[4], a2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a0[k] = 0.f; a1[k] = 0.f; a2[k] = 0.f; }
+    int bcur = 0;
+    Raw4<TI> va[RA_PG][NY], vb[RA_PG][NY];
+#define RA_ISSUE(v, xg_)                                                                                   \
+    {                                                                                                      \
+        _Pragma("unroll") for (int g2 = 0; g2 < RA_PG; ++g2) {                                             \
+            const int col_ = (xg_) + g2 < ncol ? (xg_) + g2 : ncol - 1;                                    \
+            const TI* cp_ = rp + (size_t)col_ * sstride;                                                   \
+            _Pragma("unroll") for (int j = 0; j < NY; ++j) v[g2][j].load(cp_ + j * rowstride);             \
+        }                                                                                                  \
+    }
+#define RA_FLUSH2()                                                                                        \
+    {                                                                                                      \
+        float tot[4];                                                                                      \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                    \
+            tot[k] = a0[k] * inv_count;                                                                    \
+            a0[k] = a1[k]; a1[k] = a2[k]; a2[k] = 0.f;                                                     \
+        }                                                                                                  \
+        if (cok) store4<TO>(outrow + (size_t)bcur * ostride, tot);                                         \
+        ++bcur;                                                                                            \
+    }
+#define RA_CONSUME(v, xg_)                                                                                 \
+    {                                                                                                      \
+        _Pragma("unroll") for (int g2 = 0; g2 < RA_PG; ++g2) {                                             \
+            if ((xg_) + g2 < ncol) {                                                                       \
+                const int x = (xg_) + g2;                                                                  \
+                const int cbx = __builtin_amdgcn_readfirstlane(S.colb[x]);                                 \
+                while (bcur < cbx) RA_FLUSH2();                                                            \
+                float cs[4] = {0.f, 0.f, 0.f, 0.f}, f[4];                                                  \
+                _Pragma("unroll") for (int j = 0; j < NY; ++j) {                                           \
+                    v[g2][j].get(f);                                                                       \
+                    _Pragma("unroll") for (int k = 0; k < 4; ++k) cs[k] = __builtin_fmaf(wy[j], f[k], cs[k]); \
+                }                                                                                          \
+                const float w0 = S.colw[0][x], w1 = S.colw[1][x], w2 = S.colw[2][x];                       \
+                _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                            \
+                    a0[k] = __builtin_fmaf(w0, cs[k], a0[k]);                                              \
+                    a1[k] = __builtin_fmaf(w1, cs[k], a1[k]);                                              \
+                    a2[k] = __builtin_fmaf(w2, cs[k], a2[k]);                                              \
+                }                                                                                          \
+            }                                                                                              \
+        }                                                                                                  \
+    }
+    RA_ISSUE(va, 0);
+    for (int xg = 0; xg < ncol; xg += 2 * RA_PG) {
+        RA_ISSUE(vb, xg + RA_PG);
+        RA_CONSUME(va, xg);
+        RA_ISSUE(va, xg + 2 * RA_PG);
+        RA_CONSUME(vb, xg + RA_PG);
+    }
+    while (bcur < P) RA_FLUSH2();
+#undef RA_ISSUE
+#undef RA_CONSUME
+#undef RA_FLUSH2
+}
+
+// The same bin row when its footprint is taller than 6 feature rows (tall boxes: up to H / 7 + 2 rows per bin): the column sum
+// runs over the rows in chunks of 6 loads in flight, row weights come from the LDS table.
 template <class TI, class TO>
-__global__ __launch_bounds__(256) void roi_align_kernel(RoiAlignArgs a) {
-    __shared__ RaWaveLds s_all[4];
+__device__ __forceinline__ void ra_bin_row_tall(const TI* __restrict__ rp, size_t rowstride, size_t sstride, int ncol, const RaWaveLds& S,
+                                                const float* wrow, int ny, float inv_count, TO* __restrict__ outrow, size_t ostride, bool cok, int P) {
+    float a0[4], a1[4], a2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a0[k] = 0.f; a1[k] = 0.f; a2[k] = 0.f; }
+    int bcur = 0;
+    for (int x = 0; x < ncol; ++x) {
+        const int cbx = __builtin_amdgcn_readfirstlane(S.colb[x]);
+        while (bcur < cbx) {
+            float tot[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { tot[k] = a0[k] * inv_count; a0[k] = a1[k]; a1[k] = a2[k]; a2[k] = 0.f; }
+            if (cok) store4<TO>(outrow + (size_t)bcur * ostride, tot);
+            ++bcur;
+        }
+        const TI* cp = rp + (size_t)x * sstride;
+        float cs[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j0 = 0; j0 < ny; j0 += 6) {
+            Raw4<TI> v[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (j0 + j < ny) v[j].load(cp + (size_t)(j0 + j) * rowstride);
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (j0 + j < ny) {
+                    float f[4];
+                    v[j].get(f);
+                    const float wj = wrow[j0 + j];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) cs[k] = __builtin_fmaf(wj, f[k], cs[k]);
+                }
+        }
+        const float w0 = S.colw[0][x], w1 = S.colw[1][x], w2 = S.colw[2][x];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a0[k] = __builtin_fmaf(w0, cs[k], a0[k]);
+            a1[k] = __builtin_fmaf(w1, cs[k], a1[k]);
+            a2[k] = __builtin_fmaf(w2, cs[k], a2[k]);
+        }
+    }
+    while (bcur < P) {
+        float tot[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { tot[k] = a0[k] * inv_count; a0[k] = a1[k]; a1[k] = a2[k]; a2[k] = 0.f; }
+        if (cok) store4<TO>(outrow + (size_t)bcur * ostride, tot);
+        ++bcur;
+    }
+}
+
+// One wave per RoI (RA_WPB RoIs per workgroup, no workgroup barriers). The wave builds the per-axis weight tables in its
+// private LDS slice, picks the shorter side of the footprint as the streamed axis, and then, for each of the 7 bins of the
+// other axis, walks the footprint one pixel column (or row) at a time: the pixels of the step that fall into the bin are
+// reduced with the bin's weights (software pipelined, the next step's loads in flight) and the sum goes into a 3-bin
+// sliding window of register accumulators along the streamed axis.
+template <class TI, class TO>
+__global__ __launch_bounds__(RA_WPB * 64) void roi_align_kernel(RoiAlignArgs a) {
+    __shared__ RaWaveLds s_all[RA_WPB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long long r = (long long)blockIdx.x * 4 + wid;
+    // XCD-aware order: workgroup b runs on XCD b % 8, so each XCD walks one contiguous eighth of the RoI list and RoIs that are
+    // neighbours in the list (and, when the list is spatially ordered, in the image) share an L2
+    long long r;
+    {
+        const int nwg = gridDim.x, bq = blockIdx.x, q = nwg >> 3, rr = nwg & 7, xcd = bq & 7, idx = bq >> 3;
+        const int t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+        r = (long long)t * RA_WPB + wid;
+    }
     if (r >= a.m) return;
     RaWaveLds& S = s_all[wid];
     const int P = a.pooled, C = a.c;
@@ -211,8 +343,11 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiAlignArgs a) {
 
     // ---- per-axis weight tables: entry (axis, bin, col) sums the samples that touch its column ----
     bool overflow = false;
-    for (int e = lane; e < 2 * 7 * RA_MAXC; e += 64) {
-        const int axis = e / (7 * RA_MAXC), bin = (e / RA_MAXC) % 7, col = e % RA_MAXC;
+    // (a bin's samples span its width + 1 pixels, so only the first max(gh, gw) + 3 table columns can be non-zero and only
+    // those are ever read: build just them)
+    const int tcols = min(RA_MAXC, max(max(gh, gw), 1) + 3);
+    for (int e = lane; e < 2 * 7 * tcols; e += 64) {
+        const int axis = e / (7 * tcols), bin = (e / tcols) % 7, col = e % tcols;
         if (bin >= P) continue;
         const float start = axis ? sw : sh, bs = axis ? bw : bh;
         const int grid = axis ? gw : gh, size = axis ? W : H;
@@ -231,105 +366,99 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiAlignArgs a) {
             const int n = first < 0 ? 0 : last - first + 1;
             S.lo[axis][bin] = first < 0 ? 0 : first;
             S.n[axis][bin] = n;
-            overflow |= n > RA_MAXC;
+            overflow |= n > tcols;
         }
     }
     const bool fallback = __any(overflow);
     ra_wave_sync();
 
-    // ---- column-sum fast path precondition (checked by lanes 0..P-1, one bin each) ----
-    bool bad = fallback;
-    int xs_l = 0x7fffffff, xe_l = 0;
+    // ---- streaming fast path. The footprint is walked along one axis (the "outer" axis, one step per pixel column or row);
+    //      per step the pixels of the other ("inner") axis that fall into the current bin are reduced with the bin's weights,
+    //      and the result is scattered into a 3-bin sliding window of accumulators along the outer axis. The outer axis is
+    //      the SHORTER side of the footprint: a step costs ~35 instructions however few pixels it reduces, and the proposals
+    //      are 2-10x wider than tall (or the reverse) often enough that streaming the long side doubled the kernel's time.
+    //      Preconditions (checked by lanes 0..P-1, one bin each, for both axes): bins ordered, no holes, no pixel in more
+    //      than three consecutive bins. ----
+    bool bad[2] = {fallback, fallback};
+    int lo_l[2] = {0x7fffffff, 0x7fffffff}, hi_l[2] = {0, 0};
     if (lane < P) {
-        const int lo = S.lo[1][lane], n = S.n[1][lane];
-        if (n > 0) { xs_l = lo; xe_l = lo + n; }
-        if (lane + 1 < P && n > 0 && S.n[1][lane + 1] > 0 && S.lo[1][lane + 1] < lo) bad = true;
-        if (lane + 3 < P && n > 0 && S.n[1][lane + 3] > 0 && S.lo[1][lane + 3] < lo + n) bad = true;
-        if (lane + 1 < P && lane > 0 && n == 0 && S.n[1][lane - 1] > 0 && S.n[1][lane + 1] > 0) bad = true;  // hole: not expected
-        if (S.n[0][lane] > 6) bad = true;
+#pragma unroll
+        for (int ax = 0; ax < 2; ++ax) {
+            const int lo = S.lo[ax][lane], n = S.n[ax][lane];
+            if (n > 0) { lo_l[ax] = lo; hi_l[ax] = lo + n; }
+            if (lane + 1 < P && n > 0 && S.n[ax][lane + 1] > 0 && S.lo[ax][lane + 1] < lo) bad[ax] = true;
+            if (lane + 3 < P && n > 0 && S.n[ax][lane + 3] > 0 && S.lo[ax][lane + 3] < lo + n) bad[ax] = true;
+            if (lane + 1 < P && lane > 0 && n == 0 && S.n[ax][lane - 1] > 0 && S.n[ax][lane + 1] > 0) bad[ax] = true;  // hole: not expected
+        }
     }
 #pragma unroll
-    for (int d = 1; d < 8; d <<= 1) {
-        xs_l = min(xs_l, __shfl_xor(xs_l, d, 64));
-        xe_l = max(xe_l, __shfl_xor(xe_l, d, 64));
+    for (int ax = 0; ax < 2; ++ax)
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) {
+            lo_l[ax] = min(lo_l[ax], __shfl_xor(lo_l[ax], d, 64));
+            hi_l[ax] = max(hi_l[ax], __shfl_xor(hi_l[ax], d, 64));
+        }
+    int ext_lo[2], ext_n[2];
+    bool ax_ok[2];
+#pragma unroll
+    for (int ax = 0; ax < 2; ++ax) {
+        const int l = __builtin_amdgcn_readfirstlane(lo_l[ax]), h = __builtin_amdgcn_readfirstlane(hi_l[ax]);
+        ext_lo[ax] = l == 0x7fffffff ? 0 : l;
+        ext_n[ax] = l == 0x7fffffff ? 0 : h - l;
+        ax_ok[ax] = !__any(bad[ax]) && ext_n[ax] <= RA_MAXX;
     }
-    int xs = __builtin_amdgcn_readfirstlane(xs_l), xe = __builtin_amdgcn_readfirstlane(xe_l);
-    if (xs == 0x7fffffff) xs = 0;
-    const int ncol = xe - xs;
-    const bool win_ok = !__any(bad) && ncol <= RA_MAXX;
+    // outer (streamed) axis: the shorter side when its preconditions hold, else the other one
+#ifndef RA_AXIS_SELECT
+#define RA_AXIS_SELECT 1
+#endif
+    int oa = (!RA_AXIS_SELECT || ext_n[1] <= ext_n[0]) ? 1 : 0;
+    if (!ax_ok[oa]) oa ^= 1;
 
-    if (win_ok) {
-        if (lane < ncol) {  // per-column table
-            const int x = xs + lane;
+    if (ax_ok[oa]) {
+        const int ia = oa ^ 1;
+        const int os = ext_lo[oa], nstep = ext_n[oa];
+        for (int sl = lane; sl < nstep; sl += 64) {  // per-step table: first unfinished bin of this outer pixel + its weights in 3 bins
+            const int x = os + sl;
             int cb = 0;
-            while (cb < P && (S.n[1][cb] == 0 || x >= S.lo[1][cb] + S.n[1][cb])) ++cb;
-            S.colb[lane] = cb;
+            while (cb < P && (S.n[oa][cb] == 0 || x >= S.lo[oa][cb] + S.n[oa][cb])) ++cb;
+            S.colb[sl] = cb;
 #pragma unroll
             for (int t2 = 0; t2 < 3; ++t2) {
                 const int bb = cb + t2;
                 float wv = 0.f;
-                if (bb < P) { const int i = x - S.lo[1][bb]; if (i >= 0 && i < S.n[1][bb]) wv = S.w[1][bb][i]; }
-                S.colw[t2][lane] = wv;
+                if (bb < P) { const int i = x - S.lo[oa][bb]; if (i >= 0 && i < S.n[oa][bb]) wv = S.w[oa][bb][i]; }
+                S.colw[t2][sl] = wv;
             }
         }
         ra_wave_sync();
         const float inv_count = 1.0f / count;
         const size_t rowstride = (size_t)W * C;
-        for (int ph = 0; ph < P; ++ph) {
-            const int y0 = __builtin_amdgcn_readfirstlane(S.lo[0][ph]), ny = __builtin_amdgcn_readfirstlane(S.n[0][ph]);
-            float wy[6];  // wave-uniform row weights (live in scalar registers)
+        // element strides of one step along the inner / outer axis, and between two consecutive output bins of the outer axis
+        const size_t istride = ia == 0 ? rowstride : (size_t)C, sstride = ia == 0 ? (size_t)C : rowstride;
+        const size_t ostride = oa == 1 ? (size_t)C : (size_t)P * C;
+        for (int pb = 0; pb < P; ++pb) {  // bins along the inner axis
+            const int i0 = __builtin_amdgcn_readfirstlane(S.lo[ia][pb]), ni = __builtin_amdgcn_readfirstlane(S.n[ia][pb]);
+            float wi[6];  // wave-uniform inner weights (live in scalar registers)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) wy[j] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(j < ny ? S.w[0][ph][j] : 0.f)));
+            for (int j = 0; j < 6; ++j) wi[j] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(j < ni ? S.w[ia][pb][j] : 0.f)));
             for (int cb0 = 0; cb0 < C; cb0 += 256) {
                 const int c0 = cb0 + lane * 4;
                 const bool cok = c0 < C;
-                const TI* rp = feat + ((size_t)y0 * W + xs) * C + (cok ? c0 : 0);
-                float a0[4], a1[4], a2[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { a0[k] = 0.f; a1[k] = 0.f; a2[k] = 0.f; }
-                int bcur = 0;
-#define RA_FLUSH()                                                                                        \
-                {                                                                                         \
-                    float tot[4];                                                                         \
-                    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                       \
-                        tot[k] = a0[k] * inv_count;                                                       \
-                        a0[k] = a1[k]; a1[k] = a2[k]; a2[k] = 0.f;                                        \
-                    }                                                                                     \
-                    if (cok) store4<TO>(out + (size_t)(ph * P + bcur) * C + c0, tot);                     \
-                    ++bcur;                                                                               \
-                }
-                for (int xg = 0; xg < ncol; xg += RA_G) {
-                    // issue every load of this column group before using any (memory-level parallelism)
-                    Raw4<TI> v[RA_G][6];
-#pragma unroll
-                    for (int g2 = 0; g2 < RA_G; ++g2) {
-                        const TI* cp = rp + (size_t)(xg + g2 < ncol ? xg + g2 : ncol - 1) * C;  // tail columns re-read the last one
-#pragma unroll
-                        for (int j = 0; j < 6; ++j)
-                            if (j < ny) v[g2][j].load(cp + j * rowstride);
-                    }
-#pragma unroll
-                    for (int g2 = 0; g2 < RA_G; ++g2) {
-                        if (xg + g2 < ncol) {
-                            const int x = xg + g2;
-                            const int cbx = __builtin_amdgcn_readfirstlane(S.colb[x]);
-                            while (bcur < cbx) RA_FLUSH();
-                            float cs[4] = {0.f, 0.f, 0.f, 0.f}, f[4];
-#pragma unroll
-                            for (int j = 0; j < 6; ++j)
-                                if (j < ny) { v[g2][j].get(f); _Pragma("unroll") for (int k = 0; k < 4; ++k) cs[k] = __builtin_fmaf(wy[j], f[k], cs[k]); }
-                            const float w0 = S.colw[0][x], w1 = S.colw[1][x], w2 = S.colw[2][x];
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                a0[k] = __builtin_fmaf(w0, cs[k], a0[k]);
-                                a1[k] = __builtin_fmaf(w1, cs[k], a1[k]);
-                                a2[k] = __builtin_fmaf(w2, cs[k], a2[k]);
-                            }
-                        }
+                const TI* rp = feat + (size_t)i0 * istride + (size_t)os * sstride + (cok ? c0 : 0);
+                TO* outrow = out + (size_t)pb * (oa == 1 ? (size_t)P * C : (size_t)C) + c0;
+                switch (nstep > 0 ? (ni > 6 ? 7 : ni) : 0) {  // (no step: the pipelined loop would have nothing valid to prefetch)
+                    case 1: ra_bin_row<1, TI, TO>(rp, istride, sstride, nstep, S, wi, inv_count, outrow, ostride, cok, P); break;
+                    case 2: ra_bin_row<2, TI, TO>(rp, istride, sstride, nstep, S, wi, inv_count, outrow, ostride, cok, P); break;
+                    case 3: ra_bin_row<3, TI, TO>(rp, istride, sstride, nstep, S, wi, inv_count, outrow, ostride, cok, P); break;
+                    case 4: ra_bin_row<4, TI, TO>(rp, istride, sstride, nstep, S, wi, inv_count, outrow, ostride, cok, P); break;
+                    case 5: ra_bin_row<5, TI, TO>(rp, istride, sstride, nstep, S, wi, inv_count, outrow, ostride, cok, P); break;
+                    case 6: ra_bin_row<6, TI, TO>(rp, istride, sstride, nstep, S, wi, inv_count, outrow, ostride, cok, P); break;
+                    case 7: ra_bin_row_tall<TI, TO>(rp, istride, sstride, nstep, S, S.w[ia][pb], ni, inv_count, outrow, ostride, cok, P); break;
+                    default: {  // no valid sample in this bin row / column: zeros
+                        const float z[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (cok) for (int q = 0; q < P; ++q) store4<TO>(outrow + (size_t)q * ostride, z);
                     }
                 }
-                while (bcur < P) RA_FLUSH();
-#undef RA_FLUSH
             }
         }
         return;
@@ -380,7 +509,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiAlignArgs a) {
 
 template <class TI>
 static osr_status launch_out(const RoiAlignArgs& a, int out_dtype, hipStream_t st) {
-    dim3 grid((unsigned)((a.m + 3) / 4)), block(256);
+    dim3 grid((unsigned)((a.m + RA_WPB - 1) / RA_WPB)), block(RA_WPB * 64);
     switch (out_dtype) {
         case OSR_F32: hipLaunchKernelGGL((roi_align_kernel<TI, float>), grid, block, 0, st, a); break;
         case OSR_F16: hipLaunchKernelGGL((roi_align_kernel<TI, f16_t>), grid, block, 0, st, a); break;
@@ -439,11 +568,18 @@ struct RoiAlignBwdArgs {
 };
 
 template <class TG>
-__global__ __launch_bounds__(256) void roi_align_bwd_kernel(RoiAlignBwdArgs a) {
-    __shared__ RaWaveLds s_all[4];
+__global__ __launch_bounds__(RA_WPB * 64) void roi_align_bwd_kernel(RoiAlignBwdArgs a) {
+    __shared__ RaWaveLds s_all[RA_WPB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long long r = (long long)blockIdx.x * 4 + wid;
+    // XCD-aware order: workgroup b runs on XCD b % 8, so each XCD walks one contiguous eighth of the RoI list and RoIs that are
+    // neighbours in the list (and, when the list is spatially ordered, in the image) share an L2
+    long long r;
+    {
+        const int nwg = gridDim.x, bq = blockIdx.x, q = nwg >> 3, rr = nwg & 7, xcd = bq & 7, idx = bq >> 3;
+        const int t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+        r = (long long)t * RA_WPB + wid;
+    }
     if (r >= a.m) return;
     RaWaveLds& S = s_all[wid];
     const int P = a.pooled, C = a.c;
@@ -466,8 +602,11 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(RoiAlignBwdArgs a) {
     const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
     const float count = (float)max(gh * gw, 1);
     bool overflow = false;
-    for (int e = lane; e < 2 * 7 * RA_MAXC; e += 64) {
-        const int axis = e / (7 * RA_MAXC), bin = (e / RA_MAXC) % 7, col = e % RA_MAXC;
+    // (a bin's samples span its width + 1 pixels, so only the first max(gh, gw) + 3 table columns can be non-zero and only
+    // those are ever read: build just them)
+    const int tcols = min(RA_MAXC, max(max(gh, gw), 1) + 3);
+    for (int e = lane; e < 2 * 7 * tcols; e += 64) {
+        const int axis = e / (7 * tcols), bin = (e / tcols) % 7, col = e % tcols;
         if (bin >= P) continue;
         const float start = axis ? sw : sh, bs = axis ? bw : bh;
         const int grid = axis ? gw : gh, size = axis ? W : H;
@@ -486,7 +625,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(RoiAlignBwdArgs a) {
             const int n = first < 0 ? 0 : last - first + 1;
             S.lo[axis][bin] = first < 0 ? 0 : first;
             S.n[axis][bin] = n;
-            overflow |= n > RA_MAXC;
+            overflow |= n > tcols;
         }
     }
     const bool fallback = __any(overflow);
@@ -558,7 +697,7 @@ extern "C" osr_status osr_roi_align_bwd(const osr_pyramid* dfeat, int32_t n, con
     a.pooled = pooled; a.canonical_level = canonical_level; a.canonical_size = canonical_size; a.min_level = min_level;
     a.dout = dout;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)((m + 3) / 4)), block(256);
+    dim3 grid((unsigned)((m + RA_WPB - 1) / RA_WPB)), block(RA_WPB * 64);
     switch (dout_dtype) {
         case OSR_F32: hipLaunchKernelGGL(roi_align_bwd_kernel<float>, grid, block, 0, st, a); break;
         case OSR_F16: hipLaunchKernelGGL(roi_align_bwd_kernel<f16_t>, grid, block, 0, st, a); break;

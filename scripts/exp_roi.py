@@ -61,3 +61,35 @@ torch.cuda.synchronize(); e0.record()
 for _ in range(10): run2()
 e1.record(); torch.cuda.synchronize()
 print("spatially sorted RoIs: %.3f ms" % (e0.elapsed_time(e1) / 10))
+# scaling experiment: the first k images' RoIs only (tail / launch effects show up as non-proportional times)
+cap = sel["boxes"].shape[1]
+for k in (1, 2, 4, 8, 16):
+    bk, bik = b[: k * cap].contiguous(), sel["batch_idx"].view(-1)[: k * cap].contiguous()
+    def runk():
+        return ops.roi_align(fl, (0.25, 0.125, 0.0625, 0.03125), bk, bik, 7, torch.float16)
+    for _ in range(3): runk()
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(10): runk()
+    e1.record(); torch.cuda.synchronize()
+    print("first %d image(s): %.3f ms" % (k, e0.elapsed_time(e1) / 10))
+# per-level cost: RoIs of one level only (others marked as padding)
+for L in (2, 3, 4, 5):
+    bil = torch.where(lvl == L, sel["batch_idx"].view(-1), torch.full_like(sel["batch_idx"].view(-1), -1))
+    def runl():
+        return ops.roi_align(fl, (0.25, 0.125, 0.0625, 0.03125), b, bil, 7, torch.float16)
+    for _ in range(3): runl()
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(10): runl()
+    e1.record(); torch.cuda.synchronize()
+    print("level %d only (%d RoIs): %.3f ms" % (L, int((bil >= 0).sum()), e0.elapsed_time(e1) / 10))
+# footprint statistics: column steps of the current streaming direction vs the transposed one
+sc = torch.tensor([0.25, 0.125, 0.0625, 0.03125], device=b.device)[(lvl - 2).long()]
+valid = sel["batch_idx"].view(-1) >= 0
+fw = ((b[:, 2] - b[:, 0]) * sc + 2)[valid]
+fh = ((b[:, 3] - b[:, 1]) * sc + 2)[valid]
+print("footprint cols mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f | rows mean %.1f p90 %.1f p99 %.1f max %.1f" % (
+    fw.mean(), fw.median(), fw.quantile(0.9), fw.quantile(0.99), fw.max(), fh.mean(), fh.quantile(0.9), fh.quantile(0.99), fh.max()))
+steps_now = 7 * fw
+steps_best = 7 * torch.minimum(fw, fh)
+loads = 7 * fw * (fh / 7 + 2)
+print("sum column steps now %.3g, with the shorter axis streamed %.3g (%.2fx); sum loads %.3g" % (steps_now.sum(), steps_best.sum(), steps_now.sum() / steps_best.sum(), loads.sum()))
