@@ -13,25 +13,17 @@
 #include "osr_common.h"
 #include <stdlib.h>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-#ifndef C64_COUNTED_FIRST_WAIT
-#define C64_COUNTED_FIRST_WAIT 0  // measured on one box: 13.34 ms (counted) vs 12.50 ms (wait for everything) per step
-#endif
-#ifndef C64_PRE_RES
-#define C64_PRE_RES 1
-#endif
-#ifndef C64_LEAN_SINGLE
-#define C64_LEAN_SINGLE 0  // no measurable difference (12.5 ms either way); kept as an experiment knob
-#endif
+// Fixed design choices, each measured against its alternative on one box (profiles/README.md):
+//  * the wait in front of the first K step waits for everything in flight (a counted wait that lets the bias / residual
+//    prefetch stay in flight was 6 % slower on the family);
+//  * v_mfma_f32_16x16x32 (four per 32x32 macro tile and 32-wide K step), 5-8 % faster here than v_mfma_f32_32x32x16;
+//  * two fragment register sets in every variant (a single set saved 32 VGPRs and nothing else).
 #ifndef C64_SINGLE_MINW
-#define C64_SINGLE_MINW 2
+#define C64_SINGLE_MINW 2  // waves per SIMD the single-buffer 128-wide kernels must allow (4 spills)
 #endif
 #ifndef C64_PSPREAD
-#define C64_PSPREAD 2
-#endif
-#ifndef C64_M16
-#define C64_M16 1  // 1: v_mfma_f32_16x16x32 (four per 32x32 macro tile and 32-wide K step), 0: v_mfma_f32_32x32x16
+#define C64_PSPREAD 2      // the staging pieces of the next K slice go out during the first 1/C64_PSPREAD of the MFMAs
 #endif
 typedef f16_t f16x8 __attribute__((ext_vector_type(8)));
 typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
@@ -39,12 +31,10 @@ typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
 template <class T> struct Frag64;
 template <> struct Frag64<f16_t> {
     typedef f16x8 type;
-    static __device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 template <> struct Frag64<bf16_t> {
     typedef bf16x8 type;
-    static __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 
@@ -248,10 +238,8 @@ __global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI !=
         }                                                                                             \
     }
 
-    // Accumulators of the wave's TM x TN macro tiles of 32 x 32. ACC(i,j,r) r=0..15 addresses them uniformly:
-    //   32x32x16 MFMA: one f32x16, element r at row (r&3)+8(r>>2)+4(lane>>5), column lane&31;
-    //   16x16x32 MFMA: four f32x4 sub-tiles [si][sj], element q at row si*16+(lane>>4)*4+q, column sj*16+(lane&15).
-#if C64_M16
+    // Accumulators of the wave's TM x TN macro tiles of 32 x 32, each four 16x16 sub-tiles [si][sj] (f32x4): element q sits at
+    // row si*16 + (lane>>4)*4 + q, column sj*16 + (lane&15). C64_ACC(i, j, r), r = 0..15, addresses them uniformly.
     f32x4 acc[TM][TN][2][2];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -262,29 +250,16 @@ __global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI !=
 #define C64_ACC(i, j, r) acc[i][j][((r) >> 3) & 1][((r) >> 2) & 1][(r) & 3]
 #define C64_ROW(r) ((((r) >> 3) & 1) * 16 + (lane >> 4) * 4 + ((r) & 3))
 #define C64_COL(r) ((((r) >> 2) & 1) * 16 + (lane & 15))
-#else
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#define C64_ACC(i, j, r) acc[i][j][r]
-#define C64_ROW(r) (((r) & 3) + 8 * ((r) >> 2) + 4 * (lane >> 5))
-#define C64_COL(r) (lane & 31)
-#endif
 
-    [[maybe_unused]] const int swz = ((lane & 31) >> 1) & 7;
     const int nk = a.K / 64;
     C64_ISSUE(0);
-    __builtin_amdgcn_sched_barrier(0);  // the loads below must stay younger than the slice-0 pieces (C64_FIRST_WAIT)
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- epilogue operands that do not depend on the accumulators are fetched now, under the K loop:
     //      this lane's bias values and (128x128 / 128x64 tiles) its residual segments, one 16-byte load per staged row ----
     constexpr int RPP = 8, NPASS = 4;               // 8 lanes x 8 channels cover the 64 staged columns; 8 rows per pass
     constexpr int TNP = TN / 2;                     // pairs of N tiles
-    constexpr bool PRE_RES = (TN == 2) && (TM <= 2) && (EPI == 0) && C64_PRE_RES;
+    constexpr bool PRE_RES = (TN == 2) && (TM <= 2) && (EPI == 0);
     const int cseg = (lane & 7) * 8;
     const TI* __restrict__ res = reinterpret_cast<const TI*>(a.res);
     float bias8[TNP][8];
@@ -293,7 +268,6 @@ __global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI !=
 #pragma unroll
         for (int jp = 0; jp < TNP; ++jp) {
             const int co = n0 + (wc * TN + jp * 2) * 32 + cseg;
-            // always issued (clamped address): the first K-loop wait counts these loads (C64_FIRST_WAIT)
             const int cb = co < p.cout ? co : 0;
             const float4 b0 = *reinterpret_cast<const float4*>(a.bias + cb);
             const float4 b1 = *reinterpret_cast<const float4*>(a.bias + cb + 4);
@@ -329,7 +303,6 @@ __global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI !=
             tbias[j][1] = a.bias[(wc * TN + j) * 32 + C64_COL(4)];
         }
     }
-#if C64_M16
     // 16x16x32: a fragment = 16 rows x 32 K; lane l holds row l&15, K chunk (l>>4) of the 32-wide step.
     // [set][tile][row half]; two 32-wide K steps per 64-wide slice, the second one's fragments are read under the first one's MFMAs.
 #define C64_LOAD_FRAGS(set, k32_)                                                                                                   \
@@ -348,16 +321,14 @@ __global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI !=
     constexpr int NMFMA = 2 * TM * TN * 4, NPIECE = A_PIECES + B_PIECES;
     constexpr int PSTEP = (NMFMA / C64_PSPREAD) / NPIECE > 0 ? (NMFMA / C64_PSPREAD) / NPIECE : 1;  // pieces go out in the first 1/C64_PSPREAD of the slice
     static_assert(PSTEP >= 1, "more staging pieces than MFMAs per K slice");
-    // fragment register sets: the double-buffered (MFMA-bound) kernels read the second 32-wide step's fragments under the first
-    // step's MFMAs; the single-buffer (latency-bound) kernels keep one set and trade that overlap for 32 fewer VGPRs
-    constexpr int FSETS = (TWO || !C64_LEAN_SINGLE) ? 2 : 1;
+    // two fragment register sets: the second 32-wide step's fragments are read under the first step's MFMAs
+    constexpr int FSETS = 2;
 #define C64_KSLICE(ISSUE, nstage)                                                                                                   \
     {                                                                                                                               \
         frag_t fa[FSETS][TM][2], fb[FSETS][TN][2];                                                                                  \
         C64_LOAD_FRAGS(0, 0);                                                                                                       \
         _Pragma("unroll") for (int k32 = 0; k32 < 2; ++k32) {                                                                       \
-            if (FSETS == 2) { if (k32 < 1) C64_LOAD_FRAGS(1, 1); }                                                                  \
-            else if (k32 == 1) C64_LOAD_FRAGS(0, 1);                                                                                \
+            if (k32 < 1) C64_LOAD_FRAGS(1, 1);                                                                                      \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                          \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                      \
                     _Pragma("unroll") for (int si = 0; si < 2; ++si)                                                                \
@@ -373,17 +344,7 @@ __global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI !=
                         }                                                                                                           \
         }                                                                                                                           \
     }
-    // The first wait covers only the slice-0 pieces: the bias / residual loads issued after them (consumed in the epilogue)
-    // stay in flight under the K loop. vmcnt counts in issue order, so "all but the youngest N" is exactly that.
-#define C64_FIRST_WAIT()                                                                         \
-    {                                                                                            \
-        if constexpr (EPI == 0 && C64_COUNTED_FIRST_WAIT) {                                                                \
-            if (PRE_RES && p.res_mode != 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TNP * 2 + (PRE_RES ? TM * NPASS : 0)) : "memory"); \
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TNP * 2) : "memory");                  \
-        } else {                                                                                 \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
-        }                                                                                        \
-    }
+#define C64_FIRST_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
     if constexpr (TWO) {
         for (int ks = 0; ks < nk; ++ks) {
             if (ks == 0) { C64_FIRST_WAIT(); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -414,39 +375,6 @@ __global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI !=
     }
 #undef C64_KSLICE
 #undef C64_LOAD_FRAGS
-#else
-    for (int ks = 0; ks < nk; ++ks) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // tile ks landed for every wave; every wave is done reading the other stage
-        if (TWO && ks + 1 < nk) { C64_ADVANCE(); C64_ISSUE((ks + 1) & 1); }
-        const unsigned char* sa = lds + (TWO ? (ks & 1) : 0) * STAGE;
-        const unsigned char* sb = sa + BM * 128;
-        frag_t fa[2][TM], fb[2][TN];
-#define C64_LOAD_FRAGS(set, kk_)                                                                                                    \
-        {                                                                                                                           \
-            const int sl_ = (((kk_) * 2 + (lane >> 5)) ^ swz) * 16;                                                                 \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                          \
-                fa[set][i] = *reinterpret_cast<const frag_t*>(sa + ((wr * TM + i) * 32 + (lane & 31)) * 128 + sl_);                 \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                          \
-                fb[set][j] = *reinterpret_cast<const frag_t*>(sb + ((wc * TN + j) * 32 + (lane & 31)) * 128 + sl_);                 \
-        }
-        C64_LOAD_FRAGS(0, 0);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            if (kk < 3) C64_LOAD_FRAGS((kk + 1) & 1, kk + 1);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = Frag64<TI>::mfma(fa[kk & 1][i], fb[kk & 1][j], acc[i][j]);
-        }
-#undef C64_LOAD_FRAGS
-        if (!TWO && ks + 1 < nk) {
-            __syncthreads();  // every wave has read the single staging buffer: refill it
-            C64_ADVANCE();
-            C64_ISSUE(0);
-        }
-    }
-#endif
     __syncthreads();  // all waves done with the staging buffers before the epilogue reuses them
     C64_STAMP(2);
 
@@ -574,7 +502,7 @@ static void allow_big_lds(K kernel) {
 }
 
 // Tile configurations of the plain conv / FC kernel.
-enum Conv64Tile { T128x128_1 = 1, T128x128_2, T256x256_2, T128x256_1, T256x128_1, T256x128_2, T128x64_1, T128x64_2 };
+enum Conv64Tile { T128x128_1 = 1, T128x128_2, T256x256_2, T128x256_1, T256x128_1, T128x64_1, T128x64_2 };
 static int force_tile() { static const int v = env_int("OSR_CONV_FORCE_TILE", 0); return v; }  // diagnostic: one configuration for every layer it fits
 
 template <class TI, class TO, int BM, int BN, int WM, int WN, int TWO>
@@ -628,8 +556,8 @@ static int conv64_pick_tile(const Conv64Args& a) {
     const bool res = a.p.res_mode != 0;
     const int f = force_tile();
     if (f != 0) {
-        const bool fits = (f == T256x256_2 || f == T128x256_1) ? cout % 256 == 0 : (f == T256x128_1 || f == T256x128_2) ? cout % 128 == 0 : true;
-        if (fits && !((f == T128x128_2 || f == T256x128_2 || f == T128x64_2 || f == T256x256_2) && nk < 2)) return f;
+        const bool fits = (f == T256x256_2 || f == T128x256_1) ? cout % 256 == 0 : f == T256x128_1 ? cout % 128 == 0 : true;
+        if (fits && !((f == T128x128_2 || f == T128x64_2 || f == T256x256_2) && nk < 2)) return f;
     }
     int best = T128x128_1;
     double best_us = 1e30;
@@ -657,7 +585,6 @@ static osr_status conv64_launch(Conv64Args& a, hipStream_t st) {
         case T256x256_2: conv64_launch_tile<TI, TO, 256, 256, 2, 4, 1>(a, st); break;
         case T128x256_1: conv64_launch_tile<TI, TO, 128, 256, 2, 2, 0>(a, st); break;
         case T256x128_1: conv64_launch_tile<TI, TO, 256, 128, 2, 2, 0>(a, st); break;
-        case T256x128_2: conv64_launch_tile<TI, TO, 256, 128, 2, 2, 1>(a, st); break;
         case T128x64_1: conv64_launch_tile<TI, TO, 128, 64, 4, 1, 0>(a, st); break;
         default: conv64_launch_tile<TI, TO, 128, 64, 4, 1, 1>(a, st); break;
     }

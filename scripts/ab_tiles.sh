@@ -2,14 +2,14 @@
 # Per-layer time of every conv / FC launch under each forced tile configuration (OSR_CONV_FORCE_TILE, diagnostic knob of
 # osr_conv_gemm64.hip), single stream, for the given batch sizes. Output: gpurun_out/tiles_b<batch>_f<cfg>.log
 for B in ${BATCHES:-16 8}; do
-  for F in ${CFGS:-0 1 2 3 4 5 6 7 8}; do
+  for F in ${CFGS:-0 1 2 3 4 5 6 7}; do
     OSR_CONV_FORCE_TILE=$F python3 bench.py --batch $B --steps 3 --warmup 2 --no-cpu-baseline --streams 1 --no-graph --layers > /dev/null 2> gpurun_out/tiles_b${B}_f${F}.log
   done
 done
 python3 - <<'PY'
 import re, glob, os
-names = {0: "model", 1: "128x128/1", 2: "128x128/2", 3: "256x256/2", 4: "128x256/1", 5: "256x128/1", 6: "256x128/2", 7: "128x64/1", 8: "128x64/2"}
-cfgs = [int(x) for x in os.environ.get("CFGS", "0 1 2 3 4 5 6 7 8").split()]
+names = {0: "model", 1: "128x128/1", 2: "128x128/2", 3: "256x256/2", 4: "128x256/1", 5: "256x128/1", 6: "128x64/1", 7: "128x64/2"}
+cfgs = [int(x) for x in os.environ.get("CFGS", "0 1 2 3 4 5 6 7").split()]
 for B in os.environ.get("BATCHES", "16 8").split():
     tab = {}
     order = []
