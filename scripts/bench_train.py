@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--gt", type=int, default=8, help="ground-truth boxes per image")
+    ap.add_argument("--graph", action="store_true", help="capture one iteration into a hipGraph and replay it (single GPU)")
     ap.add_argument("--phases", action="store_true", help="also time forward / backward / update separately (extra syncs)")
     args = ap.parse_args()
     rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -61,11 +62,28 @@ def main():
     for _ in range(args.warmup):
         losses = tr.step(*a)
     torch.cuda.synchronize()
+    step = lambda: tr.step(*a)  # noqa: E731
+    if args.graph:
+        if world > 1:
+            raise SystemExit("--graph: single GPU only (the all-reduce is not captured)")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                glosses = tr.step(*a)
+        torch.cuda.current_stream().wait_stream(side)
+
+        def step():  # noqa: F811
+            graph.replay()
+            return glosses
+        step()
+        torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses = tr.step(*a)
+        losses = step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
