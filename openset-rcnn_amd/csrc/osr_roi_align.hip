@@ -567,9 +567,18 @@ struct RoiAlignBwdArgs {
     const void* dout;
 };
 
+#define RA_BWD_WPB 2   // RoIs per workgroup of the backward kernel (20 KB of LDS per RoI)
+#define RA_MAXY 208    // rows of the whole RoI footprint on the streaming path (p2 of an 800 px high batch: 200)
+struct RaBwdLds {
+    RaWaveLds t;                 // per-axis bin tables + per-column (x) window table
+    int rowb[RA_MAXY];           // per footprint row: first unfinished bin
+    float roww[3][RA_MAXY];      // weight of the row in bins rowb, rowb+1, rowb+2
+    float tb[7][4][64];          // per lane: the row's gradient folded over y, for each x bin and each of the lane's 4 channels
+};
+
 template <class TG>
-__global__ __launch_bounds__(RA_WPB * 64) void roi_align_bwd_kernel(RoiAlignBwdArgs a) {
-    __shared__ RaWaveLds s_all[RA_WPB];
+__global__ __launch_bounds__(RA_BWD_WPB * 64) void roi_align_bwd_kernel(RoiAlignBwdArgs a) {
+    __shared__ RaBwdLds s_all[RA_BWD_WPB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware order: workgroup b runs on XCD b % 8, so each XCD walks one contiguous eighth of the RoI list and RoIs that are
@@ -578,10 +587,11 @@ __global__ __launch_bounds__(RA_WPB * 64) void roi_align_bwd_kernel(RoiAlignBwdA
     {
         const int nwg = gridDim.x, bq = blockIdx.x, q = nwg >> 3, rr = nwg & 7, xcd = bq & 7, idx = bq >> 3;
         const int t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
-        r = (long long)t * RA_WPB + wid;
+        r = (long long)t * RA_BWD_WPB + wid;
     }
     if (r >= a.m) return;
-    RaWaveLds& S = s_all[wid];
+    RaBwdLds& SB = s_all[wid];
+    RaWaveLds& S = SB.t;
     const int P = a.pooled, C = a.c;
     const TG* dout = reinterpret_cast<const TG*>(a.dout) + (size_t)r * P * P * C;
     const int b = a.batch_idx[r];
@@ -630,6 +640,123 @@ __global__ __launch_bounds__(RA_WPB * 64) void roi_align_bwd_kernel(RoiAlignBwdA
     }
     const bool fallback = __any(overflow);
     ra_wave_sync();
+    // ---- streaming path: ONE atomic per footprint pixel and channel. d feat[y][x] = sum_by sum_bx wy[by][y] wx[bx][x] g[by][bx]
+    //      is evaluated row by row: the three bin rows a pixel row can belong to are held in registers (gwin, sliding down the
+    //      RoI), folded over y into t[bx] (7 values per channel, parked in the lane's LDS column), and a 3-bin window of t slides
+    //      along x. The per-bin loop below it issues ny*nx atomics per bin instead (3-4x more) and remains the fallback when a
+    //      pixel touches more than three bins of an axis or the tables overflow. ----
+    {
+        bool bad = fallback;
+        int lo_l[2] = {0x7fffffff, 0x7fffffff}, hi_l[2] = {0, 0};
+        if (lane < P) {
+#pragma unroll
+            for (int ax = 0; ax < 2; ++ax) {
+                const int lo = S.lo[ax][lane], n = S.n[ax][lane];
+                if (n > 0) { lo_l[ax] = lo; hi_l[ax] = lo + n; }
+                if (lane + 1 < P && n > 0 && S.n[ax][lane + 1] > 0 && S.lo[ax][lane + 1] < lo) bad = true;
+                if (lane + 3 < P && n > 0 && S.n[ax][lane + 3] > 0 && S.lo[ax][lane + 3] < lo + n) bad = true;
+                if (lane + 1 < P && lane > 0 && n == 0 && S.n[ax][lane - 1] > 0 && S.n[ax][lane + 1] > 0) bad = true;
+            }
+        }
+#pragma unroll
+        for (int ax = 0; ax < 2; ++ax)
+#pragma unroll
+            for (int d = 1; d < 8; d <<= 1) {
+                lo_l[ax] = min(lo_l[ax], __shfl_xor(lo_l[ax], d, 64));
+                hi_l[ax] = max(hi_l[ax], __shfl_xor(hi_l[ax], d, 64));
+            }
+        const int ys0 = __builtin_amdgcn_readfirstlane(lo_l[0]), ye0 = __builtin_amdgcn_readfirstlane(hi_l[0]);
+        const int xs0 = __builtin_amdgcn_readfirstlane(lo_l[1]), xe0 = __builtin_amdgcn_readfirstlane(hi_l[1]);
+        const bool empty = ys0 == 0x7fffffff || xs0 == 0x7fffffff;
+        if (empty && !__any(bad)) return;  // no valid sample: no gradient
+        const int nrow = empty ? 0 : ye0 - ys0, ncol = empty ? 0 : xe0 - xs0;
+        if (!__any(bad) && nrow <= RA_MAXY && ncol <= RA_MAXX) {
+            for (int sl = lane; sl < nrow + ncol; sl += 64) {  // per-pixel window tables of both axes
+                const bool isx = sl >= nrow;
+                const int ax = isx ? 1 : 0, i0 = isx ? sl - nrow : sl, x = (isx ? xs0 : ys0) + i0;
+                int cb = 0;
+                while (cb < P && (S.n[ax][cb] == 0 || x >= S.lo[ax][cb] + S.n[ax][cb])) ++cb;
+                float wv[3];
+#pragma unroll
+                for (int t2 = 0; t2 < 3; ++t2) {
+                    const int bb = cb + t2;
+                    wv[t2] = 0.f;
+                    if (bb < P) { const int i = x - S.lo[ax][bb]; if (i >= 0 && i < S.n[ax][bb]) wv[t2] = S.w[ax][bb][i]; }
+                }
+                if (isx) { S.colb[i0] = cb; S.colw[0][i0] = wv[0]; S.colw[1][i0] = wv[1]; S.colw[2][i0] = wv[2]; }
+                else { SB.rowb[i0] = cb; SB.roww[0][i0] = wv[0]; SB.roww[1][i0] = wv[1]; SB.roww[2][i0] = wv[2]; }
+            }
+            ra_wave_sync();
+            const float inv_count = 1.0f / count;
+            for (int cb0 = 0; cb0 < C; cb0 += 256) {
+                bool chok[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) chok[k] = cb0 + k * 64 + lane < C;
+                // gwin[d][bx][k]: upstream gradient of bin row (rcur + d), bin column bx, channel cb0 + k*64 + lane (already / count)
+                float gwin[3][7][4];
+#define RA_G_AT(byrow, j, k) (((byrow) < P && (j) < P && chok[k]) ? osr_to_float(dout[(size_t)((byrow) * P + (j)) * C + cb0 + (k) * 64 + lane]) * inv_count : 0.f)
+                int rcur = -1;  // bin row held in gwin[0]; -1: nothing loaded yet
+                for (int yi = 0; yi < nrow; ++yi) {
+                    const int rb = __builtin_amdgcn_readfirstlane(SB.rowb[yi]);
+                    if (rcur < 0) {
+#pragma unroll
+                        for (int d = 0; d < 3; ++d)
+#pragma unroll
+                            for (int j = 0; j < 7; ++j)
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) gwin[d][j][k] = RA_G_AT(rb + d, j, k);
+                        rcur = rb;
+                    }
+                    while (rcur < rb) {  // slide the window down by one bin row
+#pragma unroll
+                        for (int j = 0; j < 7; ++j)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                gwin[0][j][k] = gwin[1][j][k];
+                                gwin[1][j][k] = gwin[2][j][k];
+                                gwin[2][j][k] = RA_G_AT(rcur + 3, j, k);
+                            }
+                        ++rcur;
+                    }
+                    const float w0 = SB.roww[0][yi], w1 = SB.roww[1][yi], w2 = SB.roww[2][yi];
+#pragma unroll
+                    for (int j = 0; j < 7; ++j)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            SB.tb[j][k][lane] = __builtin_fmaf(w2, gwin[2][j][k], __builtin_fmaf(w1, gwin[1][j][k], w0 * gwin[0][j][k]));
+                    // (a lane reads back only what it wrote: no wave synchronisation needed beyond program order)
+                    float t0[4], t1[4], t2[4];
+                    int bcur = __builtin_amdgcn_readfirstlane(S.colb[0]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        t0[k] = bcur < P ? SB.tb[bcur < P ? bcur : 0][k][lane] : 0.f;
+                        t1[k] = bcur + 1 < P ? SB.tb[bcur + 1 < P ? bcur + 1 : 0][k][lane] : 0.f;
+                        t2[k] = bcur + 2 < P ? SB.tb[bcur + 2 < P ? bcur + 2 : 0][k][lane] : 0.f;
+                    }
+                    float* frow = feat + ((size_t)(ys0 + yi) * W + xs0) * C + cb0 + lane;
+                    for (int xi = 0; xi < ncol; ++xi) {
+                        const int cbx = __builtin_amdgcn_readfirstlane(S.colb[xi]);
+                        while (bcur < cbx) {
+                            ++bcur;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                t0[k] = t1[k]; t1[k] = t2[k];
+                                t2[k] = bcur + 2 < P ? SB.tb[bcur + 2 < P ? bcur + 2 : 0][k][lane] : 0.f;
+                            }
+                        }
+                        const float c0w = S.colw[0][xi], c1w = S.colw[1][xi], c2w = S.colw[2][xi];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float v = __builtin_fmaf(c2w, t2[k], __builtin_fmaf(c1w, t1[k], c0w * t0[k]));
+                            if (chok[k] && v != 0.f) atomicAdd(frow + (size_t)xi * C + k * 64, v);
+                        }
+                    }
+                }
+            }
+#undef RA_G_AT
+            return;
+        }
+    }
     // Channel mapping: lane l takes channels l, l+64, l+128, ... so that one wave-wide atomic instruction covers 64 consecutive
     // floats (four full 64-byte lines) instead of touching 16 lines with four lanes each.
     for (int ph = 0; ph < P; ++ph)
@@ -697,7 +824,7 @@ extern "C" osr_status osr_roi_align_bwd(const osr_pyramid* dfeat, int32_t n, con
     a.pooled = pooled; a.canonical_level = canonical_level; a.canonical_size = canonical_size; a.min_level = min_level;
     a.dout = dout;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)((m + RA_WPB - 1) / RA_WPB)), block(RA_WPB * 64);
+    dim3 grid((unsigned)((m + RA_BWD_WPB - 1) / RA_BWD_WPB)), block(RA_BWD_WPB * 64);
     switch (dout_dtype) {
         case OSR_F32: hipLaunchKernelGGL(roi_align_bwd_kernel<float>, grid, block, 0, st, a); break;
         case OSR_F16: hipLaunchKernelGGL(roi_align_bwd_kernel<f16_t>, grid, block, 0, st, a); break;
