@@ -78,7 +78,8 @@ typedef struct osr_conv_params {
     int32_t pad_mode;
     int32_t in_dtype;  /* osr_dtype of in, weight, residual */
     int32_t out_dtype; /* osr_dtype of out */
-    int32_t reserved;
+    int32_t concurrency; /* scheduling hint: number of streams of the caller that launch onto the GPU at the same time (0 or 1:
+                          * this launch has the GPU to itself). Tile selection only; results do not depend on it. */
 } osr_conv_params;
 
 osr_status osr_conv2d_fwd(const osr_conv_params* p, const void* in, const void* weight, const float* bias,

@@ -542,8 +542,9 @@ static double conv64_tile_us(const TileCfg& c, int nk, int residents, bool res) 
     return fixed + nk * slice;
 }
 
-// The modelled time of the 256 x 256 tile is scaled by 0.65 (OSR_CONV_MODEL_BIG, percent): the pass runs as two micro-batch
-// streams, so the empty part of a one-workgroup-per-CU round is filled by the other stream's launches, and the big tile
+// When the caller runs several streams side by side (osr_conv_params.concurrency >= 2: the engine's micro-batch streams) the
+// modelled time of the 256 x 256 tile is scaled by 0.65 (OSR_CONV_MODEL_BIG, percent): the empty part of a
+// one-workgroup-per-CU round is then filled by the other stream's launches, and the big tile
 // moves half the L2 -> LDS and LDS -> register bytes per FLOP of the 128 x 128 tile, which is what counts once both streams
 // compete for a CU (same-box end-to-end A/B: 1.00 -> 1127, 0.85 -> 1138, 0.70 -> 1172-1193, 0.60 -> 1200, 0.50 -> 1184 img/s).
 static double model_big_scale() {
@@ -570,7 +571,7 @@ static int conv64_pick_tile(const Conv64Args& a) {
         const long long full = tiles / slots, rem = tiles % slots;
         double us = (double)full * conv64_tile_us(c, nk, c.occ, res);
         if (rem) us += conv64_tile_us(c, nk, (int)((rem + 255) / 256), res);
-        if (c.id == T256x256_2) us *= model_big_scale();
+        if (c.id == T256x256_2 && a.p.concurrency >= 2) us *= model_big_scale();
         if (us < best_us) { best_us = us; best = c.id; }
     }
     return best;

@@ -29,7 +29,7 @@ class ConvParams(C.Structure):
         ("out_stride_n", C.c_int64), ("out_stride_h", C.c_int64), ("out_stride_w", C.c_int64),
         ("res_stride_n", C.c_int64), ("res_stride_h", C.c_int64), ("res_stride_w", C.c_int64),
         ("relu", C.c_int32), ("res_mode", C.c_int32), ("pad_mode", C.c_int32),
-        ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("reserved", C.c_int32),
+        ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("concurrency", C.c_int32),
     ]
 
 

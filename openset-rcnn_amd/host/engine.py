@@ -292,7 +292,7 @@ class OpensetRCNNEngine:
             hi = lo + sizes[i]
             st = self._streams[i]
             st.wait_event(start)
-            with torch.cuda.stream(st):
+            with torch.cuda.stream(st), ops.concurrent_streams(ns):
                 o = self.forward_device(images[lo:hi], image_hw[lo:hi], hp, wp)
                 done = torch.cuda.Event()
                 done.record(st)

@@ -56,6 +56,32 @@ def preprocess(images: torch.Tensor, hp: int, wp: int, mean, std, dtype=torch.fl
     return out
 
 
+_CONCURRENCY = [1]
+
+
+class concurrent_streams:
+    """Context manager: the launches inside run on `n` HIP streams side by side (the engine's micro-batch streams). Passed to
+    the conv kernels as osr_conv_params.concurrency, a tile-selection hint (results do not depend on it)."""
+
+    def __init__(self, n: int):
+        self.n = int(n)
+
+    def __enter__(self):
+        self.prev = _CONCURRENCY[0]
+        _CONCURRENCY[0] = self.n
+        return self
+
+    def __exit__(self, *exc):
+        _CONCURRENCY[0] = self.prev
+        return False
+
+
+def _new_conv_params() -> "ConvParams":
+    p = ConvParams()
+    p.concurrency = _CONCURRENCY[0]
+    return p
+
+
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, stride: int = 1, pad: int = 0, relu: bool = False,
            residual: Optional[torch.Tensor] = None, res_mode: int = 0, out_dtype: Optional[torch.dtype] = None,
            out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -74,7 +100,7 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, stride: in
     else:
         _need(out, out_dtype, "out")
         assert out.numel() == n * ho * wo * cout
-    p = ConvParams()
+    p = _new_conv_params()
     p.n, p.hi, p.wi, p.cin, p.ho, p.wo, p.cout = n, hi, wi, cin, ho, wo, cout
     p.kh, p.kw, p.stride_h, p.stride_w, p.pad_h, p.pad_w = kh, kw, stride, stride, pad, pad
     p.in_stride_n, p.in_stride_h, p.in_stride_w = hi * wi * cin, wi * cin, cin
@@ -106,7 +132,7 @@ def stem_conv(xpad: torch.Tensor, w_view: torch.Tensor, bias: torch.Tensor, hp: 
     kh = w_view.shape[1]
     ho, wo = hp // 2, wp // 2
     out = torch.empty((n, ho, wo, cout), dtype=xpad.dtype, device=xpad.device)
-    p = ConvParams()
+    p = _new_conv_params()
     p.n, p.hi, p.wi, p.cin, p.ho, p.wo, p.cout = n, hd, wd, 32, ho, wo, cout
     p.kh, p.kw, p.stride_h, p.stride_w, p.pad_h, p.pad_w = kh, 1, 2, 2, 0, 0
     p.in_stride_n, p.in_stride_h, p.in_stride_w = hd * wd * 4, wd * 4, 4
@@ -184,7 +210,7 @@ def cfrpn_head_fused(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, 
     ctr = ctr_out if ctr_out is not None else torch.empty((rows,), dtype=torch.float32, device=x.device)
     _need(deltas, torch.float32, "deltas"); _need(ctr, torch.float32, "ctr")
     assert deltas.numel() == rows * 4 and ctr.numel() == rows
-    p = ConvParams()
+    p = _new_conv_params()
     p.n, p.hi, p.wi, p.cin, p.ho, p.wo, p.cout = n, hi, wi, cin, hi, wi, cout
     p.kh, p.kw, p.stride_h, p.stride_w, p.pad_h, p.pad_w = kh, kw, 1, 1, pad, pad
     p.in_stride_n, p.in_stride_h, p.in_stride_w = hi * wi * cin, wi * cin, cin
@@ -513,7 +539,7 @@ def softmax_ce_loss_fwd(logits, gt_classes, num_classes: int, loss_weight: float
 # training step, backward half: dense layers
 # ----------------------------------------------------------------------------------------------------------
 def _conv_params(n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, dt_in, dt_out) -> ConvParams:
-    p = ConvParams()
+    p = _new_conv_params()
     p.n, p.hi, p.wi, p.cin, p.ho, p.wo, p.cout = n, hi, wi, cin, ho, wo, cout
     p.kh, p.kw, p.stride_h, p.stride_w, p.pad_h, p.pad_w = kh, kw, stride, stride, pad, pad
     p.in_stride_n, p.in_stride_h, p.in_stride_w = hi * wi * cin, wi * cin, cin
