@@ -527,15 +527,16 @@ static void conv64_launch_tile(Conv64Args& a, hipStream_t st) {
 //   time = full_rounds x tile(occ) + tile(residents of the last partial round),  tile(r) = fixed + nk x slice(r)
 // The 256-wide tiles read the residual in the epilogue (no prefetch under the K loop), which measured 1.6x slower on the
 // HBM-bound residual layers: they are not offered when there is a residual.
-struct TileCfg { int id, bm, bn, two, occ, pre_res; };
+struct TileCfg { int id, bm, bn, two, occ, pre_res; double cap; };  // cap: per-CU MFMA rate under load, FLOP per us
 static const TileCfg kTileCfgs[] = {
-    {T128x128_1, 128, 128, 0, 3, 1}, {T128x128_2, 128, 128, 1, 2, 1}, {T256x256_2, 256, 256, 1, 1, 0}, {T128x256_1, 128, 256, 0, 2, 0},
-    {T256x128_1, 256, 128, 0, 2, 0}, {T128x64_1, 128, 64, 0, 4, 1},   {T128x64_2, 128, 64, 1, 3, 1},
+    {T128x128_1, 128, 128, 0, 3, 1, 4.45e6}, {T128x128_2, 128, 128, 1, 2, 1, 4.45e6}, {T256x256_2, 256, 256, 1, 1, 0, 5.2e6},
+    {T128x256_1, 128, 256, 0, 2, 0, 4.45e6}, {T256x128_1, 256, 128, 0, 2, 0, 4.45e6}, {T128x64_1, 128, 64, 0, 4, 1, 4.45e6},
+    {T128x64_2, 128, 64, 1, 3, 1, 4.45e6},
 };
 
 static double conv64_tile_us(const TileCfg& c, int nk, int residents, bool res) {
-    const double kCapFlopPerUs = 4.45e6, kLat = 1.0;  // per-CU MFMA rate under load; L2 -> LDS latency of one staged slice (us)
-    const double w = (double)c.bm * c.bn * 128.0 / kCapFlopPerUs;
+    const double kLat = 1.0;  // L2 -> LDS latency of one staged slice (us)
+    const double w = (double)c.bm * c.bn * 128.0 / c.cap;  // (the 256 x 256 tile measured 1.61 us per slice on fpn_output2: 5.2 TFLOP/s per CU)
     const double busy = residents * w;
     const double slice = c.two ? (busy > kLat + 0.1 ? busy : kLat + 0.1) : (busy > kLat + w ? busy : kLat + w);
     const double fixed = 1.5 + (c.two ? kLat : 0.0) + (double)c.bm * c.bn / 16384.0 * 1.3 * (res ? 1.5 : 1.0);
@@ -543,12 +544,13 @@ static double conv64_tile_us(const TileCfg& c, int nk, int residents, bool res) 
 }
 
 // When the caller runs several streams side by side (osr_conv_params.concurrency >= 2: the engine's micro-batch streams) the
-// modelled time of the 256 x 256 tile is scaled by 0.65 (OSR_CONV_MODEL_BIG, percent): the empty part of a
+// modelled time of the 256 x 256 tile is scaled by 0.8 (OSR_CONV_MODEL_BIG, percent): the empty part of a
 // one-workgroup-per-CU round is then filled by the other stream's launches, and the big tile
 // moves half the L2 -> LDS and LDS -> register bytes per FLOP of the 128 x 128 tile, which is what counts once both streams
-// compete for a CU (same-box end-to-end A/B: 1.00 -> 1127, 0.85 -> 1138, 0.70 -> 1172-1193, 0.60 -> 1200, 0.50 -> 1184 img/s).
+// compete for a CU (same-box end-to-end A/B with the per-configuration rates above: 1.00 -> 1169, 0.85 -> 1221, 0.75 -> 1219,
+// 0.65 -> 1208 img/s).
 static double model_big_scale() {
-    static const double v = [] { const char* e = getenv("OSR_CONV_MODEL_BIG"); return e ? atof(e) / 100.0 : 0.65; }();
+    static const double v = [] { const char* e = getenv("OSR_CONV_MODEL_BIG"); return e ? atof(e) / 100.0 : 0.8; }();
     return v;
 }
 
