@@ -8,7 +8,7 @@ Sharding: the test loader gives rank r the contiguous slice shard_range(N, r, wo
 draws an infinite seeded permutation stream and gives rank r every world-th element ([d2] TrainingSampler)."""
 from __future__ import annotations
 
-from typing import Callable, Dict, Iterator, List, Optional, Sequence, Tuple
+from typing import Callable, Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch

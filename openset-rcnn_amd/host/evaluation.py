@@ -23,7 +23,7 @@ from __future__ import annotations
 import os
 import xml.etree.ElementTree as ET
 from collections import defaultdict
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 

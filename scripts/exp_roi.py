@@ -1,5 +1,5 @@
 """Experiment driver (not part of the product): time osr_roi_align_fwd alone on the bench's real proposals."""
-import os, sys, time, torch
+import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 pkg = ge.load_package(); pkg._lib.load()
@@ -44,7 +44,6 @@ for _ in range(10): run1()
 e1.record(); torch.cuda.synchronize()
 print("tiny boxes (1/10 size) on image 0: %.3f ms" % (e0.elapsed_time(e1) / 10))
 # spatial-locality experiment: same RoIs, processed in (image, level, y-tile, x) order
-import math
 area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
 lvl = torch.floor(4 + torch.log2(torch.sqrt(area.clamp(min=1e-6)) / 224 + 1e-8)).clamp(2, 5)
 cy = (b[:, 1] + b[:, 3]) * 0.5

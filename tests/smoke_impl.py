@@ -1,13 +1,11 @@
 """Body of __graft_entry__.smoke(): one small pass through HIP kernels of the hot path on cuda:0, checked
 against the CPU oracle (conv -> RoIAlign -> NMS)."""
-import numpy as np
 import torch
 import torch.nn.functional as F
 
 
 def run(pkg, dev):
     from oracle import c_binding as CO
-    from oracle import osr_oracle as O
     ops = pkg.ops
     g = torch.Generator().manual_seed(0)
     x = torch.randn(1, 64, 32, 48, generator=g).half()

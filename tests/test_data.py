@@ -1,6 +1,5 @@
 """Input pipeline (host/data.py): resize rule, mapper, sharded loaders -- on synthetic PNG files."""
 import numpy as np
-import pytest
 import torch
 
 

@@ -5,7 +5,6 @@ the oracle is fed the ENGINE's own inputs to that stage: dense stages are then c
 rounding of the stored result, and every index-producing stage (top-k selection, first-stage sort, PLN class,
 NMS keep lists, final detections) must match bit-exactly given identical inputs.
 """
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F

@@ -133,7 +133,6 @@ def test_structures(osr):
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_mirrored_modules_run_on_the_hip_path(osr, tmp_path):
-    from oracle import osr_oracle as O
     from openset_rcnn_amd.host import modeling as M
     from openset_rcnn_amd.host.structures import ImageList
     from openset_rcnn_amd.host.weights import random_params

@@ -1,6 +1,5 @@
 """Open-set COCO-style evaluator (host/os_coco_evaluation.py): hand-computed case.
 Reference protocol: openset_rcnn/evaluation/os_cocoeval.py + os_coco_evaluation.py (no fixtures exist there; this is our own KAT)."""
-import numpy as np
 import pytest
 import torch
 

@@ -3,7 +3,6 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from oracle import c_binding as CO
 from oracle import osr_oracle as O
 
 pytestmark = pytest.mark.gpu
