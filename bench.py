@@ -166,12 +166,12 @@ def main():
     # the one collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x2 per the gfx950
     # guide) on this very command and committed under profiles/; null when that file is absent.
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_h_kernel_times_and_traffic.json")
+    tfile = os.path.join(ROOT, "profiles", "r01_j_kernel_times_and_traffic.json")
     if os.path.exists(tfile):
         with open(tfile) as fh:
             cf = json.load(fh).get("conv_family", {})
         traffic = {"GB_per_step": round(cf.get("fetch_GB_per_step_x2corrected", 0.0) + cf.get("write_GB_per_step", 0.0), 2),
-                   "source": "profiles/r01_h_kernel_times_and_traffic.json (scripts/profile_round.sh)"}
+                   "source": "profiles/r01_j_kernel_times_and_traffic.json (scripts/profile_round.sh)"}
     algo_bytes = sum(nb for _, _, _, _, nb in prof)
     roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic,
                     algorithmic_GB_per_step=round(algo_bytes / 1e9, 2),
