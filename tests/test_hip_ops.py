@@ -268,6 +268,35 @@ def test_roi_align_wide_bins_take_the_sample_loop(ops):
     assert_close(out, ref, rtol=1e-4, atol=1e-5, name="roi_align fallback")
 
 
+def test_roi_align_extreme_aspect_footprints(ops):
+    """Every path of the RoIAlign kernel on one level: wide-thin boxes (columns streamed in chunks of six rows: footprint taller
+    than six pixel rows per bin when transposed), tall-thin boxes (rows streamed), a footprint wider than 64 columns, boxes
+    much smaller than a pixel (a pixel in all seven bins: per-bin loop), boxes crossing the border, a full-image box whose
+    bins overflow nothing on the 64-column tables, and one on a map wide enough to overflow them (per-sample loop)."""
+    gg = g(23)
+    f = torch.randn(2, 12, 120, 340, generator=gg)
+    boxes = torch.tensor([
+        [4.0, 100.0, 1300.0, 112.0],     # 324 x 3 px footprint: rows streamed, 47-column bins
+        [300.0, 2.0, 330.0, 470.0],      # 7 x 117: columns streamed, 17-row bins (chunks of 6)
+        [10.0, 10.0, 700.0, 400.0],      # big box, 25 x 14 px bins
+        [50.3, 60.2, 51.1, 61.0],        # a fifth of a pixel: every bin samples the same pixels
+        [-40.0, -30.0, 90.0, 50.0],      # crosses the top-left border
+        [1200.0, 400.0, 1400.0, 520.0],  # crosses the bottom-right border
+        [0.0, 0.0, 1360.0, 480.0],       # the whole map
+        [600.0, 200.0, 640.0, 203.0],    # 10 x 0.75
+    ])
+    bidx = torch.tensor([0, 1, 0, 1, 0, 1, 1, 0], dtype=torch.int32)
+    out = ops.roi_align([nhwc(f).to(DEV)], (0.25,), boxes.to(DEV), bidx.to(DEV), 7, torch.float32, min_level=2).cpu().permute(0, 3, 1, 2)
+    ref = CO.roi_align(f, torch.cat((bidx.float().unsqueeze(1), boxes), 1), 0.25)
+    assert_close(out, ref, rtol=1e-4, atol=1e-5, name="roi_align extreme aspect")
+    # a map wider than 64 * 7 columns: the whole-map box has 70-column bins -> table overflow -> per-sample loop
+    f2 = torch.randn(1, 4, 24, 500, generator=gg)
+    b2 = torch.tensor([[0.0, 0.0, 2000.0, 96.0], [8.0, 8.0, 1900.0, 20.0]])
+    z = torch.zeros(2, dtype=torch.int32)
+    out2 = ops.roi_align([nhwc(f2).to(DEV)], (0.25,), b2.to(DEV), z.to(DEV), 7, torch.float32, min_level=2).cpu().permute(0, 3, 1, 2)
+    assert_close(out2, CO.roi_align(f2, torch.cat((z.float().unsqueeze(1), b2), 1), 0.25), rtol=1e-4, atol=1e-5, name="roi_align overflow")
+
+
 def test_roi_align_linear_ramp_is_exact(ops):
     ys, xs = torch.meshgrid(torch.arange(50.0), torch.arange(84.0), indexing="ij")
     f = (0.5 * xs - 0.25 * ys + 3.0).view(1, 1, 50, 84).expand(1, 4, 50, 84).contiguous()

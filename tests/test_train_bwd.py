@@ -153,6 +153,24 @@ def test_roi_align_backward(ops):
         assert rel(got[l].permute(0, 3, 1, 2), feat.grad) < 1e-4, f"level {l}"
 
 
+def test_roi_align_backward_extreme_aspect_footprints(ops):
+    """The streaming backward (one atomic per footprint pixel) and its per-bin fallback on wide-thin, tall-thin, sub-pixel and
+    border-crossing boxes of one level, against autograd through the torch restatement of the forward."""
+    gg = g(82)
+    n, c, h, w = 2, 8, 120, 340
+    boxes = torch.tensor([
+        [4.0, 100.0, 1300.0, 112.0], [300.0, 2.0, 330.0, 470.0], [10.0, 10.0, 700.0, 400.0], [50.3, 60.2, 51.1, 61.0],
+        [-40.0, -30.0, 90.0, 50.0], [1200.0, 400.0, 1400.0, 520.0], [0.0, 0.0, 1360.0, 480.0], [600.0, 200.0, 640.0, 203.0],
+    ])
+    bidx = torch.tensor([0, 1, 0, 1, 0, 1, 1, 0], dtype=torch.int32)
+    dout = torch.randn(len(boxes), 7, 7, c, generator=gg)
+    got = ops.roi_align_bwd(dout.to(DEV), [(h, w)], n, (0.25,), boxes.to(DEV), bidx.to(DEV), min_level=2)[0].cpu()
+    feat = torch.zeros(n, c, h, w, requires_grad=True)
+    out = O.roi_align_torch(feat, torch.cat((bidx.float().unsqueeze(1), boxes), dim=1), 0.25)
+    out.backward(dout.permute(0, 3, 1, 2))
+    assert rel(got.permute(0, 3, 1, 2), feat.grad) < 1e-4
+
+
 def test_elementwise_and_sgd(ops):
     gg = g(91)
     a = torch.randn(2, 9, 7, 16, generator=gg)
