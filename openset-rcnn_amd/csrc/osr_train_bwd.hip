@@ -418,16 +418,47 @@ __global__ __launch_bounds__(256) void pln_bwd_protos_kernel(const float* __rest
     __syncthreads();
     const int k = blockIdx.x;
     const float sc = s / fmaxf(rows[0], 1.0f);
-    // this thread owns channel tid (d <= 1024: up to 4 channels per thread)
-    for (int ch = threadIdx.x; ch < d; ch += blockDim.x) {
-        float acc = 0.f;
-        for (long long r = 0; r < m; ++r) {
-            const int i0 = pair_idx[r * 2], i1 = pair_idx[r * 2 + 1];
-            if (i0 != k && i1 != k) continue;
-            const float eh = emb[r * d + ch] * row_inv[r];  // ehat of the row
-            if (i0 == k) acc += pair_coef[r * 2] * eh;
-            if (i1 == k) acc += pair_coef[r * 2 + 1] * eh;
+    // Rows whose (intra, inter) prototype pair names k, in row order, PLN_LIST rows at a time: every thread scans a contiguous
+    // run of rows, a prefix sum over the threads' counts gives each its place in the list. The channel loop then visits only
+    // those rows (a few hundred of the 8192), in the same order as a scan over all rows would: the sum is unchanged.
+    constexpr int PLN_LIST = 2048;
+    __shared__ int s_list[PLN_LIST];
+    __shared__ int s_off[257];
+    float acc4[4] = {0.f, 0.f, 0.f, 0.f};  // this thread owns channels tid, tid + 256, ... (d <= 1024)
+    for (long long base = 0; base < m; base += PLN_LIST) {
+        const int chunk = (int)((m - base) < PLN_LIST ? (m - base) : PLN_LIST);
+        const int seg = (chunk + (int)blockDim.x - 1) / (int)blockDim.x;
+        const int r0 = (int)threadIdx.x * seg, r1 = r0 + seg < chunk ? r0 + seg : chunk;
+        int cnt = 0;
+        for (int r = r0; r < r1; ++r) cnt += (pair_idx[(base + r) * 2] == k || pair_idx[(base + r) * 2 + 1] == k) ? 1 : 0;
+        s_off[threadIdx.x + 1] = cnt;
+        if (threadIdx.x == 0) s_off[0] = 0;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int t = 1; t <= (int)blockDim.x; ++t) s_off[t] += s_off[t - 1];
+        __syncthreads();
+        int pos = s_off[threadIdx.x];
+        for (int r = r0; r < r1; ++r)
+            if (pair_idx[(base + r) * 2] == k || pair_idx[(base + r) * 2 + 1] == k) s_list[pos++] = r;
+        __syncthreads();
+        const int nlist = s_off[blockDim.x];
+        int q = 0;
+        for (int ch = threadIdx.x; ch < d; ch += blockDim.x, ++q) {
+            float acc = acc4[q];
+            for (int li = 0; li < nlist; ++li) {
+                const long long r = base + s_list[li];
+                const int i0 = pair_idx[r * 2], i1 = pair_idx[r * 2 + 1];
+                const float eh = emb[r * d + ch] * row_inv[r];  // ehat of the row
+                if (i0 == k) acc += pair_coef[r * 2] * eh;
+                if (i1 == k) acc += pair_coef[r * 2 + 1] * eh;
+            }
+            acc4[q] = acc;
         }
+        __syncthreads();
+    }
+    int qc = 0;
+    for (int ch = threadIdx.x; ch < d; ch += blockDim.x, ++qc) {
+        float acc = acc4[qc];
         // centre term: L += sc * relu(alpha + beta - cd_j) for every j; cd_j = 1 - phat_j . phat_arg(j)
         //   d/d phat_k gets  -(-sc) ... : dL/dcd_j = -sc [alpha+beta > cd_j];  dcd_j/dphat_j = -phat_arg(j);  dcd_j/dphat_arg(j) = -phat_j
         for (int j = 0; j < K; ++j) {
