@@ -84,6 +84,14 @@ typedef struct osr_conv_params {
 
 osr_status osr_conv2d_fwd(const osr_conv_params* p, const void* in, const void* weight, const float* bias,
                           const void* residual, void* out, void* stream);
+/* osr_conv2d_fwd followed, in the same epilogue, by a ReLU mask: out = mask > 0 ? (conv + bias [+ residual]) : 0.
+ * `mask` has in_dtype and out's logical layout (addressed with out_stride_*). This is the join of a residual block in the
+ * backward pass -- data gradient of one branch + the gradient of the other (res_mode 1), through the ReLU of the layer
+ * below ([d2] BottleneckBlock.forward's `F.relu_(out + shortcut)`, entered from train.py:145 `losses.backward()`) -- in one
+ * launch. res_mode 0 or 1. Returns OSR_ERR_UNSUPPORTED (nothing launched) outside the BK=64 kernel's envelope
+ * (cin % 64 != 0): run osr_conv2d_fwd + osr_relu_mask instead. */
+osr_status osr_conv2d_fwd_masked(const osr_conv_params* p, const void* in, const void* weight, const float* bias,
+                                 const void* residual, const void* mask, void* out, void* stream);
 
 /* [d2] F.max_pool2d(k=3,s=2,p=1) of the ResNet stem, NHWC contiguous. */
 osr_status osr_maxpool3x3s2(const void* in, int32_t n, int32_t hi, int32_t wi, int32_t c, void* out, int32_t dtype,

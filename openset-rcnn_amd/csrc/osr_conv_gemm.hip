@@ -261,17 +261,21 @@ static osr_status conv_launch(const ConvArgs& a0, hipStream_t st) {
 }
 
 int osr_conv64_eligible(const osr_conv_params* p, long long in_bytes, long long w_bytes);
-osr_status osr_conv64_run(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* residual, void* out,
-                          long long in_bytes, long long w_bytes, hipStream_t st);
+osr_status osr_conv64_run(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* residual, const void* mask,
+                          void* out, long long in_bytes, long long w_bytes, hipStream_t st);
 
 static bool force_bk32() {
     static const bool v = [] { const char* e = getenv("OSR_CONV_BK32"); return e && e[0] == '1'; }();
     return v;
 }
 
-extern "C" osr_status osr_conv2d_fwd(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* residual,
-                                     void* out, void* stream) {
+static osr_status conv2d_fwd_impl(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* residual,
+                                  const void* mask, bool masked, void* out, void* stream) {
     OSR_REQUIRE(p && in && weight && bias && out, OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: null pointer");
+    if (masked) {
+        OSR_REQUIRE(mask && (((uintptr_t)mask) & 15) == 0, OSR_ERR_INVALID_ARG, "osr_conv2d_fwd_masked: mask must be a 16-byte aligned pointer");
+        OSR_REQUIRE(p->res_mode == 0 || p->res_mode == 1, OSR_ERR_INVALID_ARG, "osr_conv2d_fwd_masked: res_mode must be 0 or 1");
+    }
     OSR_REQUIRE(p->n >= 1 && p->hi >= 1 && p->wi >= 1 && p->ho >= 1 && p->wo >= 1, OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: bad spatial sizes");
     OSR_REQUIRE(p->cin >= 32 && p->cin % 32 == 0, OSR_ERR_UNSUPPORTED, "osr_conv2d_fwd: cin must be a multiple of 32, got %d", p->cin);
     OSR_REQUIRE(p->cout >= 8 && p->cout % 8 == 0, OSR_ERR_UNSUPPORTED, "osr_conv2d_fwd: cout must be a multiple of 8, got %d", p->cout);
@@ -309,7 +313,12 @@ extern "C" osr_status osr_conv2d_fwd(const osr_conv_params* p, const void* in, c
         const long long in_elems = p->in_stride_n > 0 ? (long long)p->n * p->in_stride_n
                                                       : (long long)(p->hi - 1) * p->in_stride_h + (long long)(p->wi - 1) * p->in_stride_w + p->cin;
         const long long in_bytes = in_elems * 2, w_bytes = (long long)p->cout * K * 2;
-        if (!force_bk32() && osr_conv64_eligible(p, in_bytes, w_bytes)) return osr_conv64_run(p, in, weight, bias, residual, out, in_bytes, w_bytes, st);
+        if (!force_bk32() && osr_conv64_eligible(p, in_bytes, w_bytes))
+            return osr_conv64_run(p, in, weight, bias, residual, masked ? mask : nullptr, out, in_bytes, w_bytes, st);
+    }
+    if (masked) {
+        osr_set_error("osr_conv2d_fwd_masked: outside the BK=64 kernel's envelope (cin %% 64 != 0 or tensor too large)");
+        return OSR_ERR_UNSUPPORTED;
     }
     if (p->in_dtype == OSR_F16) {
         if (p->out_dtype == OSR_F16) return conv_launch<f16_t, f16_t>(a, st);
@@ -320,6 +329,16 @@ extern "C" osr_status osr_conv2d_fwd(const osr_conv_params* p, const void* in, c
     }
     osr_set_error("osr_conv2d_fwd: out_dtype must equal in_dtype or be f32");
     return OSR_ERR_UNSUPPORTED;
+}
+
+extern "C" osr_status osr_conv2d_fwd(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* residual,
+                                     void* out, void* stream) {
+    return conv2d_fwd_impl(p, in, weight, bias, residual, nullptr, false, out, stream);
+}
+
+extern "C" osr_status osr_conv2d_fwd_masked(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* residual,
+                                            const void* mask, void* out, void* stream) {
+    return conv2d_fwd_impl(p, in, weight, bias, residual, mask, true, out, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------

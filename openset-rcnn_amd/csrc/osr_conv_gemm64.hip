@@ -73,6 +73,7 @@ struct Conv64Args {
     const void* w;
     const float* bias;
     const void* res;
+    const void* mask;      // nullable: ReLU mask applied after bias / residual (osr_conv2d_fwd_masked), out's layout, in_dtype
     void* out;
     long long M;
     int K;                 // GEMM K of the weight rows (multiple of 64)
@@ -474,6 +475,12 @@ __global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI !=
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                     }
+                    if (a.mask) {
+                        const frag_t mv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const TI*>(a.mask) + (long long)nimg * p.out_stride_n +
+                                                                          (long long)oh * p.out_stride_h + (long long)ow * p.out_stride_w + co);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (float)mv[e] > 0.f ? v[e] : 0.f;
+                    }
                     store8_64<TO>(out + (long long)nimg * p.out_stride_n + (long long)oh * p.out_stride_h + (long long)ow * p.out_stride_w + co, v);
                 }
             }
@@ -635,10 +642,10 @@ int osr_conv64_eligible(const osr_conv_params* p, long long in_bytes, long long 
     return 1;
 }
 
-osr_status osr_conv64_run(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* residual, void* out,
-                          long long in_bytes, long long w_bytes, hipStream_t st) {
+osr_status osr_conv64_run(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* residual, const void* mask,
+                          void* out, long long in_bytes, long long w_bytes, hipStream_t st) {
     Conv64Args a;
-    a.p = *p; a.in = in; a.w = weight; a.bias = bias; a.res = residual; a.out = out;
+    a.p = *p; a.in = in; a.w = weight; a.bias = bias; a.res = residual; a.mask = mask; a.out = out;
     a.M = (long long)p->n * p->ho * p->wo;
     a.K = p->kh * p->kw * p->cin;
     a.div_howo = fastdiv_make((unsigned)(p->ho * p->wo));
@@ -682,7 +689,7 @@ extern "C" osr_status osr_cfrpn_head_fwd(const osr_conv_params* p, const void* i
     const long long in_bytes = (long long)p->n * p->in_stride_n * 2, w_bytes = (long long)p->cout * p->kh * p->kw * p->cin * 2;
     OSR_REQUIRE(osr_conv64_eligible(p, in_bytes, w_bytes), OSR_ERR_UNSUPPORTED, "osr_cfrpn_head_fwd: tensor too large for 32-bit buffer offsets");
     Conv64Args a;
-    a.p = *p; a.in = in; a.w = weight; a.bias = bias; a.res = nullptr; a.out = nullptr;
+    a.p = *p; a.in = in; a.w = weight; a.bias = bias; a.res = nullptr; a.mask = nullptr; a.out = nullptr;
     a.M = (long long)p->n * p->ho * p->wo;
     a.K = p->kh * p->kw * p->cin;
     a.div_howo = fastdiv_make((unsigned)(p->ho * p->wo));

@@ -19,6 +19,9 @@ class OsrError(RuntimeError):
     pass
 
 
+ERR_UNSUPPORTED = -2  # include/osr.h OSR_ERR_UNSUPPORTED: nothing was launched, the caller takes its other path
+
+
 class ConvParams(C.Structure):
     _fields_ = [
         ("n", C.c_int32), ("hi", C.c_int32), ("wi", C.c_int32), ("cin", C.c_int32),
@@ -59,6 +62,7 @@ PROTOTYPES = {
     "osr_stem_padded_width": (I32, [I32]),
     "osr_preprocess": (I32, [P, I32, I32, I32, I32, I32, I32, C.POINTER(C.c_float), C.POINTER(C.c_float), P, I32, P]),
     "osr_conv2d_fwd": (I32, [C.POINTER(ConvParams), P, P, P, P, P, P]),
+    "osr_conv2d_fwd_masked": (I32, [C.POINTER(ConvParams), P, P, P, P, P, P, P]),
     "osr_maxpool3x3s2": (I32, [P, I32, I32, I32, I32, P, I32, P]),
     "osr_subsample2": (I32, [P, I32, I32, I32, I32, P, I32, P]),
     "osr_gemm_f32": (I32, [P, I64, P, P, P, I64, I32, I32, I32, I32, P]),

@@ -84,8 +84,10 @@ def _new_conv_params() -> "ConvParams":
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, stride: int = 1, pad: int = 0, relu: bool = False,
            residual: Optional[torch.Tensor] = None, res_mode: int = 0, out_dtype: Optional[torch.dtype] = None,
-           out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """NHWC implicit-GEMM convolution. x (n,h,w,cin) f16/bf16; weight (cout,kh,kw,cin) same dtype; bias f32."""
+           out: Optional[torch.Tensor] = None, post_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """NHWC implicit-GEMM convolution. x (n,h,w,cin) f16/bf16; weight (cout,kh,kw,cin) same dtype; bias f32.
+    post_mask (n,ho,wo,cout), x's dtype: the result is zeroed where post_mask <= 0, in the same launch
+    (osr_conv2d_fwd_masked; needs cin % 64 == 0, else the mask is applied by a second launch)."""
     lib = _lib.load()
     _need(x, name="x"); _need(weight, x.dtype, "weight"); _need(bias, torch.float32, "bias")
     n, hi, wi, cin = x.shape
@@ -114,8 +116,19 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, stride: in
         if (rn, rh, rw, rc) != exp:
             raise OsrError(f"residual shape {tuple(residual.shape)} != expected {exp} for res_mode {res_mode}")
         p.res_stride_n, p.res_stride_h, p.res_stride_w = rh * rw * rc, rw * rc, rc
+    if post_mask is not None:
+        _need(post_mask, x.dtype, "post_mask")
+        if tuple(post_mask.shape) != (n, ho, wo, cout):
+            raise OsrError(f"post_mask shape {tuple(post_mask.shape)} != {(n, ho, wo, cout)}")
+        st = lib.osr_conv2d_fwd_masked(C.byref(p), _p(x), _p(weight), _p(bias), _p(residual) if res_mode else None, _p(post_mask), _p(out),
+                                       _stream())
+        if st != _lib.ERR_UNSUPPORTED:
+            check(st, "osr_conv2d_fwd_masked")
+            return out
     check(lib.osr_conv2d_fwd(C.byref(p), _p(x), _p(weight), _p(bias), _p(residual) if res_mode else None, _p(out), _stream()),
           "osr_conv2d_fwd")
+    if post_mask is not None:
+        relu_mask_(out, post_mask)
     return out
 
 
@@ -550,11 +563,13 @@ def _conv_params(n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, dt_in, dt_ou
 
 
 def conv2d_dgrad(dy: torch.Tensor, w_dgrad: torch.Tensor, x_hw: Tuple[int, int], stride: int = 1, pad: int = 0,
-                 mask: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+                 mask: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None,
+                 post_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Gradient w.r.t. the input of a convolution: dy (n,ho,wo,cout), w_dgrad = pack_dgrad_weight(w) (cin,kh,kw,cout).
     mask: forward activation at dx's positions (n,hi,wi,cin) -> dx is zeroed where mask <= 0 (the ReLU below);
-    add: a second gradient of dx's shape summed in (residual / shortcut branch). At most one of the two (a conv epilogue has
-    one auxiliary operand); stride 2 is supported for 1x1 layers (every second pixel of a zeroed dx)."""
+    add: a second gradient of dx's shape summed in (residual / shortcut branch). At most one of the two (they share the
+    epilogue's auxiliary operand); post_mask: a forward activation of dx's shape applied as a ReLU mask AFTER the sum (the
+    join of a residual block: osr_conv2d_fwd_masked); stride 2 is supported for 1x1 layers (every second pixel of a zeroed dx)."""
     lib = _lib.load()
     _need(dy, name="dy"); _need(w_dgrad, dy.dtype, "w_dgrad")
     n, ho, wo, cout = dy.shape
@@ -570,7 +585,7 @@ def conv2d_dgrad(dy: torch.Tensor, w_dgrad: torch.Tensor, x_hw: Tuple[int, int],
     if stride == 1:
         if (hi + 2 * pad - kh) + 1 != ho or (wi + 2 * pad - kw) + 1 != wo:
             raise OsrError("x_hw inconsistent with dy and the kernel geometry")
-        return conv2d(dy, w_dgrad, zero_bias, 1, kh - 1 - pad, False, aux, mode, out_dtype)
+        return conv2d(dy, w_dgrad, zero_bias, 1, kh - 1 - pad, False, aux, mode, out_dtype, post_mask=post_mask)
     if not (kh == 1 and kw == 1 and pad == 0):
         raise OsrError("strided backward-data is implemented for 1x1 layers only (the reference's R-50 strides in the 1x1)")
     if (hi - 1) // stride + 1 != ho or (wi - 1) // stride + 1 != wo:
@@ -584,7 +599,19 @@ def conv2d_dgrad(dy: torch.Tensor, w_dgrad: torch.Tensor, x_hw: Tuple[int, int],
         if tuple(aux.shape) != (n, hi, wi, cin):
             raise OsrError(f"mask/add shape {tuple(aux.shape)} != {(n, hi, wi, cin)}")
         p.res_stride_n, p.res_stride_h, p.res_stride_w = hi * wi * cin, stride * wi * cin, stride * cin
+    if post_mask is not None:
+        _need(post_mask, dy.dtype, "post_mask")
+        if tuple(post_mask.shape) != (n, hi, wi, cin):
+            raise OsrError(f"post_mask shape {tuple(post_mask.shape)} != {(n, hi, wi, cin)}")
+        if mode == 3:
+            raise OsrError("conv2d_dgrad: mask and post_mask are the same thing; pass one")
+        st = lib.osr_conv2d_fwd_masked(C.byref(p), _p(dy), _p(w_dgrad), _p(zero_bias), _p(aux), _p(post_mask), _p(dx), _stream())
+        if st != _lib.ERR_UNSUPPORTED:
+            check(st, "osr_conv2d_fwd_masked(dgrad)")
+            return dx  # (the pixels the stride skips stay zero: masking them changes nothing)
     check(lib.osr_conv2d_fwd(C.byref(p), _p(dy), _p(w_dgrad), _p(zero_bias), _p(aux), _p(dx), _stream()), "osr_conv2d_fwd(dgrad)")
+    if post_mask is not None:
+        relu_mask_(dx, post_mask)
     return dx
 
 

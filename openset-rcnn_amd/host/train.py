@@ -274,15 +274,17 @@ class OpensetRCNNTrainer:
                 d_res[lvl] = (d_ls, ln)  # the lateral's data gradient is formed together with the next stage's (see below)
             d_ls_prev = d_ls
         # --- backbone res5 -> res3: bottlenecks in reverse; G = gradient w.r.t. a block's output ---
+        # G always arrives already masked by the ReLU that produced y (`post_mask=` of the launch that formed it): the join of
+        # the two gradient branches and the ReLU below it are one epilogue (osr_conv2d_fwd_masked)
         G = None
-        for blk in reversed(s["blocks"]):
+        for bi in range(len(s["blocks"]) - 1, -1, -1):
+            blk = s["blocks"][bi]
             pre, x, o1, o2, y, stride = blk["pre"], blk["x"], blk["o1"], blk["o2"], blk["y"], blk["stride"]
             hy, wy = y.shape[1], y.shape[2]
             last_of_stage = blk is s["blocks"][-1] or pre.endswith(f".{R50_BLOCKS[blk['stage'] - 2] - 1}")
             if last_of_stage:  # the stage output also feeds its FPN lateral
                 d_ls, ln = d_res[blk["stage"]]
-                G = ops.conv2d_dgrad(d_ls, self.wd[ln], (hy, wy), 1, 0, add=G)
-            ops.relu_mask_(G, y)
+                G = ops.conv2d_dgrad(d_ls, self.wd[ln], (hy, wy), 1, 0, add=G, post_mask=y)
             d_o2 = ops.conv2d_dgrad(G, self.wd[pre + ".conv3"], (hy, wy), 1, 0, mask=o2)
             ops.conv2d_wgrad(o2, G, 1, 1, dw=g[pre + ".conv3.w"])
             d_o1 = ops.conv2d_dgrad(d_o2, self.wd[pre + ".conv2"], (o1.shape[1], o1.shape[2]), 1, 1, mask=o1)
@@ -293,11 +295,15 @@ class OpensetRCNNTrainer:
             if blk["first"] and blk["stage"] == self.freeze_at + 1:
                 break  # the block's input comes from frozen layers
             hx, wx = x.shape[1], x.shape[2]
+            # x is the output of the block below (post-ReLU): its mask goes into the launch that completes G -- unless that block
+            # is the last of its stage, whose G is completed (and masked) by the lateral's launch at the top of the next turn
+            below_last = bi > 0 and s["blocks"][bi - 1]["pre"].endswith(f".{R50_BLOCKS[s['blocks'][bi - 1]['stage'] - 2] - 1}")
+            pm = None if below_last else x
             if blk["first"]:
                 dx = ops.conv2d_dgrad(d_o1, self.wd[pre + ".conv1"], (hx, wx), stride, 0)
-                G = ops.conv2d_dgrad(G, self.wd[pre + ".shortcut"], (hx, wx), stride, 0, add=dx)
+                G = ops.conv2d_dgrad(G, self.wd[pre + ".shortcut"], (hx, wx), stride, 0, add=dx, post_mask=pm)
             else:
-                G = ops.conv2d_dgrad(d_o1, self.wd[pre + ".conv1"], (hx, wx), 1, 0, add=G)
+                G = ops.conv2d_dgrad(d_o1, self.wd[pre + ".conv1"], (hx, wx), 1, 0, add=G, post_mask=pm)
 
     # ---- optimiser ------------------------------------------------------------------------------------------------
     def all_reduce_grads(self) -> int:

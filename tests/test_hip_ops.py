@@ -98,6 +98,32 @@ def test_conv2d(ops, case):
         assert_close(out, ref, rtol=eps, atol=eps * float(ref.abs().max()) * 0.01 + 1e-6, name="conv half out")
 
 
+@pytest.mark.parametrize("cin,odt", [(64, torch.float16), (128, torch.float32), (32, torch.float16)])
+def test_conv2d_post_mask(ops, cin, odt):
+    """osr_conv2d_fwd_masked: (conv + bias + residual) zeroed where the mask tensor is <= 0, one launch on the BK=64 kernel
+    (cin % 64 == 0); cin = 32 takes the documented two-launch route (OSR_ERR_UNSUPPORTED -> conv + relu_mask)."""
+    gg = g(300 + cin)
+    n, h, w, cout, k = 2, 19, 23, 64, 3
+    x = torch.randn(n, cin, h, w, generator=gg).half()
+    wt = (torch.randn(cout, cin, k, k, generator=gg) / math.sqrt(cin * k * k)).half()
+    b = torch.randn(cout, generator=gg)
+    res = torch.randn(n, cout, h, w, generator=gg).half()
+    mask = torch.randn(n, cout, h, w, generator=gg).half()
+    mask[0, :, 3, :] = 0.0  # exactly zero: masked (the ReLU output was not positive)
+    ref = (F.conv2d(x.float(), wt.float(), b, padding=1) + res.float()) * (mask.float() > 0)
+    out = ops.conv2d(nhwc(x).to(DEV), wt.permute(0, 2, 3, 1).contiguous().to(DEV), b.to(DEV), pad=1, residual=nhwc(res).to(DEV), res_mode=1,
+                     out_dtype=odt, post_mask=nhwc(mask).to(DEV)).cpu().float().permute(0, 3, 1, 2)
+    assert bool(((out == 0) | (mask.float() > 0)).all())  # exact zeros where masked
+    if odt == torch.float32:
+        assert_close(out, ref, rtol=1e-4, name="masked conv fp32 out")
+    else:
+        assert_close(out, ref, rtol=2.0 ** -10, atol=2.0 ** -10 * float(ref.abs().max()) * 0.01 + 1e-6, name="masked conv half out")
+    # no residual
+    out0 = ops.conv2d(nhwc(x).to(DEV), wt.permute(0, 2, 3, 1).contiguous().to(DEV), b.to(DEV), pad=1, out_dtype=torch.float32,
+                      post_mask=nhwc(mask).to(DEV)).cpu().permute(0, 3, 1, 2)
+    assert_close(out0, F.conv2d(x.float(), wt.float(), b, padding=1) * (mask.float() > 0), rtol=1e-4, name="masked conv, no residual")
+
+
 def test_stem_conv_matches_7x7(ops):
     gg = g(5)
     img = torch.randint(0, 256, (2, 3, 61, 90), generator=gg, dtype=torch.uint8)
