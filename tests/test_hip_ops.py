@@ -403,6 +403,22 @@ def test_nms_topk_bit_exact(ops, stride, lens, ncls, thr, topk):
         assert (keep[s, cnt[s]:] == -1).all()
 
 
+def test_nms_topk_many_seeds(ops):
+    """Index parity is the bar for NMS: sixteen more random scenes (clustered boxes, ties, dropped candidates) at three
+    thresholds, kept lists compared element by element with the C oracle."""
+    for seed in range(16):
+        thr = (0.3, 0.5, 0.7)[seed % 3]
+        stride, lens, ncls, topk = 700, [700, 333, 1, 0], 1 + seed % 5, 100
+        boxes, scores, cls, cand, seg_len = _nms_inputs(1000 + seed, len(lens), stride, lens, ncls)
+        keep, cnt = ops.nms_topk(torch.from_numpy(boxes).to(DEV), torch.from_numpy(scores).to(DEV), torch.from_numpy(cls).to(DEV),
+                                 torch.from_numpy(cand).to(DEV), len(lens), stride, torch.from_numpy(seg_len).to(DEV), thr, topk)
+        keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+        for s_ in range(len(lens)):
+            ids = np.nonzero(cand[s_, : lens[s_]])[0]
+            k = ids[CO.batched_nms(boxes[s_, ids], scores[s_, ids], cls[s_, ids].astype(np.int64), thr)][:topk] if len(ids) else ids
+            assert cnt[s_] == len(k) and keep[s_, : cnt[s_]].tolist() == k.tolist(), f"seed {seed} segment {s_}"
+
+
 def test_nms_no_class_no_cand(ops):
     boxes, scores, _, _, seg_len = _nms_inputs(3, 2, 300, [300, 150], 1)
     keep, cnt = ops.nms_topk(torch.from_numpy(boxes).to(DEV), torch.from_numpy(scores).to(DEV), None, None, 2, 300,
