@@ -238,6 +238,15 @@ def test_rpn_select_small_with_ties_and_poison(ops):
     assert int(r["status_flags"].cpu()[0]) == 0
 
 
+def test_rpn_select_many_seeds(ops):
+    """Top-k order, decoded and clipped boxes and counts are bit-exact: twelve more random score / delta fields (every
+    other one with ties) on a mid-size pyramid, k below and above the level sizes."""
+    shapes, strides, sizes = [(40, 64), (20, 32), (10, 16), (5, 8), (3, 4)], (4, 8, 16, 32, 64), (32, 64, 128, 256, 512)
+    for seed in range(12):
+        k = (50, 300, 2000)[seed % 3]
+        _run_select(ops, shapes, strides, sizes, 2, k, [(160, 256), (150, 250)], 500 + seed, ties=seed % 2 == 0)
+
+
 def test_rpn_select_full_size(ops):
     shapes = O.level_shapes(800, 1344)
     r, ref = _run_select(ops, shapes, O.FPN_STRIDES, O.ANCHOR_SIZES, 2, 1000, [(800, 1333), (750, 1333)], 13, ties=True)
