@@ -165,15 +165,16 @@ def main():
     # HBM-side traffic of the same kernel family: PMC counters cannot be read from inside the process, so the value is
     # the one collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x2 per the gfx950
     # guide) on this very command and committed under profiles/; null when that file is absent.
-    traffic = None
+    traffic, traffic_source = None, None
     tfile = os.path.join(ROOT, "profiles", "r01_j_kernel_times_and_traffic.json")
     if os.path.exists(tfile):
         with open(tfile) as fh:
             cf = json.load(fh).get("conv_family", {})
-        traffic = {"GB_per_step": round(cf.get("fetch_GB_per_step_x2corrected", 0.0) + cf.get("write_GB_per_step", 0.0), 2),
-                   "source": "profiles/r01_j_kernel_times_and_traffic.json (scripts/profile_round.sh)"}
+        traffic = round(cf.get("fetch_GB_per_step_x2corrected", 0.0) + cf.get("write_GB_per_step", 0.0), 2)
+        traffic_source = "profiles/r01_j_kernel_times_and_traffic.json (scripts/profile_round.sh: --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
     algo_bytes = sum(nb for _, _, _, _, nb in prof)
     roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic,
+                    traffic_unit="GB of HBM traffic per step of the same kernel family (all its launches)", traffic_source=traffic_source,
                     algorithmic_GB_per_step=round(algo_bytes / 1e9, 2),
                     kernel="conv_igemm64_kernel family (implicit-GEMM conv + FC)", launches_per_step=len(prof),
                     flops_per_step=mfma_flops, kernel_ms_per_step=round(mfma_ms, 3))
