@@ -37,6 +37,26 @@ def test_setup_merges_yaml_overrides_and_benchmark_flag(osr, tmp_path):
         cfg.SOLVER.BASE_LR = 1.0
 
 
+def test_num_gpus_relaunches_one_process_per_gpu(osr, monkeypatch):
+    """--num-gpus N without a launcher: the driver becomes the parent of a torch.distributed.run job (one rank per GPU,
+    rendezvous on 127.0.0.1) before it imports anything that touches the GPU, and returns the job's exit code."""
+    seen = {}
+
+    def fake_call(cmd):
+        seen["cmd"] = cmd
+        return 7
+
+    monkeypatch.setattr(run_net.subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["run_net.py", "--num-gpus", "4", "--eval-only", "--config-file", "c.yaml", "MODEL.WEIGHTS", "w.pth"])
+    assert run_net.main(["--num-gpus", "4", "--eval-only", "--config-file", "c.yaml", "MODEL.WEIGHTS", "w.pth"]) == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-7:] == ["--num-gpus", "4", "--eval-only", "--config-file", "c.yaml", "MODEL.WEIGHTS", "w.pth"]  # the ranks see the same flags
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "run_net.py"
+
+
 def _coco_gt():
     cats = [{"id": 1, "name": "banana"}, {"id": 2, "name": "mug"}, {"id": 7, "name": "novel_thing"}]
     imgs = [{"id": 10, "height": 100, "width": 200, "file_name": "a.jpg"}, {"id": 11, "height": 100, "width": 200, "file_name": "b.jpg"}]
