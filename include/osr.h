@@ -422,10 +422,16 @@ osr_status osr_pool_bwd(const void* src, int32_t hs, int32_t ws, const void* bas
 
 /* SGD with momentum and weight decay ([d2] build_optimizer -> torch.optim.SGD): g' = grad*grad_scale*row_scale + wd*param;
  * buf = momentum*buf + g'; param -= lr*buf; lowp_copy (nullable) = (T)(param*row_scale). row_scale (nullable): folded
- * FrozenBN scale per leading-dimension row of row_elems elements. */
+ * FrozenBN scale per leading-dimension row of row_elems elements. apply_flag (nullable, device int32): when it reads 0 the
+ * launch changes nothing (the overflow guard of the fp16 step, see osr_check_finite). */
 osr_status osr_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
                         float weight_decay, float grad_scale, const float* row_scale, int64_t row_elems, void* lowp_copy,
-                        int32_t lowp_dtype, void* stream);
+                        int32_t lowp_dtype, const int32_t* apply_flag, void* stream);
+
+/* Overflow guard: *flag (device int32, preset to 1 by the caller) is cleared when any of the n floats of x is inf or NaN.
+ * The reference trains in fp32 and has no such step (train.py:135-146); the fp16 gradients of this build do, and an
+ * overflowed iteration must not reach the fp32 masters or a checkpoint. x 16-byte aligned. Asynchronous, no host sync. */
+osr_status osr_check_finite(const float* x, int64_t n, int32_t* flag, void* stream);
 
 #ifdef __cplusplus
 }

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 #include "../../include/osr.h"
 
 #define OSR_WAVE 64
@@ -27,6 +28,20 @@ void osr_set_error(const char* fmt, ...);
             return OSR_ERR_LAUNCH;                                               \
         }                                                                        \
     } while (0)
+
+// hipFuncSetAttribute (the > 64 KB dynamic-LDS opt-in) applies to the CURRENT device, whichever host thread asks: one bit per
+// device ordinal, set AFTER the attribute call has returned (a second thread that does not see the bit yet repeats the call, which
+// is harmless; none can launch on a device whose attribute is still missing).
+typedef std::atomic<unsigned long long> osr_dev_mask;
+template <class F>
+static inline void osr_once_per_device(osr_dev_mask& mask, F&& set_attributes) {
+    int dev = 0;
+    const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+    const unsigned long long bit = known ? 1ull << dev : 0ull;
+    if (known && (mask.load(std::memory_order_acquire) & bit)) return;
+    set_attributes();
+    if (known) mask.fetch_or(bit, std::memory_order_release);
+}
 
 typedef _Float16 f16_t;
 typedef __bf16 bf16_t;

@@ -293,12 +293,11 @@ extern "C" osr_status osr_conv2d_wgrad(const osr_conv_params* p, const void* x, 
     hipStream_t st = (hipStream_t)stream;
     if (big) {
         const size_t ldsb = 2 * WG_BM * (256 + 256) * 2;  // 128 KiB
-        static thread_local bool attr = false;
-        if (!attr) {
+        static osr_dev_mask attr{0};
+        osr_once_per_device(attr, [] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<f16_t, 256, 256, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<bf16_t, 256, 256, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr = true;
-        }
+        });
         if (p->in_dtype == OSR_F16) hipLaunchKernelGGL((conv_wgrad_kernel<f16_t, 256, 256, 2, 4>), dim3((unsigned)grid), dim3(512), ldsb, st, a);
         else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 256, 256, 2, 4>), dim3((unsigned)grid), dim3(512), ldsb, st, a);
     } else {

@@ -265,8 +265,12 @@ osr_status osr_conv64_run(const osr_conv_params* p, const void* in, const void* 
                           void* out, long long in_bytes, long long w_bytes, hipStream_t st);
 
 static bool force_bk32() {
+#ifdef OSR_EXPERIMENT  // diagnostic builds only: route every layer through the BK=32 kernel
     static const bool v = [] { const char* e = getenv("OSR_CONV_BK32"); return e && e[0] == '1'; }();
     return v;
+#else
+    return false;
+#endif
 }
 
 static osr_status conv2d_fwd_impl(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* residual,

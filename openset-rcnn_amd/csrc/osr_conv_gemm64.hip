@@ -496,12 +496,19 @@ static size_t conv64_lds_bytes(int bm, int bn, int two_stage, int nw = 4) {
     return stages > epi ? stages : epi;
 }
 
+// Tuning constants. A -DOSR_EXPERIMENT build (never shipped; scripts/ab_*.sh) reads them from the environment instead, so
+// that one box can compare settings; the product library has no environment dependence.
+#ifdef OSR_EXPERIMENT
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
 }
-static int rpn_big_min_tiles() { static const int v = env_int("OSR_RPN_BIG_MIN_TILES", 512); return v; }  // fused CF-RPN head: 256-row tiles from this many tiles on
-static int tap_minor_default() { static const int v = env_int("OSR_CONV_TAP_MINOR", 1); return v; }
+#define OSR_KNOB(name, dflt) ([] { static const int v = env_int(name, dflt); return v; }())
+#else
+#define OSR_KNOB(name, dflt) (dflt)
+#endif
+static int rpn_big_min_tiles() { return OSR_KNOB("OSR_RPN_BIG_MIN_TILES", 512); }  // fused CF-RPN head: 256-row tiles from this many tiles on
+static int tap_minor_default() { return OSR_KNOB("OSR_CONV_TAP_MINOR", 1); }
 
 template <class K>
 static void allow_big_lds(K kernel) {
@@ -510,7 +517,7 @@ static void allow_big_lds(K kernel) {
 
 // Tile configurations of the plain conv / FC kernel.
 enum Conv64Tile { T128x128_1 = 1, T128x128_2, T256x256_2, T128x256_1, T256x128_1, T128x64_1, T128x64_2 };
-static int force_tile() { static const int v = env_int("OSR_CONV_FORCE_TILE", 0); return v; }  // diagnostic: one configuration for every layer it fits
+static int force_tile() { return OSR_KNOB("OSR_CONV_FORCE_TILE", 0); }  // diagnostic: one configuration for every layer it fits
 
 template <class TI, class TO, int BM, int BN, int WM, int WN, int TWO>
 static void conv64_launch_tile(Conv64Args& a, hipStream_t st) {
@@ -520,8 +527,8 @@ static void conv64_launch_tile(Conv64Args& a, hipStream_t st) {
     a.tiles_n = (a.p.cout + BN - 1) / BN;
     const size_t lds = conv64_lds_bytes(BM, BN, TWO, NW);
     if (lds > 64 * 1024) {
-        static thread_local bool attr = false;
-        if (!attr) { allow_big_lds(conv_igemm64_kernel<TI, TO, BM, BN, WM, WN, 0, TWO>); attr = true; }
+        static osr_dev_mask attr{0};
+        osr_once_per_device(attr, [] { allow_big_lds(conv_igemm64_kernel<TI, TO, BM, BN, WM, WN, 0, TWO>); });
     }
     hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, BM, BN, WM, WN, 0, TWO>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(NW * 64), lds, st, a);
 }
@@ -556,10 +563,7 @@ static double conv64_tile_us(const TileCfg& c, int nk, int residents, bool res) 
 // moves half the L2 -> LDS and LDS -> register bytes per FLOP of the 128 x 128 tile, which is what counts once both streams
 // compete for a CU (same-box end-to-end A/B with the per-configuration rates above: 1.00 -> 1169, 0.85 -> 1221, 0.75 -> 1219,
 // 0.65 -> 1208 img/s).
-static double model_big_scale() {
-    static const double v = [] { const char* e = getenv("OSR_CONV_MODEL_BIG"); return e ? atof(e) / 100.0 : 0.8; }();
-    return v;
-}
+static double model_big_scale() { return OSR_KNOB("OSR_CONV_MODEL_BIG", 80) / 100.0; }
 
 static int conv64_pick_tile(const Conv64Args& a) {
     const int nk = a.K / 64, cout = a.p.cout;
@@ -612,8 +616,8 @@ static osr_status cfrpn_fused_launch(Conv64Args& a, hipStream_t st) {
         const size_t t_bytes = (size_t)256 * (256 + 8) * 2, stages = (size_t)2 * (256 + 256) * 128;
         a.tail_lds_off = (int)(t_bytes > stages ? t_bytes : stages);
         const size_t lds = (size_t)a.tail_lds_off + 5 * 256 * 4;
-        static thread_local bool attr8 = false;
-        if (!attr8) { allow_big_lds(conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1, 1>); attr8 = true; }
+        static osr_dev_mask attr8{0};
+        osr_once_per_device(attr8, [] { allow_big_lds(conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1, 1>); });
         hipLaunchKernelGGL((conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1, 1>), dim3((unsigned)a.tiles_m), dim3(512), lds, st, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { osr_set_error("osr_cfrpn_head_fwd: launch failed: %s", hipGetErrorString(e)); return OSR_ERR_LAUNCH; }
@@ -624,8 +628,8 @@ static osr_status cfrpn_fused_launch(Conv64Args& a, hipStream_t st) {
     const size_t t_bytes = (size_t)128 * (256 + 8) * 2, stage = (size_t)(128 + 256) * 128;
     a.tail_lds_off = (int)(t_bytes > stage ? t_bytes : stage);
     const size_t lds = (size_t)a.tail_lds_off + 5 * 256 * 4;
-    static thread_local bool attr = false;
-    if (!attr) { allow_big_lds(conv_igemm64_kernel<TI, TI, 128, 256, 2, 2, 1, 0>); attr = true; }
+    static osr_dev_mask attr{0};
+    osr_once_per_device(attr, [] { allow_big_lds(conv_igemm64_kernel<TI, TI, 128, 256, 2, 2, 1, 0>); });
     hipLaunchKernelGGL((conv_igemm64_kernel<TI, TI, 128, 256, 2, 2, 1, 0>), dim3((unsigned)a.tiles_m), dim3(256), lds, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { osr_set_error("osr_cfrpn_head_fwd: launch failed: %s", hipGetErrorString(e)); return OSR_ERR_LAUNCH; }

@@ -267,11 +267,10 @@ extern "C" osr_status osr_nms_topk(const float* boxes, const float* scores, cons
     long long np = pow2ceil(seg_stride);
     const int lds_cap = (int)(np <= SORT_LDS_CAP ? np : SORT_LDS_CAP);
     const size_t smem = (size_t)lds_cap * 8 + 128;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in; 160 KB per CU on gfx950
+    static osr_dev_mask attr_set{0};
+    osr_once_per_device(attr_set, [] {  // > 64 KB of dynamic LDS needs the opt-in (per device); 160 KB per CU on gfx950
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seg_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_CAP * 8 + 128);
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL(seg_sort_kernel, dim3(num_segments), dim3(SORT_THREADS), smem, st, scores, cand, (long long)seg_stride, seg_len, ws_order,
                        ws_count, ws_keys, ks, lds_cap);
     OSR_CHECK_LAUNCH("osr_nms_topk(sort)");

@@ -605,7 +605,9 @@ extern "C" osr_status osr_pool_bwd(const void* src, int32_t hs, int32_t ws, cons
 // ------------------------------------------------------------------------------------------------------
 template <class T>
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ v, long long n, float lr, float mu,
-                                                  float wd, float grad_scale, const float* __restrict__ row_scale, long long row_elems, T* __restrict__ lp) {
+                                                  float wd, float grad_scale, const float* __restrict__ row_scale, long long row_elems, T* __restrict__ lp,
+                                                  const int* __restrict__ gate) {
+    if (gate && *gate == 0) return;  // this iteration's gradients held an inf / NaN (osr_check_finite): leave parameters and momentum alone
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float rs = row_scale ? row_scale[i / row_elems] : 1.0f;
         const float gi = g[i] * grad_scale * rs + wd * p[i];
@@ -618,7 +620,8 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 }
 
 extern "C" osr_status osr_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum, float weight_decay,
-                                   float grad_scale, const float* row_scale, int64_t row_elems, void* lowp_copy, int32_t lowp_dtype, void* stream) {
+                                   float grad_scale, const float* row_scale, int64_t row_elems, void* lowp_copy, int32_t lowp_dtype, const int32_t* apply_flag,
+                                   void* stream) {
     OSR_REQUIRE(param && grad && momentum_buf && n >= 0, OSR_ERR_INVALID_ARG, "osr_sgd_step: null pointer / bad n");
     OSR_REQUIRE(!row_scale || row_elems >= 1, OSR_ERR_INVALID_ARG, "osr_sgd_step: row_elems must be >= 1 with a row scale");
     OSR_REQUIRE(!lowp_copy || osr_dtype_ok(lowp_dtype), OSR_ERR_INVALID_ARG, "osr_sgd_step: bad low-precision dtype");
@@ -627,11 +630,39 @@ extern "C" osr_status osr_sgd_step(float* param, const float* grad, float* momen
     const dim3 grid((unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192));
     const long long re = row_scale ? row_elems : 1;
     if (!lowp_copy || lowp_dtype == OSR_F32)
-        hipLaunchKernelGGL(sgd_kernel<float>, grid, dim3(256), 0, st, param, grad, momentum_buf, (long long)n, lr, momentum, weight_decay, grad_scale, row_scale, re, (float*)lowp_copy);
+        hipLaunchKernelGGL(sgd_kernel<float>, grid, dim3(256), 0, st, param, grad, momentum_buf, (long long)n, lr, momentum, weight_decay, grad_scale, row_scale, re, (float*)lowp_copy, apply_flag);
     else if (lowp_dtype == OSR_F16)
-        hipLaunchKernelGGL(sgd_kernel<f16_t>, grid, dim3(256), 0, st, param, grad, momentum_buf, (long long)n, lr, momentum, weight_decay, grad_scale, row_scale, re, (f16_t*)lowp_copy);
+        hipLaunchKernelGGL(sgd_kernel<f16_t>, grid, dim3(256), 0, st, param, grad, momentum_buf, (long long)n, lr, momentum, weight_decay, grad_scale, row_scale, re, (f16_t*)lowp_copy, apply_flag);
     else
-        hipLaunchKernelGGL(sgd_kernel<bf16_t>, grid, dim3(256), 0, st, param, grad, momentum_buf, (long long)n, lr, momentum, weight_decay, grad_scale, row_scale, re, (bf16_t*)lowp_copy);
+        hipLaunchKernelGGL(sgd_kernel<bf16_t>, grid, dim3(256), 0, st, param, grad, momentum_buf, (long long)n, lr, momentum, weight_decay, grad_scale, row_scale, re, (bf16_t*)lowp_copy, apply_flag);
     OSR_CHECK_LAUNCH("osr_sgd_step");
+    return OSR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Overflow guard of the fp16 training step (static / dynamic loss scaling): *flag is cleared when any x[i] is inf or NaN.
+// The caller presets *flag = 1 once per iteration, runs this over the (all-reduced) flat gradient buffer and hands the flag to
+// every osr_sgd_step launch of the iteration, which then leave parameters and momentum untouched -- no host sync in between.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void check_finite_kernel(const float* __restrict__ x, long long n, int* __restrict__ flag) {
+    bool bad = false;
+    const long long n4 = n >> 2, stride = (long long)gridDim.x * blockDim.x;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = x4[i];
+        bad |= !(osr_finite(v.x) && osr_finite(v.y) && osr_finite(v.z) && osr_finite(v.w));
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) bad |= !osr_finite(x[i]);
+    if (__any(bad) && (threadIdx.x & 63) == 0) *flag = 0;  // every racing writer stores the same value
+}
+
+extern "C" osr_status osr_check_finite(const float* x, int64_t n, int32_t* flag, void* stream) {
+    OSR_REQUIRE(x && flag && n >= 0, OSR_ERR_INVALID_ARG, "osr_check_finite: null pointer / bad n");
+    OSR_REQUIRE((((uintptr_t)x) & 15) == 0, OSR_ERR_INVALID_ARG, "osr_check_finite: x must be 16-byte aligned");
+    if (n == 0) return OSR_OK;
+    const long long blocks = (n / 4 + 255) / 256;
+    hipLaunchKernelGGL(check_finite_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks < 4096 ? blocks : 4096))), dim3(256), 0, (hipStream_t)stream, x, (long long)n,
+                       flag);
+    OSR_CHECK_LAUNCH("osr_check_finite");
     return OSR_OK;
 }

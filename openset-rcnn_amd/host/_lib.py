@@ -106,7 +106,8 @@ PROTOTYPES = {
     "osr_relu_mask": (I32, [P, I32, P, I32, I64, P]),
     "osr_add_cast": (I32, [P, P, P, I32, I64, P]),
     "osr_pool_bwd": (I32, [P, I32, I32, P, P, I32, I32, I32, I32, I32, I32, P]),
-    "osr_sgd_step": (I32, [P, P, P, I64, F32, F32, F32, F32, P, I64, P, I32, P]),
+    "osr_sgd_step": (I32, [P, P, P, I64, F32, F32, F32, F32, P, I64, P, I32, P, P]),
+    "osr_check_finite": (I32, [P, I64, P, P]),
 }
 
 _lib = None

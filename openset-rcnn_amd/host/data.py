@@ -57,16 +57,20 @@ class DatasetMapper:
             self.min_sizes, self.max_size, self.flip = (cfg.INPUT.MIN_SIZE_TEST,), cfg.INPUT.MAX_SIZE_TEST, False
         self.rng = np.random.RandomState(seed)
 
-    def __call__(self, d: dict) -> dict:
+    def __call__(self, d: dict, sample_seed: Optional[int] = None) -> dict:
+        """sample_seed: draw this sample's augmentation (flip, training size) from its own seeded stream instead of the mapper's
+        running one -- the train loader passes f(seed, position in the sample stream), which makes every sample's augmentation
+        independent of how many samples were mapped before it (a resumed run skips positions without decoding images)."""
+        rng = self.rng if sample_seed is None else np.random.RandomState(sample_seed % (2 ** 31))
         img = read_image(d["file_name"], self.format)
         h, w = img.shape[:2]
         out = {k: v for k, v in d.items() if k != "annotations"}
         out.setdefault("height", h)
         out.setdefault("width", w)
-        do_flip = self.flip and self.rng.rand() < 0.5
+        do_flip = self.flip and rng.rand() < 0.5
         if do_flip:
             img = img[:, ::-1]
-        size = int(self.min_sizes[self.rng.randint(len(self.min_sizes))]) if self.is_train else int(self.min_sizes[0])
+        size = int(self.min_sizes[rng.randint(len(self.min_sizes))]) if self.is_train else int(self.min_sizes[0])
         nh, nw = shortest_edge_size(h, w, size, self.max_size) if size > 0 else (h, w)
         img = resize_image(np.ascontiguousarray(img), (nh, nw))
         out["image"] = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1)))
@@ -97,10 +101,13 @@ def build_detection_test_loader(dataset_dicts: Sequence[dict], mapper: Callable[
 
 
 def build_detection_train_loader(dataset_dicts: Sequence[dict], mapper: Callable[[dict], dict], images_per_batch: int, seed: int = 0,
-                                 rank: Optional[int] = None, world: Optional[int] = None, filter_empty: bool = True) -> Iterator[List[dict]]:
+                                 rank: Optional[int] = None, world: Optional[int] = None, filter_empty: bool = True,
+                                 start_iter: int = 0) -> Iterator[List[dict]]:
     """Infinite stream of per-rank batches (images_per_batch is the GLOBAL batch, SOLVER.IMS_PER_BATCH): a seeded permutation per
     epoch shared by all ranks, rank r takes elements r, r+world, ... ([d2] TrainingSampler); images without annotations are dropped
-    first (DATALOADER.FILTER_EMPTY_ANNOTATIONS)."""
+    first (DATALOADER.FILTER_EMPTY_ANNOTATIONS). start_iter: the first batch yielded is the one iteration `start_iter` of an
+    uninterrupted run would have seen -- the skipped positions only advance the permutation (no image is read), and every
+    sample's augmentation is seeded by (seed, its position), so a resumed run continues the exact data stream."""
     if rank is None or world is None:
         rank, world = world_info()
     assert images_per_batch % world == 0, "IMS_PER_BATCH must be divisible by the number of ranks"
@@ -108,11 +115,16 @@ def build_detection_train_loader(dataset_dicts: Sequence[dict], mapper: Callable
     dicts = [d for d in dataset_dicts if not filter_empty or len(d.get("annotations", [])) > 0]
     g = torch.Generator().manual_seed(seed)
     batch: List[dict] = []
-    pos = 0
+    pos, skip = 0, start_iter * images_per_batch  # positions of the global sample stream consumed by iterations < start_iter
+    seeded = isinstance(mapper, DatasetMapper)
     while True:
-        for idx in torch.randperm(len(dicts), generator=g).tolist():
-            if pos % world == rank:
-                batch.append(mapper(dicts[idx]))
+        perm = torch.randperm(len(dicts), generator=g).tolist()
+        if skip - pos >= len(perm):  # a whole epoch lies before the resume point
+            pos += len(perm)
+            continue
+        for idx in perm:
+            if pos >= skip and pos % world == rank:
+                batch.append(mapper(dicts[idx], sample_seed=seed * 1000003 + pos) if seeded else mapper(dicts[idx]))
                 if len(batch) == per_rank:
                     yield batch
                     batch = []

@@ -14,8 +14,6 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence, Tuple
 
-import os
-
 import torch
 
 from . import ops
@@ -282,11 +280,6 @@ class OpensetRCNNEngine:
         outs = []
         base, extra = divmod(n, ns)
         sizes = [base + (1 if i < extra else 0) for i in range(ns)]
-        split = os.environ.get("OSR_MB_SPLIT")  # experiment knob: explicit micro-batch sizes, e.g. "10,6"
-        if split:
-            req = [int(x) for x in split.split(",")]
-            if len(req) == ns and sum(req) == n and min(req) > 0:
-                sizes = req
         lo = 0
         for i in range(ns):
             hi = lo + sizes[i]
@@ -329,30 +322,30 @@ class OpensetRCNNEngine:
         return self.id_map[cls].contiguous(), self.cfg["num_known"]  # a gather: cls == -1 reads the last slot (-1)
 
     # ---- training step, forward half ----------------------------------------------------------------------
-    def forward_losses(self, images: torch.Tensor, image_hw: torch.Tensor, hp: int, wp: int, gt_boxes: torch.Tensor,
-                       gt_classes: torch.Tensor, gt_count: torch.Tensor, keys: Dict[str, torch.Tensor], keep: Optional[dict] = None):
-        """GeneralizedRCNN.forward in training mode, forward values only (no gradients yet): the loss dict of
-        ClsFreeRPN.forward (classification_free_rpn.py:493-547) and OpensetROIHeads._forward_box (osrcnn_roi_heads.py:282-
-        318) for a batch, every tensor staying on the GPU. gt_boxes (n,gmax,4) fp32 / gt_classes (n,gmax) int64 padded,
-        gt_count (n) int32. keys: uniform fp32 sampling keys 'rpn_reg' (n,R), 'rpn_obj' (n,R), 'roi' (n, cap+gmax) -- the
-        randomness [d2] subsample_labels draws with torch.randperm (see include/osr.h). Returns a dict of 0-d / small GPU
-        tensors named as the reference names its losses."""
-        c = self.cfg
-        n = images.shape[0]
-        feats = self._backbone(images, hp, wp, keep)
-        sel = self._rpn(feats, image_hw, keep, topk=c["pre_nms_topk_train"])
-        lv = sel["levels"]
+    def rpn_losses_forward(self, sel: dict, n: int, gt_boxes: torch.Tensor, gt_count: torch.Tensor, keys: Dict[str, torch.Tensor],
+                           keep: Optional[dict] = None):
+        """ClsFreeRPN.label_and_sample_anchors + .losses (classification_free_rpn.py:320-491) on the head outputs `sel` carries
+        (level-major pred_deltas / pred_ctr). Returns (6 floats: loss_rpn_loc, loss_rpn_ctr, 4 anchor counts; state dict that the
+        backward needs: labels, obj_labels, matched_boxes, ctr_target)."""
+        c, lv = self.cfg, sel["levels"]
         midx, miou, lab, olab = ops.rpn_match_anchors(lv, self.cell_anchors, n, gt_boxes, gt_count, c["rpn_iou_thresholds"],
                                                       c["rpn_iou_thresholds_objectness"])
         if keep is not None:
-            keep.update(feats=feats, sel=sel, matched_idx=midx, matched_iou=miou, labels_pre=lab.clone(), obj_labels_pre=olab.clone())
+            keep.update(matched_idx=midx, matched_iou=miou, labels_pre=lab.clone(), obj_labels_pre=olab.clone())
         ops.subsample_labels_(lab, keys["rpn_reg"], c["rpn_batch_size"], c["rpn_positive_fraction"])
         ops.subsample_labels_(olab, keys["rpn_obj"], c["rpn_batch_size"], c["rpn_positive_fraction_objectness"])
         mboxes, ctr_t = ops.rpn_anchor_targets(lv, self.cell_anchors, n, gt_boxes, gt_count, midx, olab)
         rpn = ops.rpn_losses_fwd(lv, self.cell_anchors, n, sel["pred_deltas"], sel["pred_ctr"], lab, olab, mboxes, ctr_t,
                                  c["rpn_loc_weight"], c["rpn_ctr_weight"], c["rpn_batch_size"])
-        # RoI heads: proposals are fixed inputs here (predict_proposals runs under no_grad, :575)
-        smp = ops.roi_match_and_sample(sel["boxes"], sel["scores"], sel["counts"], gt_boxes, gt_classes, gt_count, keys["roi"],
+        return rpn, dict(labels=lab, obj_labels=olab, matched_boxes=mboxes, ctr_target=ctr_t)
+
+    def roi_losses_forward(self, feats: Dict[str, torch.Tensor], prop_boxes, prop_scores, prop_counts, gt_boxes, gt_classes, gt_count,
+                           keys_roi: torch.Tensor):
+        """OpensetROIHeads.label_and_sample_proposals + _forward_box in training mode (osrcnn_roi_heads.py:137-230,282-318):
+        proposals are fixed inputs (predict_proposals runs under no_grad, classification_free_rpn.py:575). Returns (losses of the
+        four heads as a dict of GPU scalars + 'roi_counts', state dict with every activation the backward reads)."""
+        c = self.cfg
+        smp = ops.roi_match_and_sample(prop_boxes, prop_scores, prop_counts, gt_boxes, gt_classes, gt_count, keys_roi,
                                        c["num_classes"], c["roi_batch_size"], c["roi_positive_fraction"], c["roi_iou_threshold"])
         boxes = smp["boxes"].view(-1, 4)
         pooled = ops.roi_align([feats[k] for k in ("p2", "p3", "p4", "p5")], c["pooler_scales"], boxes, smp["batch_idx"],
@@ -370,11 +363,30 @@ class OpensetRCNNEngine:
         dml = ops.pln_loss_fwd(emb, self.protos, cls_k, ious, c["pln_iou_threshold"], c["pln_alpha"], c["pln_beta"], c["pln_loss_weight"])
         logits = ops.gemm_f32(rec, self.cls_w, self.cls_b)
         ce = ops.softmax_ce_loss_fwd(logits, cls_k, nck, c["cls_loss_weight"])
+        state = dict(smp=smp, sampled=smp, boxes=boxes, pooled=pooled, h1=h1, box_feats=box_feats, pred=pred, emb=emb, rec=rec, logits=logits,
+                     cls=cls, ious=ious, cls_k=cls_k, nck=nck)
+        return dict(loss_box_reg=box[0], loss_iou=box[1], loss_dml=dml[0], loss_cls=ce[0], roi_counts=smp["counts"]), state
+
+    def forward_losses(self, images: torch.Tensor, image_hw: torch.Tensor, hp: int, wp: int, gt_boxes: torch.Tensor,
+                       gt_classes: torch.Tensor, gt_count: torch.Tensor, keys: Dict[str, torch.Tensor], keep: Optional[dict] = None):
+        """GeneralizedRCNN.forward in training mode, forward values only (no gradients yet): the loss dict of
+        ClsFreeRPN.forward (classification_free_rpn.py:493-547) and OpensetROIHeads._forward_box (osrcnn_roi_heads.py:282-
+        318) for a batch, every tensor staying on the GPU. gt_boxes (n,gmax,4) fp32 / gt_classes (n,gmax) int64 padded,
+        gt_count (n) int32. keys: uniform fp32 sampling keys 'rpn_reg' (n,R), 'rpn_obj' (n,R), 'roi' (n, cap+gmax) -- the
+        randomness [d2] subsample_labels draws with torch.randperm (see include/osr.h). Returns a dict of 0-d / small GPU
+        tensors named as the reference names its losses."""
+        c = self.cfg
+        n = images.shape[0]
+        feats = self._backbone(images, hp, wp, keep)
+        sel = self._rpn(feats, image_hw, keep, topk=c["pre_nms_topk_train"])
         if keep is not None:
-            keep.update(labels=lab, obj_labels=olab, matched_boxes=mboxes, ctr_target=ctr_t, sampled=smp, pooled=pooled, box_feats=box_feats,
-                        pred=pred, emb=emb, rec=rec, logits=logits)
-        return dict(loss_rpn_loc=rpn[0], loss_rpn_ctr=rpn[1], loss_box_reg=box[0], loss_iou=box[1], loss_dml=dml[0], loss_cls=ce[0],
-                    rpn_anchor_counts=rpn[2:], roi_counts=smp["counts"])
+            keep.update(feats=feats, sel=sel)
+        rpn, rpn_state = self.rpn_losses_forward(sel, n, gt_boxes, gt_count, keys, keep)
+        roi, roi_state = self.roi_losses_forward(feats, sel["boxes"], sel["scores"], sel["counts"], gt_boxes, gt_classes, gt_count, keys["roi"])
+        if keep is not None:
+            keep.update(rpn_state)
+            keep.update({k: roi_state[k] for k in ("sampled", "pooled", "box_feats", "pred", "emb", "rec", "logits")})
+        return dict(loss_rpn_loc=rpn[0], loss_rpn_ctr=rpn[1], rpn_anchor_counts=rpn[2:], **roi)
 
     @staticmethod
     def to_instances(result, n: int) -> List[dict]:

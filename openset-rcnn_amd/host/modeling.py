@@ -7,9 +7,13 @@ registered names the yaml files select --
 
 -- with the same constructor configuration keys, forward signatures, output field names and state-dict key names.
 The modules own fp32 parameters under detectron2's names (checkpoint compatible); their inference forwards run on
-the HIP library through `OpensetRCNNEngine` (no eager path). Training: `GeneralizedRCNN.make_trainer()` returns the object whose
-`step()` is the trainer loop body (forward, explicit backward, SGD); `losses_forward` evaluates the loss dict only; module
-forwards in training mode raise, because they cannot return losses that carry autograd gradients.
+the HIP library through `OpensetRCNNEngine` (no eager path). Training: `model(batched_inputs)` in training mode returns the six
+losses as GPU scalars whose sum's `.backward()` runs the explicit HIP backward (no autograd graph is recorded: one
+torch.autograd.Function stands for the whole step), so the loop body of train.py:135-146 runs as written with
+`solver.build_optimizer` / `build_lr_scheduler`; `GeneralizedRCNN.make_trainer()` returns the object that does the work
+(`trainer.step()` = forward + backward + all-reduce + SGD in one call). `ClsFreeRPN.forward(..., gt_instances)` and
+`OpensetROIHeads.forward(..., targets)` return `(proposals, losses)` with the reference's keys -- loss VALUES: gradients exist
+only through the model-level call, which fuses both modules' backward passes into one explicit sequence of launches.
 Feature maps cross these signatures as logical (N,C,H,W) tensors in channels_last memory (= the kernels' NHWC)."""
 from __future__ import annotations
 
@@ -21,7 +25,7 @@ from torch import nn
 
 from . import ops
 from .config import CfgNode
-from .engine import OpensetRCNNEngine
+from .engine import DEFAULT_CFG, OpensetRCNNEngine
 from .structures import Boxes, ImageList, Instances, ShapeSpec
 from .weights import R50_BLOCKS, R50_MID, fold_frozen_bn
 
@@ -60,8 +64,46 @@ RPN_HEAD_REGISTRY = Registry("RPN_HEAD")
 ROI_HEADS_REGISTRY = Registry("ROI_HEADS")
 ROI_BOX_HEAD_REGISTRY = Registry("ROI_BOX_HEAD")
 
-_TRAIN_MSG = ("model(batched_inputs) in training mode must return losses that carry autograd gradients; the HIP path has no autograd graph. "
-              "Use GeneralizedRCNN.make_trainer().step(...) (forward + explicit backward + SGD) or .losses_forward(...) (loss values only)")
+
+
+def pad_ground_truth(instances: List["Instances"]):
+    """list[Instances{gt_boxes, gt_classes}] -> padded CPU tensors (n,gmax,4) fp32, (n,gmax) int64, (n) int32 counts."""
+    n = len(instances)
+    gmax = max(1, max(len(x) for x in instances))
+    gt = torch.zeros((n, gmax, 4), dtype=torch.float32)
+    gcls = torch.zeros((n, gmax), dtype=torch.int64)
+    gcnt = torch.zeros((n,), dtype=torch.int32)
+    for i, x in enumerate(instances):
+        k = len(x)
+        gcnt[i] = k
+        if k:
+            gt[i, :k] = x.gt_boxes.tensor.float().cpu()
+            gcls[i, :k] = x.gt_classes.cpu()
+    return gt, gcls, gcnt
+
+
+class _ExplicitBackward(torch.autograd.Function):
+    """Stands for the whole training step in torch's autograd: forward hands out the six loss values the HIP kernels computed,
+    backward runs OpensetRCNNTrainer._backward (the explicit sequence of data-gradient / weight-gradient launches) when
+    `losses.backward()` reaches it. The gradients land in the trainer's flat fp32 buffer, where the optimizer mirror reads them."""
+
+    @staticmethod
+    def forward(ctx, hook, trainer, saved, n, *values):
+        ctx.trainer, ctx.saved, ctx.n = trainer, saved, n
+        return tuple(v.detach().clone() for v in values)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if ctx.saved is None:
+            raise RuntimeError("the HIP backward of this iteration has already run (its saved activations are released)")
+        vals = [float(g) if g is not None else 0.0 for g in grads]  # one small D2H read; train.py:138 syncs on the losses anyway
+        if min(vals) != max(vals) or vals[0] <= 0.0:
+            raise NotImplementedError(f"the HIP backward differentiates a uniformly weighted sum of the six losses (train.py:136); got d total / d loss = {vals}")
+        ctx.trainer._backward(ctx.saved, ctx.n, grad_scale=vals[0])
+        ctx.trainer.grads_ready = True
+        ctx.saved = None
+        return (None,) * (4 + len(grads))
+
 
 
 def _to_nhwc(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -251,6 +293,8 @@ class ClsFreeRPN(nn.Module):
         self.min_box_size = float(cfg.MODEL.PROPOSAL_GENERATOR.MIN_SIZE)
         self.loss_weight = {"loss_rpn_loc": cfg.MODEL.RPN.BBOX_REG_LOSS_WEIGHT * cfg.MODEL.RPN.LOSS_WEIGHT,
                             "loss_rpn_ctr": cfg.MODEL.RPN.CTR_REG_LOSS_WEIGHT * cfg.MODEL.RPN.LOSS_WEIGHT}
+        self.rpn_head._eng_cfg = engine_cfg_from(cfg)  # a stand-alone ClsFreeRPN trains / selects with the yaml's hyper-parameters
+        self.sampler_generator = torch.Generator().manual_seed(max(int(cfg.SEED), 0))  # uniform keys replacing torch.randperm (H6)
 
     def select(self, features: Dict[str, torch.Tensor], image_sizes: List[Tuple[int, int]]):
         """Device-resident result of predict_proposals (padded arrays + counts), as the engine consumes it."""
@@ -265,13 +309,24 @@ class ClsFreeRPN(nn.Module):
         lv = ops.make_rpn_levels(shapes, self.strides, n, 1)
         cell = torch.tensor([[[-s / 2, -s / 2, s / 2, s / 2]] for s in self.anchor_sizes], dtype=torch.float32, device=dev)
         hw = torch.tensor(image_sizes, dtype=torch.int32, device=dev)
-        return ops.rpn_select(lv, cell, c_cat, d_cat, n, hw, int(self.pre_nms_topk[self.training]), self.min_box_size), hw
+        sel = ops.rpn_select(lv, cell, c_cat, d_cat, n, hw, int(self.pre_nms_topk[self.training]), self.min_box_size)
+        sel.update(pred_deltas=d_cat, pred_ctr=c_cat, levels=lv)
+        return sel, hw
 
     def forward(self, images: ImageList, features: Dict[str, torch.Tensor], gt_instances: Optional[List[Instances]] = None):
-        if self.training:
-            assert gt_instances is not None, "RPN requires gt_instances in training!"
-            raise NotImplementedError(_TRAIN_MSG)
         sel, _ = self.select(features, images.image_sizes)
+        losses = {}
+        if self.training:
+            # classification_free_rpn.py:531-547: targets + both losses on the head outputs. Loss VALUES (GPU scalars): the
+            # gradients of a training step come from the model-level call (see the module docstring).
+            assert gt_instances is not None, "RPN requires gt_instances in training!"
+            n, dev = len(gt_instances), sel["boxes"].device
+            gt, _, gcnt = pad_ground_truth(gt_instances)
+            r = sel["pred_ctr"].numel() // n
+            keys = {k: torch.rand((n, r), generator=self.sampler_generator).to(dev) for k in ("rpn_reg", "rpn_obj")}
+            with torch.no_grad():
+                rpn, _ = self.rpn_head.engine().rpn_losses_forward(sel, n, gt.to(dev), gcnt.to(dev), keys)
+            losses = {"loss_rpn_loc": rpn[0], "loss_rpn_ctr": rpn[1]}
         counts = sel["counts"].cpu().tolist()  # the list-of-Instances API needs the lengths on the host
         out = []
         for i, size in enumerate(images.image_sizes):
@@ -279,7 +334,7 @@ class ClsFreeRPN(nn.Module):
             r.proposal_boxes = Boxes(sel["boxes"][i, : counts[i]])
             r.objectness_logits = sel["scores"][i, : counts[i]]
             out.append(r)
-        return out, {}
+        return out, losses
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -339,7 +394,16 @@ class SoftMaxClassifier(nn.Module):
 
 def engine_cfg_from(cfg: CfgNode) -> dict:
     """yaml keys -> engine hyper-parameters."""
-    rh, bh = cfg.MODEL.ROI_HEADS, cfg.MODEL.ROI_BOX_HEAD
+    rh, bh, rpn = cfg.MODEL.ROI_HEADS, cfg.MODEL.ROI_BOX_HEAD, cfg.MODEL.RPN
+    # what the loss kernels implement (the two shipped yaml files select exactly these; anything else would silently train another loss)
+    if cfg.MODEL.PROPOSAL_GENERATOR.NAME == "ClsFreeRPN" and rpn.BBOX_REG_LOSS_TYPE != "iou":
+        raise NotImplementedError(f"MODEL.RPN.BBOX_REG_LOSS_TYPE '{rpn.BBOX_REG_LOSS_TYPE}': the HIP CF-RPN loss implements \"iou\" "
+                                  "(box_regression_w_iou.py:49-61), as both Openset yaml files select")
+    for key, typ, beta in (("MODEL.RPN.CTR_REG_LOSS_TYPE", rpn.CTR_REG_LOSS_TYPE, rpn.CTR_SMOOTH_L1_BETA),
+                           ("MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE", bh.BBOX_REG_LOSS_TYPE, bh.SMOOTH_L1_BETA),
+                           ("MODEL.ROI_BOX_HEAD.IOU_REG_LOSS_TYPE", bh.IOU_REG_LOSS_TYPE, bh.IOU_SMOOTH_L1_BETA)):
+        if typ != "smooth_l1" or float(beta) != 0.0:
+            raise NotImplementedError(f"{key} '{typ}' with beta {beta}: the HIP losses implement smooth_l1 with beta 0 (= L1), the yaml default")
     return dict(
         pixel_mean=tuple(cfg.MODEL.PIXEL_MEAN), pixel_std=tuple(cfg.MODEL.PIXEL_STD),
         anchor_sizes=tuple(float(s[0]) for s in cfg.MODEL.ANCHOR_GENERATOR.SIZES),
@@ -355,7 +419,7 @@ def engine_cfg_from(cfg: CfgNode) -> dict:
         pre_nms_topk_train=cfg.MODEL.RPN.PRE_NMS_TOPK_TRAIN, rpn_batch_size=cfg.MODEL.RPN.BATCH_SIZE_PER_IMAGE,
         rpn_positive_fraction=cfg.MODEL.RPN.POSITIVE_FRACTION, rpn_positive_fraction_objectness=cfg.MODEL.RPN.POSITIVE_FRACTION_OBJECTNESS,
         rpn_iou_thresholds=tuple(cfg.MODEL.RPN.IOU_THRESHOLDS), rpn_iou_thresholds_objectness=tuple(cfg.MODEL.RPN.IOU_THRESHOLDS_OBJECTNESS),
-        rpn_loc_weight=cfg.MODEL.RPN.BBOX_REG_LOSS_WEIGHT, rpn_ctr_weight=cfg.MODEL.RPN.CTR_REG_LOSS_WEIGHT,
+        rpn_loc_weight=rpn.BBOX_REG_LOSS_WEIGHT * rpn.LOSS_WEIGHT, rpn_ctr_weight=rpn.CTR_REG_LOSS_WEIGHT * rpn.LOSS_WEIGHT,
         roi_batch_size=rh.BATCH_SIZE_PER_IMAGE, roi_positive_fraction=rh.POSITIVE_FRACTION, roi_iou_threshold=float(rh.IOU_THRESHOLDS[0]),
         box_reg_weight=bh.BBOX_REG_LOSS_WEIGHT, iou_reg_weight=bh.IOU_REG_LOSS_WEIGHT, pln_alpha=cfg.MODEL.PLN.ALPHA, pln_beta=cfg.MODEL.PLN.BETA,
         pln_iou_threshold=cfg.MODEL.PLN.IOU_THRESHOLD, pln_loss_weight=cfg.MODEL.PLN.LOSS_WEIGHT, cls_loss_weight=bh.CLS_LOSS_WEIGHT,
@@ -384,18 +448,15 @@ class OpensetROIHeads(_EngineOwner):
         self._eng_cfg["pooler_scales"] = self.pooler_scales
         # GraspNet: sorted contiguous ids of the known categories (prototype_learning_network.py:80-95); VOC-COCO: identity
         self._class_map = class_id
+        self.sampler_generator = torch.Generator().manual_seed(max(int(cfg.SEED), 0))  # uniform keys replacing torch.randperm (H6)
 
     def forward_device(self, features: Dict[str, torch.Tensor], sel: dict, image_hw: torch.Tensor):
         eng = self.engine()
         feats = {k: _to_nhwc(features[k], eng.dtype) for k in self.in_features}
         return eng._roi_heads(feats, sel, image_hw)
 
-    def forward(self, images: ImageList, features: Dict[str, torch.Tensor], proposals: List[Instances],
-                targets: Optional[List[Instances]] = None):
-        del images
-        if self.training:
-            assert targets, "'targets' argument is required during training"
-            raise NotImplementedError(_TRAIN_MSG)
+    @staticmethod
+    def _pack_proposals(proposals: List[Instances]):
         n = len(proposals)
         dev = proposals[0].proposal_boxes.tensor.device
         counts = [len(p) for p in proposals]
@@ -407,7 +468,43 @@ class OpensetROIHeads(_EngineOwner):
             boxes[i, : counts[i]] = p.proposal_boxes.tensor
             scores[i, : counts[i]] = p.objectness_logits
             bidx[i, : counts[i]] = i
-        sel = dict(boxes=boxes, scores=scores, batch_idx=bidx.view(-1), counts=torch.tensor(counts, dtype=torch.int32, device=dev), cap=cap)
+        return boxes, scores, bidx, torch.tensor(counts, dtype=torch.int32, device=dev), cap
+
+    def _forward_train(self, features: Dict[str, torch.Tensor], proposals: List[Instances], targets: List[Instances]):
+        """osrcnn_roi_heads.py:268-277: label_and_sample_proposals + the four head losses. Returns the sampled proposals (with
+        gt_classes / gt_boxes / ious attached, as :203-216 does) and the loss VALUES (see the module docstring for gradients)."""
+        eng = self.engine()
+        boxes, scores, _, counts, cap = self._pack_proposals(proposals)
+        n, dev = len(proposals), boxes.device
+        gt, gcls, gcnt = pad_ground_truth(targets)
+        keys = torch.rand((n, cap + gt.shape[1]), generator=self.sampler_generator).to(dev)
+        feats = {k: _to_nhwc(features[k], eng.dtype) for k in self.in_features}
+        with torch.no_grad():
+            losses, st = eng.roi_losses_forward(feats, boxes, scores, counts, gt.to(dev), gcls.to(dev), gcnt.to(dev), keys)
+        smp = st["smp"]
+        nsmp = smp["counts"][:, 0].cpu().tolist()  # rows actually sampled per image (<= BATCH_SIZE_PER_IMAGE)
+        out = []
+        for i, p in enumerate(proposals):
+            k = int(nsmp[i])
+            r = Instances(p.image_size)
+            r.proposal_boxes = Boxes(smp["boxes"][i, :k])
+            r.objectness_logits = smp["logits"][i, :k]
+            r.gt_classes = smp["gt_classes"][i, :k]
+            r.gt_boxes = Boxes(smp["gt_boxes"][i, :k])
+            r.ious = smp["ious"][i, :k]
+            out.append(r)
+        return out, {k: v for k, v in losses.items() if k.startswith("loss_")}
+
+    def forward(self, images: ImageList, features: Dict[str, torch.Tensor], proposals: List[Instances],
+                targets: Optional[List[Instances]] = None):
+        del images
+        if self.training:
+            assert targets, "'targets' argument is required during training"
+            return self._forward_train(features, proposals, targets)
+        n = len(proposals)
+        boxes, scores, bidx, counts, cap = self._pack_proposals(proposals)
+        dev = boxes.device
+        sel = dict(boxes=boxes, scores=scores, batch_idx=bidx.view(-1), counts=counts, cap=cap)
         hw = torch.tensor([p.image_size for p in proposals], dtype=torch.int32, device=dev)
         res = OpensetRCNNEngine.to_instances(self.forward_device(features, sel, hw), n)
         out = []
@@ -450,6 +547,9 @@ class GeneralizedRCNN(_EngineOwner):
         self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1), False)
         self._eng_cfg = engine_cfg_from(cfg)
         self._class_map = class_id
+        self._trainer = None
+        self._hook: Optional[torch.Tensor] = None
+        self.sampler_generator = torch.Generator().manual_seed(max(int(cfg.SEED), 0))  # uniform keys replacing torch.randperm (H6)
 
     @property
     def device(self):
@@ -461,20 +561,45 @@ class GeneralizedRCNN(_EngineOwner):
             child._shared = eng  # one packed copy of the weights for the whole model
         return eng
 
-    def refresh(self):
-        super().refresh()
-        for child in (self.backbone, self.proposal_generator.rpn_head, self.roi_heads):
-            child._shared = None
-            child.refresh()
-
     def preprocess_image(self, batched_inputs: List[dict]) -> ImageList:
         images = [(x["image"].to(self.device).float() - self.pixel_mean) / self.pixel_std for x in batched_inputs]
         return ImageList.from_tensors(images, self.backbone.size_divisibility)
 
     def forward(self, batched_inputs: List[dict]):
-        if self.training:
-            raise NotImplementedError(_TRAIN_MSG)
-        return self.inference(batched_inputs)
+        """[d2] GeneralizedRCNN.forward. Eval mode: list[{"instances": Instances}]. Training mode (train.py:135): the dict of the six
+        losses, GPU scalars whose sum's .backward() runs the explicit HIP backward of this iteration into the trainer's gradient
+        buffer (`solver.build_optimizer(cfg, model).step()` then all-reduces and applies it)."""
+        if not self.training:
+            return self.inference(batched_inputs)
+        trainer = self.trainer()
+        tensors = self._train_tensors(batched_inputs, self.sampler_generator)
+        with torch.no_grad():
+            trainer.poll_overflow()
+            losses, saved = trainer._forward(*tensors)
+        names = list(losses)
+        outs = _ExplicitBackward.apply(self._grad_hook(), trainer, saved, tensors[0].shape[0], *[losses[k] for k in names])
+        trainer.grads_ready = False
+        return dict(zip(names, outs))
+
+    def _grad_hook(self) -> torch.Tensor:
+        """A 0-d leaf that requires grad: what makes torch call _ExplicitBackward.backward (it receives no gradient itself)."""
+        if self._hook is None or self._hook.device != self.device:
+            self._hook = torch.zeros((), device=self.device, requires_grad=True)
+        return self._hook
+
+    def trainer(self):
+        """The trainer behind training-mode forwards, built on first use with the module's current parameters
+        (`solver.build_optimizer` sets its learning rate, momentum and weight decay from cfg.SOLVER)."""
+        if self._trainer is None:
+            self._trainer = self.make_trainer()
+        return self._trainer
+
+    def train(self, mode: bool = True):
+        """Leaving training mode writes the trained masters back into the module's parameters, so that eval-mode forwards,
+        state_dict() and checkpoints see them ([d2] trains the module's parameters in place)."""
+        if not mode and self.training and self._trainer is not None:
+            self.load_trainer_state(self._trainer, keep_trainer=True)
+        return super().train(mode)
 
     def make_trainer(self, lr: float = 0.005, momentum: float = 0.9, weight_decay: float = 1e-4, loss_scale: float = 1024.0):
         """The training loop body of train.py:132-148 as one object: `losses = trainer.step(...)` replaces
@@ -482,6 +607,8 @@ class GeneralizedRCNN(_EngineOwner):
         owns fp32 master copies of this model's trainable parameters (res3+ weights un-folded from their FrozenBN, FPN, heads);
         `load_trainer_state(trainer)` writes them back into the module for evaluation / checkpointing."""
         from .train import OpensetRCNNTrainer
+        if self.device.type != "cuda":
+            raise ops.OsrError("the model must be on the GPU (model.to('cuda')): the HIP path has no CPU fallback")
         sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
         bn = {}
         for k in sd:
@@ -489,15 +616,26 @@ class GeneralizedRCNN(_EngineOwner):
                 pre = k[: -len(".norm.weight")]
                 scale = sd[pre + ".norm.weight"] * (sd[pre + ".norm.running_var"] + 1e-5).rsqrt()
                 bn[pre] = (sd[pre + ".weight"], scale)
+        # class_map: the GraspNet id_map of the PLN / classifier losses (prototype_learning_network.py:80-95) -- without it the
+        # trainer would treat dataset ids 0..NUM_KNOWN-1 as the known classes
         return OpensetRCNNTrainer(fold_frozen_bn(sd), self._eng_cfg, self.kernel_dtype, str(self.device), lr=lr, momentum=momentum,
-                                  weight_decay=weight_decay, loss_scale=loss_scale, frozen_bn=bn)
+                                  weight_decay=weight_decay, loss_scale=loss_scale, frozen_bn=bn, class_map=self._class_map)
 
-    def load_trainer_state(self, trainer) -> None:
+    def load_trainer_state(self, trainer, keep_trainer: bool = False) -> None:
         sd = dict(self.state_dict())
         for k, v in trainer.export_state_dict().items():
             assert k in sd and tuple(sd[k].shape) == tuple(v.shape), k
             sd[k] = v
+        kept = self._trainer if keep_trainer else None
         self.load_state_dict(sd)
+        self._trainer = kept  # (load_state_dict drops a cached trainer: its masters would no longer match the module)
+
+    def refresh(self):
+        super().refresh()
+        self._trainer = None
+        for child in (self.backbone, self.proposal_generator.rpn_head, self.roi_heads):
+            child._shared = None
+            child.refresh()
 
     def _stack_images(self, imgs: List[torch.Tensor]):
         """One (N,3,H,W) device tensor for a list of CHW images: same-size uint8/float32 images are stacked as they are (the
@@ -515,26 +653,18 @@ class GeneralizedRCNN(_EngineOwner):
     def _train_tensors(self, batched_inputs: List[dict], generator: Optional[torch.Generator] = None):
         """The tensors a training iteration consumes: stacked images, their true sizes, the padded size, ground truth padded to
         the batch maximum, and the uniform keys that replace torch.randperm in the two samplers (seeded by `generator`)."""
-        eng = self.engine()
+        ecfg = {**DEFAULT_CFG, **self._eng_cfg}
         batch, sizes = self._stack_images([x["image"] for x in batched_inputs])
         n, dev = len(sizes), self.device
-        gmax = max(1, max(len(x["instances"]) for x in batched_inputs))
-        gt = torch.zeros((n, gmax, 4), dtype=torch.float32)
-        gcls = torch.zeros((n, gmax), dtype=torch.int64)
-        gcnt = torch.zeros((n,), dtype=torch.int32)
-        for i, x in enumerate(batched_inputs):
-            k = len(x["instances"])
-            gcnt[i] = k
-            if k:
-                gt[i, :k] = x["instances"].gt_boxes.tensor.float().cpu()
-                gcls[i, :k] = x["instances"].gt_classes.cpu()
-        d = eng.cfg["size_divisibility"]
+        gt, gcls, gcnt = pad_ground_truth([x["instances"] for x in batched_inputs])
+        gmax = gt.shape[1]
+        d = ecfg["size_divisibility"]
         hm, wm = int(batch.shape[-2]), int(batch.shape[-1])
         hp, wp = (hm + d - 1) // d * d, (wm + d - 1) // d * d
-        shapes = [((hp // s), (wp // s)) for s in eng.cfg["fpn_strides"][:4]]
+        shapes = [((hp // s), (wp // s)) for s in ecfg["fpn_strides"][:4]]
         shapes.append(((shapes[-1][0] - 1) // 2 + 1, (shapes[-1][1] - 1) // 2 + 1))
         r = sum(a * b for a, b in shapes)
-        cap = sum(min(eng.cfg["pre_nms_topk_train"], a * b) for a, b in shapes)
+        cap = sum(min(ecfg["pre_nms_topk_train"], a * b) for a, b in shapes)
         keys = {k: torch.rand(shape, generator=generator).to(dev) for k, shape in
                 (("rpn_reg", (n, r)), ("rpn_obj", (n, r)), ("roi", (n, cap + gmax)))}
         hw = torch.tensor(sizes, dtype=torch.int32, device=dev)

@@ -775,11 +775,20 @@ def pool_bwd(src: torch.Tensor, out_hw: Tuple[int, int], base: Optional[torch.Te
     return out
 
 
-def sgd_step_(param, grad, buf, lr: float, momentum: float, weight_decay: float, grad_scale: float = 1.0, row_scale=None, lowp=None):
+def check_finite_(x: torch.Tensor, flag: torch.Tensor) -> torch.Tensor:
+    """Clears flag (int32 (1,), preset to 1 by the caller) when x holds an inf / NaN. Asynchronous."""
+    lib = _lib.load()
+    _need(x, torch.float32, "x"); _need(flag, torch.int32, "flag")
+    check(lib.osr_check_finite(_p(x), x.numel(), _p(flag), _stream()), "osr_check_finite")
+    return flag
+
+
+def sgd_step_(param, grad, buf, lr: float, momentum: float, weight_decay: float, grad_scale: float = 1.0, row_scale=None, lowp=None,
+              apply_flag: Optional[torch.Tensor] = None):
     lib = _lib.load()
     _need(param, torch.float32, "param"); _need(grad, torch.float32, "grad"); _need(buf, torch.float32, "buf")
     if grad.numel() != param.numel() or buf.numel() != param.numel():
         raise OsrError("sgd_step_: size mismatch")
     row_elems = param.numel() // param.shape[0] if row_scale is not None else 1
     check(lib.osr_sgd_step(_p(param), _p(grad), _p(buf), param.numel(), lr, momentum, weight_decay, grad_scale, _p(row_scale), row_elems,
-                           _p(lowp), _DT[lowp.dtype] if lowp is not None else 0, _stream()), "osr_sgd_step")
+                           _p(lowp), _DT[lowp.dtype] if lowp is not None else 0, _p(apply_flag), _stream()), "osr_sgd_step")

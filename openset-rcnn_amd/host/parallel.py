@@ -5,7 +5,7 @@ takes a contiguous slice of the global batch, results are gathere
 ([d2] comm.gather at pascal_voc_evaluation.py:106) and timings are reduced with MAX."""
 from __future__ import annotations
 
-from typing import Any, List, Optional, Tuple
+from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -64,3 +64,84 @@ def all_reduce_sum_(flat: torch.Tensor) -> int:
         return 1
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return dist.get_world_size()
+
+
+def reduce_dict(input_dict: dict, average: bool = True) -> dict:
+    """[d2] comm.reduce_dict (train.py:139): the scalar tensors of a dict reduced to rank 0 in one collective (sorted keys, one
+    stacked tensor), averaged by default; the other ranks get their partial sums back, as in detectron2. Not distributed: the
+    dict itself."""
+    if not is_dist() or dist.get_world_size() < 2:
+        return input_dict
+    with torch.no_grad():
+        names = sorted(input_dict.keys())
+        values = torch.stack([input_dict[k].detach().reshape(()) for k in names])
+        dist.reduce(values, dst=0)
+        if dist.get_rank() == 0 and average:
+            values = values / dist.get_world_size()
+        return {k: v for k, v in zip(names, values)}
+
+
+class GradBuckets:
+    """Bucketed gradient all-reduce overlapped with the backward (what DDP gives train.py:201-205 for free).
+
+    The trainer lays its flat fp32 gradient buffer out in REVERSE order of completion (the heads, whose gradients the backward
+    finishes first, sit at the end), so the finished part of the buffer grows from the end towards the start. The buffer is cut
+    from the end into contiguous buckets of >= bucket_bytes (25 MB default: on xGMI's point-to-point links a ring is per-link
+    bound, so few large collectives beat many small ones; 166.5 MB -> 6 buckets). `mark_done(name)` is called by the backward
+    when a parameter's gradient is final; the call that completes a bucket issues its all-reduce with async_op=True -- the
+    collective runs on the backend's own stream, ordered after everything enqueued so far on the compute stream, while the
+    remaining data- and weight-gradient launches keep the compute stream busy. `finish()` waits for every outstanding bucket
+    (a stream dependency for RCCL, a host wait for gloo) and returns the world size. Sums are associative-order independent
+    here: every element is reduced exactly once, so bucketed == single-shot bit for bit for two ranks and up to the backend's
+    own reduction order beyond."""
+
+    def __init__(self, flat: torch.Tensor, layout: Sequence[Tuple[str, int, int]], bucket_bytes: int = 25 << 20):
+        """layout: (name, offset, numel) of every parameter's view in `flat`, ascending offsets."""
+        self.flat = flat
+        self.buckets: List[Dict[str, Any]] = []
+        self.owner: Dict[str, int] = {}
+        esz = flat.element_size()
+        hi, names, lo = flat.numel(), [], flat.numel()
+        for name, off, numel in reversed(list(layout)):
+            names.append(name)
+            lo = off
+            if (hi - lo) * esz >= bucket_bytes:
+                self._close(lo, hi, names)
+                hi, names = lo, []
+        if names or hi > 0:
+            self._close(0, hi, names)
+        self.reset()
+
+    def _close(self, lo: int, hi: int, names: List[str]) -> None:
+        if hi <= lo:
+            return
+        for n in names:
+            self.owner[n] = len(self.buckets)
+        self.buckets.append(dict(lo=lo, hi=hi, names=tuple(names)))
+
+    def reset(self) -> None:
+        self.pending = [set(b["names"]) for b in self.buckets]
+        self.works: List[Any] = []
+        self.issued = [False] * len(self.buckets)
+
+    def mark_done(self, name: str) -> None:
+        b = self.owner[name]
+        self.pending[b].discard(name)
+        if not self.pending[b] and not self.issued[b]:
+            self._issue(b)
+
+    def _issue(self, b: int) -> None:
+        self.issued[b] = True
+        if is_dist() and dist.get_world_size() > 1:
+            bk = self.buckets[b]
+            self.works.append(dist.all_reduce(self.flat[bk["lo"]:bk["hi"]], op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self) -> int:
+        """Issue whatever the backward did not mark (a bucket with an untracked parameter), wait for all, re-arm."""
+        for b in range(len(self.buckets)):
+            if not self.issued[b]:
+                self._issue(b)
+        for w in self.works:
+            w.wait()
+        self.reset()
+        return dist.get_world_size() if is_dist() else 1

@@ -42,7 +42,8 @@ def _dgrad_pack(w_lp: torch.Tensor) -> torch.Tensor:
 class OpensetRCNNTrainer:
     def __init__(self, params: Dict[str, torch.Tensor], cfg: Optional[dict] = None, dtype: torch.dtype = torch.float16, device: str = "cuda",
                  lr: float = 0.005, momentum: float = 0.9, weight_decay: float = 1e-4, loss_scale: float = 1024.0, freeze_at: int = 2,
-                 frozen_bn: Optional[Dict[str, Tuple[torch.Tensor, torch.Tensor]]] = None, class_map: Optional[torch.Tensor] = None):
+                 frozen_bn: Optional[Dict[str, Tuple[torch.Tensor, torch.Tensor]]] = None, class_map: Optional[torch.Tensor] = None,
+                 bucket_bytes: int = 25 << 20):
         """params: BN-folded parameters under detectron2 names (what the engine reads). frozen_bn (optional): for convs followed by
         FrozenBatchNorm, name -> (un-folded weight (cout,cin,kh,kw), per-channel scale gamma/sqrt(var+eps)): the trainable parameter
         is the un-folded weight (weight decay acts on it, the chain rule multiplies the kernel's gradient by the scale)."""
@@ -66,7 +67,10 @@ class OpensetRCNNTrainer:
                 pre = f"backbone.bottom_up.res{si + 2}.{b}"
                 for cname in (["shortcut"] if b == 0 else []) + ["conv1", "conv2", "conv3"]:
                     self._add_conv(f"{pre}.{cname}", params, bias=False)  # FrozenBN: the folded shift is not a parameter
-        for lvl in (2, 3, 4, 5):
+        # (the masters are laid out in REVERSE order of gradient completion -- backbone bottom-up, FPN coarse to fine, RPN head, box
+        # head, the small fp32 heads last -- so that the finished part of the flat gradient buffer grows from its end and the
+        # all-reduce buckets of parallel.GradBuckets are contiguous)
+        for lvl in (5, 4, 3, 2):
             self._add_conv(f"backbone.fpn_lateral{lvl}", params, bias=True)
             self._add_conv(f"backbone.fpn_output{lvl}", params, bias=True)
         self._add_conv("proposal_generator.rpn_head.conv", params, bias=True)
@@ -88,12 +92,22 @@ class OpensetRCNNTrainer:
         total = sum(al(t.numel()) for t in self.master.values())
         self.grad_flat = torch.zeros((total,), dtype=torch.float32, device=dev)
         self.grad: Dict[str, torch.Tensor] = {}
-        off = 0
+        off, layout = 0, []
         for k, t in self.master.items():
             self.grad[k] = self.grad_flat[off:off + t.numel()].view(t.shape)
+            layout.append((k, off, al(t.numel())))
             off += al(t.numel())
+        self.buckets = parallel.GradBuckets(self.grad_flat, layout, bucket_bytes)
         self.mom = {k: torch.zeros_like(t) for k, t in self.master.items()}
         self.num_params = sum(t.numel() for t in self.master.values())
+        # overflow guard: device flag read by every osr_sgd_step launch, mirrored into pinned host memory after the update
+        self._ok = torch.ones((1,), dtype=torch.int32, device=dev)
+        self._ok_host = torch.ones((1,), dtype=torch.int32).pin_memory() if dev.type == "cuda" else torch.ones((1,), dtype=torch.int32)
+        self._ok_event = torch.cuda.Event()
+        self._ok_pending = False
+        self.overflow_steps = 0
+        self._overlap = False
+        self.grads_ready = False
         self._refresh_derived()
 
     def _add_conv(self, name: str, params, bias: bool):
@@ -160,36 +174,13 @@ class OpensetRCNNTrainer:
         keep: dict = {}
         sel = e._rpn(out, image_hw, keep, topk=c["pre_nms_topk_train"])
         s["rpn_t"], s["rpn_shapes"], s["sel"] = keep["rpn_t"], keep["rpn_shapes"], sel
-        lv = sel["levels"]
-        midx, miou, lab, olab = ops.rpn_match_anchors(lv, e.cell_anchors, n, gt_boxes, gt_count, c["rpn_iou_thresholds"], c["rpn_iou_thresholds_objectness"])
-        ops.subsample_labels_(lab, keys["rpn_reg"], c["rpn_batch_size"], c["rpn_positive_fraction"])
-        ops.subsample_labels_(olab, keys["rpn_obj"], c["rpn_batch_size"], c["rpn_positive_fraction_objectness"])
-        mboxes, ctr_t = ops.rpn_anchor_targets(lv, e.cell_anchors, n, gt_boxes, gt_count, midx, olab)
-        rpn = ops.rpn_losses_fwd(lv, e.cell_anchors, n, sel["pred_deltas"], sel["pred_ctr"], lab, olab, mboxes, ctr_t, c["rpn_loc_weight"],
-                                 c["rpn_ctr_weight"], c["rpn_batch_size"])
-        s.update(labels=lab, obj_labels=olab, matched_boxes=mboxes, ctr_target=ctr_t)
+        rpn, rpn_state = e.rpn_losses_forward(sel, n, gt_boxes, gt_count, keys)
+        s.update(rpn_state)
         # RoI heads on the sampled proposals
-        smp = ops.roi_match_and_sample(sel["boxes"], sel["scores"], sel["counts"], gt_boxes, gt_classes, gt_count, keys["roi"], c["num_classes"],
-                                       c["roi_batch_size"], c["roi_positive_fraction"], c["roi_iou_threshold"])
-        boxes = smp["boxes"].view(-1, 4)
-        pooled = ops.roi_align([out[k] for k in ("p2", "p3", "p4", "p5")], c["pooler_scales"], boxes, smp["batch_idx"], c["pooler_resolution"],
-                               self.dtype, c["canonical_level"], c["canonical_size"], 2)
-        m = pooled.shape[0]
-        h1 = e._linear(pooled.view(m, -1), e.fc1_w, e.fc1_b, True)
-        box_feats = e._linear(h1, e.fc2_w, e.fc2_b, True, torch.float32)
-        pred = ops.gemm_f32(box_feats, e.pred_w, e.pred_b)
-        cls, ious = smp["gt_classes"].view(-1), smp["ious"].view(-1)
-        box = ops.roi_box_losses_fwd(pred[:, :4], pred[:, 4], boxes, smp["gt_boxes"].view(-1, 4), cls, ious, c["num_classes"], c["bbox_reg_weights"],
-                                     c["box_reg_weight"], c["iou_reg_weight"], iou_is_logit=True)
-        emb = ops.gemm_f32(box_feats, e.enc_w, e.enc_b)
-        rec = ops.gemm_f32(emb, e.dec_w, e.dec_b)
-        cls_k, nck = e.known_class_targets(cls)
-        dml = ops.pln_loss_fwd(emb, e.protos, cls_k, ious, c["pln_iou_threshold"], c["pln_alpha"], c["pln_beta"], c["pln_loss_weight"])
-        logits = ops.gemm_f32(rec, e.cls_w, e.cls_b)
-        ce = ops.softmax_ce_loss_fwd(logits, cls_k, nck, c["cls_loss_weight"])
-        s.update(smp=smp, boxes=boxes, pooled=pooled, h1=h1, box_feats=box_feats, pred=pred, emb=emb, rec=rec, logits=logits, cls=cls, ious=ious,
-                 cls_k=cls_k, nck=nck)
-        losses = dict(loss_rpn_loc=rpn[0], loss_rpn_ctr=rpn[1], loss_box_reg=box[0], loss_iou=box[1], loss_dml=dml[0], loss_cls=ce[0])
+        roi, roi_state = e.roi_losses_forward(out, sel["boxes"], sel["scores"], sel["counts"], gt_boxes, gt_classes, gt_count, keys["roi"])
+        s.update(roi_state)
+        losses = dict(loss_rpn_loc=rpn[0], loss_rpn_ctr=rpn[1], loss_box_reg=roi["loss_box_reg"], loss_iou=roi["loss_iou"],
+                      loss_dml=roi["loss_dml"], loss_cls=roi["loss_cls"])
         return losses, s
 
     # ---- backward -------------------------------------------------------------------------------------------------
@@ -201,10 +192,22 @@ class OpensetRCNNTrainer:
         dw = ops.gemm_f32(dy.t().contiguous(), x.t().contiguous(), None)                    # (n_out, k_in)
         g[name + ".w"].copy_(dw)
         ops.bias_grad(dy, g[name + ".b"])
+        self._done(name + ".w", name + ".b")
         return dx
 
-    def _backward(self, s, n):
-        e, c, g, S = self.eng, self.eng.cfg, self.grad, self.loss_scale
+    def _done(self, *names: str) -> None:
+        """The gradients of these parameters are final (their last launch is enqueued): a bucket they complete starts its
+        all-reduce now, under the rest of the backward."""
+        if self._overlap:
+            for k in names:
+                self.buckets.mark_done(k)
+
+    def _backward(self, s, n, grad_scale: float = 1.0, overlap: bool = True):
+        """Gradients of grad_scale * (sum of the six losses), times the loss scale, into self.grad. overlap: start each gradient
+        bucket's all-reduce as soon as the backward has passed it (several ranks only; all_reduce_grads() then just waits)."""
+        e, c, g, S = self.eng, self.eng.cfg, self.grad, self.loss_scale * grad_scale
+        self._overlap = overlap and parallel.is_dist()
+        self.buckets.reset()
         dt = self.dtype
         # --- RoI-head losses -> predictor / PLN / classifier (fp32 heads) ---
         d_pred = ops.roi_box_losses_bwd(s["pred"], s["boxes"], s["smp"]["gt_boxes"].view(-1, 4), s["cls"], s["ious"], c["num_classes"],
@@ -213,6 +216,7 @@ class OpensetRCNNTrainer:
         d_emb_pln, d_protos = ops.pln_loss_bwd(s["emb"], self.master["protos"], s["cls_k"], s["ious"], c["pln_iou_threshold"], c["pln_alpha"],
                                                c["pln_beta"], c["pln_loss_weight"], S)
         g["protos"].copy_(d_protos)
+        self._done("protos")
         d_rec = self._f32_linear_bwd(s["rec"], d_logits, self.t_cls, "cls", dy_pad=32)
         d_emb = self._f32_linear_bwd(s["emb"], d_rec, self.t_dec, "dec")
         d_emb = ops.add_cast(d_emb, d_emb_pln, torch.float32)
@@ -226,10 +230,12 @@ class OpensetRCNNTrainer:
         d_h1 = ops.conv2d_dgrad(dy2.view(1, m, 1, -1), self.wd["fc2"], (m, 1), mask=s["h1"].view(1, m, 1, -1)).view(m, -1)
         ops.conv2d_wgrad(s["h1"].view(1, m, 1, -1), dy2.view(1, m, 1, -1), 1, 1, dw=g["fc2.w"].view(-1, 1, 1, g["fc2.w"].shape[1]))
         ops.bias_grad(dy2, g["fc2.b"])
+        self._done("fc2.w", "fc2.b")
         pooled2 = s["pooled"].view(1, m, 1, -1)
         d_pooled = ops.conv2d_dgrad(d_h1.view(1, m, 1, -1), self.wd["fc1"], (m, 1))
         ops.conv2d_wgrad(pooled2, d_h1.view(1, m, 1, -1), 1, 1, dw=g["fc1.w"].view(-1, 1, 1, g["fc1.w"].shape[1]))
         ops.bias_grad(d_h1, g["fc1.b"])
+        self._done("fc1.w", "fc1.b")
         P = c["pooler_resolution"]
         p = s["p"]
         shapes = [(p[k].shape[1], p[k].shape[2]) for k in ("p2", "p3", "p4", "p5")]
@@ -242,6 +248,7 @@ class OpensetRCNNTrainer:
         dt_all, dw_tail, db_tail = ops.cfrpn_tail_bwd(s["rpn_t"], e.rpn_wtail, d5)
         g["rpn_tail.w"].copy_(dw_tail)
         g["rpn_tail.b"].copy_(db_tail)
+        self._done("rpn_tail.w", "rpn_tail.b")
         rn = "proposal_generator.rpn_head.conv"
         dP = {}
         off = 0
@@ -253,6 +260,7 @@ class OpensetRCNNTrainer:
             dP[k] = ops.conv2d_dgrad(dtl, self.wd[rn], (h, w), 1, 1, add=roi_part)
             ops.conv2d_wgrad(p[k], dtl, 3, 3, 1, 1, dw=g[rn + ".w"], accumulate=li > 0)
             ops.bias_grad(dtl, g[rn + ".b"], accumulate=li > 0)
+        self._done(rn + ".w", rn + ".b")
         h5, w5 = p["p5"].shape[1], p["p5"].shape[2]
         dP["p5"] = ops.pool_bwd(dP["p6"], (h5, w5), dP["p5"], 1)  # p6 = p5[::2, ::2]
         # --- FPN: output convs, top-down adds, laterals (finest level first: its gradient flows up to the coarser sums) ---
@@ -270,6 +278,7 @@ class OpensetRCNNTrainer:
             res = s["res"][f"res{lvl}"]
             ops.conv2d_wgrad(res, d_ls, 1, 1, dw=g[ln + ".w"])
             ops.bias_grad(d_ls, g[ln + ".b"])
+            self._done(on + ".w", on + ".b", ln + ".w", ln + ".b")
             if lvl > self.freeze_at:
                 d_res[lvl] = (d_ls, ln)  # the lateral's data gradient is formed together with the next stage's (see below)
             d_ls_prev = d_ls
@@ -292,6 +301,8 @@ class OpensetRCNNTrainer:
             ops.conv2d_wgrad(x, d_o1, 1, 1, stride, 0, dw=g[pre + ".conv1.w"])
             if blk["first"]:
                 ops.conv2d_wgrad(x, G, 1, 1, stride, 0, dw=g[pre + ".shortcut.w"])
+                self._done(pre + ".shortcut.w")
+            self._done(pre + ".conv3.w", pre + ".conv2.w", pre + ".conv1.w")
             if blk["first"] and blk["stage"] == self.freeze_at + 1:
                 break  # the block's input comes from frozen layers
             hx, wx = x.shape[1], x.shape[2]
@@ -307,21 +318,47 @@ class OpensetRCNNTrainer:
 
     # ---- optimiser ------------------------------------------------------------------------------------------------
     def all_reduce_grads(self) -> int:
-        """Sum the flat gradient buffer over the data-parallel ranks (RCCL over xGMI); returns the world size."""
-        return parallel.all_reduce_sum_(self.grad_flat)
+        """Sum the flat gradient buffer over the data-parallel ranks (RCCL over xGMI); returns the world size. The buckets whose
+        parameters the backward has already marked are in flight since then (overlapped with the rest of the backward); this
+        issues the remainder and waits for all of them."""
+        return self.buckets.finish()
 
     def _update(self, world: int):
+        """SGD on every master, gated on the device by the overflow flag: an iteration whose (all-reduced) gradients hold an inf or
+        NaN changes neither parameters nor momentum (the reference trains in fp32 and cannot overflow; fp16 gradients can). The
+        flag is read back lazily by `poll_overflow()` -- no host sync here."""
         gs = 1.0 / (self.loss_scale * world)
+        self._ok.fill_(1)
+        ops.check_finite_(self.grad_flat, self._ok)
         for k, pm in self.master.items():
             lp = self.lowp.get(k)
-            ops.sgd_step_(pm, self.grad[k], self.mom[k], self.lr, self.momentum, self.weight_decay, gs, self.row_scale.get(k), lp)
+            ops.sgd_step_(pm, self.grad[k], self.mom[k], self.lr, self.momentum, self.weight_decay, gs, self.row_scale.get(k), lp, self._ok)
         self._refresh_derived()
+        self._ok_host.copy_(self._ok, non_blocking=True)
+        self._ok_event.record()
+        self._ok_pending = True
+
+    def poll_overflow(self, wait: bool = False) -> bool:
+        """True when the last finished update was skipped because of non-finite gradients. Then the loss scale is halved (dynamic
+        loss scaling; floor 1.0) and `overflow_steps` counts it. Cheap: reads a pinned flag once its copy event has completed
+        (`wait=True` blocks for it: the checkpoint writer does, so that no skipped or half-applied state is written blind)."""
+        if not self._ok_pending or not (wait or self._ok_event.query()):
+            return False
+        if wait:
+            self._ok_event.synchronize()
+        self._ok_pending = False
+        if int(self._ok_host[0]) == 1:
+            return False
+        self.overflow_steps += 1
+        self.loss_scale = max(1.0, self.loss_scale * 0.5)
+        return True
 
     def step(self, images, image_hw, hp, wp, gt_boxes, gt_classes, gt_count, keys, update: bool = True) -> Dict[str, torch.Tensor]:
         """One iteration: returns the loss dict (GPU scalars). update=False leaves the parameters untouched (gradients stay in
         self.grad, scaled by loss_scale)."""
+        self.poll_overflow()  # the previous iteration's verdict (already on the host by now): adjusts the loss scale
         losses, saved = self._forward(images, image_hw, hp, wp, gt_boxes, gt_classes, gt_count, keys)
-        self._backward(saved, images.shape[0])
+        self._backward(saved, images.shape[0], overlap=update)
         if update:
             self._update(self.all_reduce_grads())
         return losses

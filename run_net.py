@@ -8,8 +8,9 @@ What differs, by construction of this build:
     process BEFORE anything touches the GPU and exits with its code; under torchrun (WORLD_SIZE set) it joins the job.
     Rendezvous is always 127.0.0.1 (single node; --num-machines / --machine-rank / --dist-url are accepted and rejected
     when they ask for more than one machine).
-  * training has no autograd graph: `losses = trainer.step(batch)` replaces model(data) / backward() / optimizer.step()
-    (train.py:132-148); gradients are summed over ranks with one RCCL all-reduce of the flat buffer.
+  * training records no autograd graph, yet the loop body of train.py:135-147 runs as written: `model(data)` returns the losses,
+    `losses.backward()` runs the explicit HIP backward (one autograd Function stands for the whole step), `optimizer.step()`
+    finishes the bucketed RCCL all-reduce that the backward started and applies SGD (host/solver.py).
   * datasets live under $DETECTRON2_DATASETS (default ./datasets) in the reference's layout (datasets/README of the
     reference: voc_coco/{Annotations,ImageSets,JPEGImages}, graspnet_os/{annotations,images}).
 """
@@ -40,7 +41,9 @@ def parse_args(argv=None):
     ap.add_argument("--test_iter", default=0, type=int, help="with --resume_test: iteration whose detections to score, 0 for Final")
     ap.add_argument("--eval_type", default="openset", type=str)
     ap.add_argument("--opendet-benchmark", action="store_true", help="unknown class id 80 and the VOC-COCO class list of OpenDet")
-    ap.add_argument("--test-batch", type=int, default=16, help="images per inference launch (the reference runs 1; results do not depend on it)")
+    ap.add_argument("--test-batch", type=int, default=1,
+                    help="images per inference launch. 1 = the reference's evaluation (each image padded to a multiple of 32 on its own); larger "
+                         "batches are faster but pad every image to the largest one of its batch, which changes features near the padded border")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="storage dtype of activations / MFMA operands")
     ap.add_argument("opts", default=None, nargs=argparse.REMAINDER, help="KEY VALUE config overrides")
     args = ap.parse_args(argv)
@@ -50,6 +53,8 @@ def parse_args(argv=None):
         ap.error("opendet benchmark does not support test_iter")
     if args.num_machines != 1 or args.machine_rank != 0:
         ap.error("single node only: one process per GPU over RCCL/xGMI inside one machine")
+    if args.eval_type != "openset":
+        ap.error("--eval_type: only 'openset' is implemented (the evaluators here are the open-set ones the reference's yaml files use)")
     return args
 
 
@@ -132,12 +137,20 @@ def checkpoint_path(cfg, iteration=None):
     return os.path.join(cfg.OUTPUT_DIR, "model_final.pth" if iteration is None else f"model_{iteration:07d}.pth")
 
 
-def save_checkpoint(cfg, model, trainer, iteration: int, final: bool = False):
+def save_checkpoint(cfg, model, trainer, iteration: int, final: bool = False, write: bool = True):
+    """Never writes a state that an overflowed update may have left half-judged: waits for the overflow verdict of the last
+    update, and validates the masters (an fp32 inf / NaN in the weights would otherwise only surface at the next iteration)."""
     import torch
-    model.load_trainer_state(trainer)
+    trainer.poll_overflow(wait=True)
+    bad = [k for k, v in trainer.master.items() if not bool(torch.isfinite(v).all())]
+    if bad:
+        raise FloatingPointError(f"refusing to checkpoint iteration {iteration}: non-finite values in {bad[:4]}{' ...' if len(bad) > 4 else ''}")
+    if not write:
+        return
+    model.load_trainer_state(trainer, keep_trainer=True)
     path = checkpoint_path(cfg, None if final else iteration)
     torch.save({"model": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "iteration": iteration,
-                "momentum": trainer.export_optimizer_state()}, path)
+                "momentum": trainer.export_optimizer_state(), "loss_scale": trainer.loss_scale}, path)
     with open(os.path.join(cfg.OUTPUT_DIR, "last_checkpoint"), "w") as f:
         f.write(os.path.basename(path))
     logger.info("saved %s", path)
@@ -145,7 +158,8 @@ def save_checkpoint(cfg, model, trainer, iteration: int, final: bool = False):
 
 def resume_or_load(cfg, model, resume: bool):
     """[d2] DetectionCheckpointer.resume_or_load: with --resume and a last_checkpoint file continue from it, otherwise load
-    MODEL.WEIGHTS (.pth state dict or the MSRA R-50.pkl); returns (iteration to start from, momentum buffers or None)."""
+    MODEL.WEIGHTS (.pth state dict or the MSRA R-50.pkl); returns (iteration to start from, optimizer state {momentum buffers,
+    loss scale} or None)."""
     import torch
     from openset_rcnn_amd.host.checkpoint import load_checkpoint, load_into
     last = os.path.join(cfg.OUTPUT_DIR, "last_checkpoint")
@@ -155,7 +169,7 @@ def resume_or_load(cfg, model, resume: bool):
         blob = torch.load(path, map_location="cpu", weights_only=False)
         load_into(model, blob["model"], strict=False)
         logger.info("resumed from %s (iteration %d)", path, blob.get("iteration", -1))
-        return int(blob.get("iteration", -1)) + 1, blob.get("momentum")
+        return int(blob.get("iteration", -1)) + 1, {"momentum": blob.get("momentum"), "loss_scale": blob.get("loss_scale")}
     w = cfg.MODEL.WEIGHTS
     if w:
         if w.startswith("detectron2://"):
@@ -165,43 +179,58 @@ def resume_or_load(cfg, model, resume: bool):
     return 0, None
 
 
-def do_train(cfg, args, model, D, start_iter: int, momentum=None):
-    """train.py:109-162 with the explicit-backward trainer."""
+def do_train(cfg, args, model, D, start_iter: int, opt_state=None):
+    """train.py:109-162. The loop body is the reference's (train.py:135-147) line for line: `model(data)` returns the loss dict,
+    `losses.backward()` runs the explicit HIP backward, `optimizer.step()` all-reduces and applies SGD."""
     import torch
+    from openset_rcnn_amd.host import parallel as comm
     from openset_rcnn_amd.host.data import DatasetMapper, build_detection_train_loader
-    from openset_rcnn_amd.host.train import warmup_multistep_lr
+    from openset_rcnn_amd.host.solver import build_lr_scheduler, build_optimizer
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    trainer = model.make_trainer(lr=cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM, weight_decay=cfg.SOLVER.WEIGHT_DECAY)
-    if momentum is not None:
-        trainer.load_optimizer_state(momentum)
+    model.train()
+    optimizer = build_optimizer(cfg, model)
+    scheduler = build_lr_scheduler(cfg, optimizer, last_iter=start_iter - 1)
+    trainer = model.trainer()
+    if opt_state and opt_state.get("momentum") is not None:
+        trainer.load_optimizer_state(opt_state["momentum"])
+    if opt_state and opt_state.get("loss_scale"):
+        trainer.loss_scale = float(opt_state["loss_scale"])
+    seed = cfg.SEED if cfg.SEED >= 0 else 0
     dicts = [d for n in cfg.DATASETS.TRAIN for d in D.DatasetCatalog[n]()]
-    loader = build_detection_train_loader(dicts, DatasetMapper(cfg, is_train=True, seed=cfg.SEED if cfg.SEED >= 0 else 0),
-                                          cfg.SOLVER.IMS_PER_BATCH, seed=cfg.SEED if cfg.SEED >= 0 else 0)
-    gen = torch.Generator().manual_seed((cfg.SEED if cfg.SEED >= 0 else 0) + rank)  # sampler keys: seed + rank (SURVEY 8e)
+    data_loader = build_detection_train_loader(dicts, DatasetMapper(cfg, is_train=True, seed=seed), cfg.SOLVER.IMS_PER_BATCH, seed=seed,
+                                               start_iter=start_iter)  # a resumed run continues the data stream (no image is decoded to skip)
     max_iter = cfg.SOLVER.MAX_ITER
     logger.info("Starting training from iteration %d", start_iter)
-    for _ in range(start_iter):  # a resumed run continues the data stream where it stopped
-        next(loader)
-    for iteration in range(start_iter, max_iter):
-        batch = next(loader)
-        trainer.lr = warmup_multistep_lr(iteration, cfg.SOLVER.BASE_LR, tuple(cfg.SOLVER.STEPS), cfg.SOLVER.GAMMA, cfg.SOLVER.WARMUP_ITERS,
-                                         cfg.SOLVER.WARMUP_FACTOR)
-        losses = model.train_step(trainer, batch, gen)
-        vals = {k: float(v) for k, v in losses.items()}
-        total = sum(vals.values())
-        if not all(map(lambda x: x == x and abs(x) != float("inf"), vals.values())):
-            raise FloatingPointError(f"non-finite loss at iteration {iteration}: {vals}")  # train.py:137
+    for data, iteration in zip(data_loader, range(start_iter, max_iter)):
+        # sampler keys (the randomness of both subsample_labels calls): a function of (seed, rank, iteration), so a resumed run
+        # draws what the uninterrupted one would have (SURVEY 8e: seed + rank)
+        model.sampler_generator.manual_seed((seed * 1000003 + iteration) * 64 + rank)
+
+        loss_dict = model(data)
+        losses = sum(loss_dict.values())
+        assert torch.isfinite(losses).all(), loss_dict
+
+        loss_dict_reduced = {k: v.item() for k, v in comm.reduce_dict(loss_dict).items()}
+        losses_reduced = sum(loss for loss in loss_dict_reduced.values())
+
+        optimizer.zero_grad()
+        losses.backward()
+        optimizer.step()
+        lr = optimizer.param_groups[0]["lr"]
+        scheduler.step()
+
         if rank == 0 and ((iteration + 1) % 20 == 0 or iteration == max_iter - 1):
-            logger.info("iter %d  total_loss %.4f  %s  lr %.6f", iteration + 1, total, "  ".join(f"{k} {v:.4f}" for k, v in vals.items()), trainer.lr)
+            logger.info("iter %d  total_loss %.4f  %s  lr %.6f%s", iteration + 1, losses_reduced,
+                        "  ".join(f"{k} {v:.4f}" for k, v in loss_dict_reduced.items()), lr,
+                        f"  (overflow-skipped steps: {trainer.overflow_steps}, loss scale {trainer.loss_scale:g})" if trainer.overflow_steps else "")
         if cfg.TEST.EVAL_PERIOD > 0 and (iteration + 1) % cfg.TEST.EVAL_PERIOD == 0 and iteration != max_iter - 1:
-            model.load_trainer_state(trainer)
-            model.eval()
+            model.eval()  # writes the trained masters back into the module
             do_test(cfg, args, model, D, iteration=iteration + 1)
-        if rank == 0 and cfg.SOLVER.CHECKPOINT_PERIOD > 0 and (iteration + 1) % cfg.SOLVER.CHECKPOINT_PERIOD == 0:
-            save_checkpoint(cfg, model, trainer, iteration)
-    if rank == 0:
-        save_checkpoint(cfg, model, trainer, max_iter - 1, final=True)
-    model.load_trainer_state(trainer)
+            model.train()
+            comm.barrier()
+        if cfg.SOLVER.CHECKPOINT_PERIOD > 0 and (iteration + 1) % cfg.SOLVER.CHECKPOINT_PERIOD == 0:
+            save_checkpoint(cfg, model, trainer, iteration, write=rank == 0)
+    save_checkpoint(cfg, model, trainer, max_iter - 1, final=True, write=rank == 0)
     model.eval()
 
 
@@ -215,7 +244,8 @@ def main(argv=None) -> int:
     cfg = setup(args)
     D = register_datasets(cfg)
     if args.resume_test:
-        do_test(cfg, args, None, D, iteration=args.test_iter)
+        if int(os.environ.get("RANK", "0")) == 0:  # re-scores a detections file: host-only work for one process
+            do_test(cfg, args, None, D, iteration=args.test_iter)
         return 0
     import torch
     world, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
@@ -241,10 +271,10 @@ def main(argv=None) -> int:
     cfgm.freeze()
     model = build_model(cfgm, class_id_for(cfg, D))
     model.kernel_dtype = torch.float16 if args.dtype == "f16" else torch.bfloat16
-    start, momentum = resume_or_load(cfg, model, args.resume)
+    start, opt_state = resume_or_load(cfg, model, args.resume)
     model.eval()
     if not args.eval_only:
-        do_train(cfg, args, model, D, start, momentum)
+        do_train(cfg, args, model, D, start, opt_state)
     do_test(cfg, args, model, D)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -99,7 +99,7 @@ def test_registry_names_and_state_dict_keys(osr, tmp_path):
     with pytest.raises(osr.OsrError):  # CPU model: refused, no eager fallback
         model([{"image": torch.zeros(3, 64, 64, dtype=torch.uint8), "height": 64, "width": 64}])
     model.train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(osr.OsrError):  # training mode builds the trainer: refused on the CPU as well
         model([{"image": torch.zeros(3, 64, 64, dtype=torch.uint8)}])
 
 

@@ -149,3 +149,60 @@ def test_two_rank_gradient_all_reduce():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert w == 2 and torch.equal(flat, torch.arange(1000, dtype=torch.float32) * 3)
+
+
+def _bucket_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as ge
+    ge.load_package()
+    from openset_rcnn_amd.host import parallel as P
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # a flat gradient buffer with the trainer's structure: parameter views at 16-byte aligned offsets, completion order = descending offset
+    g = torch.Generator().manual_seed(100 + rank)
+    sizes = [4096, 12, 70000, 256, 33000, 5, 120000, 1024, 20]
+    layout, off = [], 0
+    for i, n in enumerate(sizes):
+        al = (n + 3) // 4 * 4
+        layout.append((f"p{i}", off, al))
+        off += al
+    flat = torch.randn(off, generator=g)
+    single = flat.clone()
+    P.all_reduce_sum_(single)  # the single-shot exchange of round 1
+    buckets = P.GradBuckets(flat, layout, bucket_bytes=200_000)
+    assert len(buckets.buckets) >= 3 and buckets.buckets[0]["hi"] == off and buckets.buckets[-1]["lo"] == 0
+    assert all(a["lo"] == b["hi"] for a, b in zip(buckets.buckets, buckets.buckets[1:]))  # contiguous, from the end towards the start
+    for name, _, _ in reversed(layout[1:]):  # the backward marks parameters as their gradients complete; p0 is never marked
+        buckets.mark_done(name)
+    in_flight = sum(buckets.issued)
+    w = buckets.finish()  # issues the bucket the backward did not complete, waits for all
+    # a second iteration on the same object (re-armed by finish)
+    flat2 = flat.clone()
+    for name, _, _ in reversed(layout):
+        buckets.mark_done(name)
+    w2 = buckets.finish()
+    # the 6-scalar loss reduce of train.py:139
+    red = P.reduce_dict({"loss_b": torch.tensor(1.0 + rank), "loss_a": torch.tensor(10.0 * (rank + 1))})
+    if rank == 0:
+        q.put((w, w2, in_flight, len(buckets.buckets), torch.equal(flat2, single), flat, single, {k: float(v) for k, v in red.items()}))
+    dist.destroy_process_group()
+
+
+def test_bucketed_all_reduce_equals_single_shot_and_loss_reduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    w, w2, in_flight, nb, first_ok, flat, single, red = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert w == 2 and w2 == 2 and first_ok
+    assert in_flight == nb - 1  # every bucket but the one holding the unmarked parameter was already in flight before finish()
+    # the second pass reduced the already-summed buffer again: (a+b) + (a+b)
+    assert torch.equal(flat, single * 2)
+    assert red == {"loss_a": 15.0, "loss_b": 1.5}  # averaged on rank 0, sorted keys

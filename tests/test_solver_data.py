@@ -1,0 +1,84 @@
+"""CPU tests of the host pieces around the training loop: the solver mirror (build_optimizer / build_lr_scheduler), the
+resume-exact training data stream and the configuration guards of the loss kernels."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg(osr, extra=()):
+    from openset_rcnn_amd.host.config import add_openset_rcnn_config, get_cfg
+    cfg = get_cfg()
+    add_openset_rcnn_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "voc_coco.yaml"))
+    cfg.merge_from_list(list(extra))
+    return cfg
+
+
+def test_scheduler_mirror_follows_warmup_multistep(osr):
+    from openset_rcnn_amd.host.solver import HipSGD, build_lr_scheduler
+    from openset_rcnn_amd.host.train import warmup_multistep_lr
+    cfg = _cfg(osr)
+    opt = HipSGD(model=None, lr=cfg.SOLVER.BASE_LR, momentum=0.9, weight_decay=1e-4)
+    sch = build_lr_scheduler(cfg, opt)
+    kw = dict(base_lr=cfg.SOLVER.BASE_LR, steps=tuple(cfg.SOLVER.STEPS), gamma=cfg.SOLVER.GAMMA, warmup_iters=cfg.SOLVER.WARMUP_ITERS,
+              warmup_factor=cfg.SOLVER.WARMUP_FACTOR)
+    for it in range(0, 1000):
+        assert opt.param_groups[0]["lr"] == warmup_multistep_lr(it, **kw)  # the lr iteration `it` trains with (train.py:147 logs it)
+        sch.step()
+    # resumed at iteration 84000: the first milestone has been passed
+    opt2 = HipSGD(None, cfg.SOLVER.BASE_LR, 0.9, 1e-4)
+    build_lr_scheduler(cfg, opt2, last_iter=83999)
+    assert opt2.param_groups[0]["lr"] == pytest.approx(cfg.SOLVER.BASE_LR * 0.1)
+    opt.zero_grad()  # accepted, a no-op
+
+
+def test_unsupported_loss_types_are_rejected_not_silently_replaced(osr):
+    from openset_rcnn_amd.host.modeling import engine_cfg_from
+    assert engine_cfg_from(_cfg(osr))["rpn_loc_weight"] == 0.5
+    for opt in (["MODEL.RPN.BBOX_REG_LOSS_TYPE", "giou"], ["MODEL.RPN.BBOX_REG_LOSS_TYPE", "smooth_l1"], ["MODEL.RPN.CTR_SMOOTH_L1_BETA", "0.1"],
+                ["MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE", "giou"], ["MODEL.ROI_BOX_HEAD.IOU_SMOOTH_L1_BETA", "1.0"]):
+        with pytest.raises(NotImplementedError):
+            engine_cfg_from(_cfg(osr, opt))
+    # RPN.LOSS_WEIGHT multiplies both CF-RPN losses (classification_free_rpn.py:273-276)
+    assert engine_cfg_from(_cfg(osr, ["MODEL.RPN.LOSS_WEIGHT", "2.0"]))["rpn_ctr_weight"] == 1.0
+
+
+@pytest.fixture()
+def toy_dicts(tmp_path):
+    from PIL import Image
+    g = np.random.default_rng(0)
+    out = []
+    for i in range(7):
+        f = tmp_path / f"im{i}.png"
+        Image.fromarray(g.integers(0, 256, (40 + i, 60, 3), dtype=np.uint8)).save(f)
+        out.append(dict(file_name=str(f), image_id=i, annotations=[dict(bbox=[5, 5, 30, 30], category_id=i % 3)]))
+    return out
+
+
+def test_train_loader_resume_continues_the_exact_stream(osr, toy_dicts, monkeypatch):
+    """A loader started at iteration k yields what an uninterrupted loader yields from its k-th batch on (same images, same
+    flips and sizes), without mapping any of the skipped samples; ranks see disjoint interleaved samples."""
+    from openset_rcnn_amd.host import data as D
+    cfg = _cfg(osr, ["INPUT.MIN_SIZE_TRAIN", "(32, 40, 48)", "INPUT.MAX_SIZE_TRAIN", "80"])
+    calls = []
+    real = D.read_image
+    monkeypatch.setattr(D, "read_image", lambda f, fmt="BGR": (calls.append(f), real(f, fmt))[1])
+
+    def take(loader, k):
+        return [[(d["image_id"], tuple(d["image"].shape), d["image"].sum().item(), d["instances"].gt_boxes.tensor.tolist()) for d in next(loader)] for _ in range(k)]
+
+    full = take(D.build_detection_train_loader(toy_dicts, D.DatasetMapper(cfg, True, seed=5), 4, seed=5, rank=0, world=1), 9)  # 36 samples: > 5 epochs of 7
+    calls.clear()
+    tail = take(D.build_detection_train_loader(toy_dicts, D.DatasetMapper(cfg, True, seed=5), 4, seed=5, rank=0, world=1, start_iter=6), 3)
+    assert tail == full[6:9]
+    assert len(calls) == 12  # only the 3 yielded batches were decoded, none of the 24 skipped samples
+    assert len({b[0][1] for b in full}) > 1  # the augmentation does vary
+    # two ranks: the union of their per-rank batches is the global batch of the single-rank stream, in interleaved order
+    r0 = take(D.build_detection_train_loader(toy_dicts, D.DatasetMapper(cfg, True, seed=5), 4, seed=5, rank=0, world=2), 4)
+    r1 = take(D.build_detection_train_loader(toy_dicts, D.DatasetMapper(cfg, True, seed=5), 4, seed=5, rank=1, world=2), 4)
+    for it in range(4):
+        assert [r0[it][0], r1[it][0], r0[it][1], r1[it][1]] == full[it]
