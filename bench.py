@@ -8,16 +8,22 @@ resident in HBM. Images shard across ranks with no data-path collective (weak sc
 
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank/GPU)
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
   roofline     -- the dominant kernel family (MFMA implicit-GEMM conv/FC): algorithmic FLOPs per step divided by
                   the summed duration of its launches, measured with HIP events on the launch stream.
-  cpu_baseline -- the CPU oracle ("port") timed on this box's host cores on a bounded sample of the same workload.
+  roofline_hbm -- the HBM group of SURVEY.md 8d (RoIAlign + proposal selection + NMS): algorithmic bytes per step over
+                  the summed HIP-event duration, fraction of the 8 TB/s HBM peak; per kernel, and NMS as time + IoU pairs/s.
+  train_step   -- BASELINE.json config 3 (train step with the PLN contrastive loss, batch 16, one GPU), measured in the
+                  same process after the headline: ms per iteration, images/s, forward / data-gradient / weight-gradient TFLOP/s.
+  cpu_baseline -- the CPU oracle ("port") timed on this box's host cores on a bounded sample of the same workload
+                  (3 warm-ups + median of 5 at all cores; a 1-thread point on a smaller sample).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -30,6 +36,7 @@ import __graft_entry__ as ge  # noqa: E402
 
 METRIC = "images/sec at 3x800x1333, R50-FPN, 1/2/4/8 MI355X; mAP_k vs ref"
 MFMA_PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0                                # HBM3E spec peak (same guide; 6290 GB/s is its measured copy ceiling)
 
 
 def host_cores() -> int:
@@ -48,24 +55,99 @@ def host_cores() -> int:
     return n
 
 
-def cpu_baseline(params, batch: int, iters: int):
-    """The oracle (a port: the reference itself cannot run here) timed on the host cores."""
+def cpu_baseline(params, batch: int, one_thread: bool):
+    """The oracle (a port: the reference itself cannot run here) timed on the host cores, BASELINE.md section 3:
+    3 warm-ups + 5 timed passes, median, at all cores; plus a 1-thread point on a smaller sample (1 image, 1 warm-up + median
+    of 3: a full 3 + 5 protocol at one thread would take minutes)."""
     cores = host_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)  # the C oracle's OpenMP runtime reads it when the library loads
     from oracle import c_binding as CO
     from oracle import osr_oracle as O
     g = torch.Generator().manual_seed(0)
     images = [torch.randint(0, 256, (3, 800, 1333), generator=g, dtype=torch.uint8) for _ in range(batch)]
-    torch.set_num_threads(cores)
-    with torch.no_grad():
-        O.detector_inference(images[:1], params, params, roi_align_fn=CO.roi_align)  # warm-up (1 image)
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            O.detector_inference(images, params, params, roi_align_fn=CO.roi_align)
-        dt = time.perf_counter() - t0
-    return dict(value=batch * iters / dt, unit="images/sec", cores=cores, kind="port",
-                sample=f"{iters} pass(es) of the fp32 torch-CPU/C oracle over {batch} synthetic 3x800x1333 images "
-                       f"(same seeded weights), {torch.get_num_threads()} threads, after a 1-image warm-up")
+
+    def timed(threads, imgs, warm, reps):
+        torch.set_num_threads(threads)
+        CO.set_threads(threads)
+        ts = []
+        with torch.no_grad():
+            for i in range(warm + reps):
+                t0 = time.perf_counter()
+                O.detector_inference(imgs, params, params, roi_align_fn=CO.roi_align)
+                if i >= warm:
+                    ts.append(time.perf_counter() - t0)
+        return len(imgs) / statistics.median(ts)
+
+    allc = timed(cores, images, 3, 5)
+    points = [dict(threads=cores, images_per_sec=round(allc, 4), sample=f"{batch} images, 3 warm-ups + median of 5")]
+    if one_thread:
+        one = timed(1, images[:1], 1, 3)
+        points.append(dict(threads=1, images_per_sec=round(one, 4), sample="1 image, 1 warm-up + median of 3"))
+        torch.set_num_threads(cores)
+    return dict(value=allc, unit="images/sec", cores=cores, kind="port", os_cpu_count=os.cpu_count(),
+                sample=f"fp32 torch-CPU/C oracle, whole inference path on {batch} synthetic 3x800x1333 images (same seeded weights), "
+                       f"{cores} threads, 3 warm-ups + median of 5 passes (BASELINE.md section 3)",
+                points=points)
+
+
+def synthetic_gt(n: int, h: int, w: int, per_image: int = 8, seed: int = 0):
+    """BASELINE.md section 3 / SURVEY.md 8d: 8 boxes per image, sizes uniform in 32-512 px, classes uniform in [0, 20), seed 0."""
+    g = torch.Generator().manual_seed(seed)
+    size = torch.rand(n, per_image, 2, generator=g) * (512 - 32) + 32
+    size[..., 0].clamp_(max=w - 1)
+    size[..., 1].clamp_(max=h - 1)
+    x1 = torch.rand(n, per_image, generator=g) * (w - size[..., 0])
+    y1 = torch.rand(n, per_image, generator=g) * (h - size[..., 1])
+    boxes = torch.stack((x1, y1, x1 + size[..., 0], y1 + size[..., 1]), dim=-1)
+    classes = torch.randint(0, 20, (n, per_image), generator=g)
+    return boxes, classes, torch.full((n,), per_image, dtype=torch.int32)
+
+
+def train_step_leg(params, tdt, device, images, image_hw, steps: int, warmup: int):
+    """BASELINE.json config 3: forward + explicit backward + SGD on one GPU (no all-reduce at N = 1), batch 16 at 800x1333."""
+    from openset_rcnn_amd.host import ops
+    from openset_rcnn_amd.host.train import OpensetRCNNTrainer
+    n = images.shape[0]
+    tr = OpensetRCNNTrainer(params, dtype=tdt, device=device, lr=1e-4, loss_scale=1024.0 if tdt == torch.float16 else 1.0)
+    gt, gcls, gcnt = synthetic_gt(n, 800, 1333)
+    shapes = [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
+    r = sum(a * b for a, b in shapes)
+    cap = sum(min(2000, a * b) for a, b in shapes)
+    g = torch.Generator().manual_seed(0)
+    keys = {k: torch.rand(s, generator=g).to(device) for k, s in (("rpn_reg", (n, r)), ("rpn_obj", (n, r)), ("roi", (n, cap + gt.shape[1])))}
+    args = (images, image_hw, 800, 1344, gt.to(device), gcls.to(device), gcnt.to(device), keys)
+    for _ in range(warmup):
+        losses = tr.step(*args)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses = tr.step(*args)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    # one instrumented iteration: algorithmic FLOPs of the MFMA launches per phase, HIP events around the phases
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ops.FLOP_COUNT = dict(conv=0.0, wgrad=0.0)
+    ev[0].record()
+    _, saved = tr._forward(*args)
+    ev[1].record()
+    fwd = dict(ops.FLOP_COUNT)
+    tr._backward(saved, n, overlap=False)
+    ev[2].record()
+    bwd = {k: ops.FLOP_COUNT[k] - fwd[k] for k in fwd}
+    ops.FLOP_COUNT = None
+    tr._update(tr.all_reduce_grads())
+    ev[3].record()
+    torch.cuda.synchronize()
+    ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
+    total = float(sum(float(v) for v in losses.values()))
+    return dict(config="VOC-COCO openset_rcnn_R50_FPN_128k.yaml, train step with PLN contrastive loss, batch 16, 1xMI355X (BASELINE.json config 3)",
+                ms_per_iter=round(dt * 1e3, 3), images_per_sec=round(n / dt, 2), steps=steps, warmup=warmup,
+                forward_ms=round(ms[0], 3), backward_ms=round(ms[1], 3), update_ms=round(ms[2], 3),
+                forward_TFLOP=round(fwd["conv"] / 1e12, 3), dgrad_TFLOP=round(bwd["conv"] / 1e12, 3), wgrad_TFLOP=round(bwd["wgrad"] / 1e12, 3),
+                forward_TFLOPs=round(fwd["conv"] / ms[0] / 1e9, 1), backward_TFLOPs=round((bwd["conv"] + bwd["wgrad"]) / ms[1] / 1e9, 1),
+                whole_iteration_TFLOPs=round((fwd["conv"] + bwd["conv"] + bwd["wgrad"]) / dt / 1e12, 1),
+                trainable_params=tr.num_params, gt_boxes_per_image=8, proposals_per_image_train=cap, rois_sampled_per_image=512,
+                loss_total_last=round(total, 4), overflow_skipped_steps=tr.overflow_steps)
 
 
 def main():
@@ -76,8 +158,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU (config: 16)")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the config-3 train-step leg")
     ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--cpu-iters", type=int, default=5)
+    ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--streams", type=int, default=2, help="micro-batch streams inside one GPU (1 = single stream)")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage breakdown to stderr")
@@ -107,14 +190,30 @@ def main():
     pkg = ge.load_package()
     pkg._lib.load()
     from openset_rcnn_amd.host.engine import OpensetRCNNEngine
-    from openset_rcnn_amd.host.weights import random_params
+    from openset_rcnn_amd.host.weights import random_params, with_known_unknown_mix
 
-    params = random_params(0)  # identical weights on every rank (data parallel)
     tdt = torch.float16 if args.dtype == "f16" else torch.bfloat16
-    eng = OpensetRCNNEngine(params, dtype=tdt, device=f"cuda:{local_rank}")
+    dev = f"cuda:{local_rank}"
     g = torch.Generator().manual_seed(1234 + rank)  # each rank has its own shard of images
-    images = torch.randint(0, 256, (args.batch, 3, 800, 1333), generator=g, dtype=torch.uint8).to(eng.device)
-    image_hw = torch.tensor([(800, 1333)] * args.batch, dtype=torch.int32, device=eng.device)
+    images = torch.randint(0, 256, (args.batch, 3, 800, 1333), generator=g, dtype=torch.uint8).to(dev)
+    image_hw = torch.tensor([(800, 1333)] * args.batch, dtype=torch.int32, device=dev)
+    # Synthetic weights, identical on every rank (data parallel). Random prototypes alone make every detection "unknown" and
+    # leave the known-class leg (softmax over <= 20 000 candidates per image + per-class NMS) idle: calibrate the PLN encoder
+    # bias on rank 0's images so that about half of the first-stage detections fall within UNK_THR (0.23, the yaml's value)
+    # of a prototype (weights.with_known_unknown_mix), un-timed, then build the engine that is measured.
+    params = random_params(0)
+    cal = OpensetRCNNEngine(params, dtype=tdt, device=dev)
+    keep = {}
+    cal.forward_device(images[:4], image_hw[:4], 800, 1344, keep)
+    cnt = keep["cnt1"].cpu()
+    emb = torch.cat([keep["emb"].view(4, -1, keep["emb"].shape[-1])[i, :int(cnt[i])] for i in range(4)]).cpu()
+    if dist is not None:  # every rank uses rank 0's calibration: identical weights
+        blob = [emb if rank == 0 else None]
+        dist.broadcast_object_list(blob, src=0)
+        emb = blob[0]
+    params = with_known_unknown_mix(params, emb)
+    del cal, keep
+    eng = OpensetRCNNEngine(params, dtype=tdt, device=dev)
 
     def step():
         if args.streams > 1:
@@ -147,37 +246,62 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     n_det = int(out[3].sum().item())
+    n_unknown = int((out[2] == eng.cfg["unknown_id"]).logical_and(torch.arange(out[2].shape[1], device=out[2].device)[None, :] < out[3][:, None]).sum().item())
 
-    # ---- roofline of the dominant kernel family, measured live with HIP events on the launch stream ----
+    # ---- rooflines of the two kernel groups, measured live with HIP events on the launch stream ----
     # (the single-stream full-batch pass picks other tile configurations than the micro-batched one: run it once untimed so
     # that no launch of the bracketed pass is the first use of its kernel)
     eng.forward_device(images, image_hw, 800, 1344)
     torch.cuda.synchronize()
-    eng.profile = []
+    eng.profile, eng.profile_hbm = [], []
     eng.forward_device(images, image_hw, 800, 1344)  # attribution pass: one stream, so each launch can be bracketed
     torch.cuda.synchronize()
-    prof = eng.profile
-    eng.profile = None
+    prof, prof_hbm = eng.profile, eng.profile_hbm
+    eng.profile = eng.profile_hbm = None
     mfma_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1, _ in prof)
     mfma_flops = sum(f for _, f, _, _, _ in prof)
     achieved = mfma_flops / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
     peak = MFMA_PEAK_TFLOPS[args.dtype]
-    # HBM-side traffic of the same kernel family: PMC counters cannot be read from inside the process, so the value is
-    # the one collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x2 per the gfx950
-    # guide) on this very command and committed under profiles/; null when that file is absent.
-    traffic, traffic_source = None, None
-    tfile = os.path.join(ROOT, "profiles", "r01_j_kernel_times_and_traffic.json")
-    if os.path.exists(tfile):
-        with open(tfile) as fh:
-            cf = json.load(fh).get("conv_family", {})
-        traffic = round(cf.get("fetch_GB_per_step_x2corrected", 0.0) + cf.get("write_GB_per_step", 0.0), 2)
-        traffic_source = "profiles/r01_j_kernel_times_and_traffic.json (scripts/profile_round.sh: --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+    # HBM-side traffic of the same kernel family: PMC counters cannot be read from inside the process, so the value is the
+    # one collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x2 per the gfx950 guide) on this
+    # very command by scripts/profile_round.sh and committed under profiles/ (newest round first); null when absent.
+    traffic, traffic_source, hbm_traffic = None, None, None
+    for tag in ("r02_b", "r02_a", "r01_j"):
+        tfile = os.path.join(ROOT, "profiles", f"{tag}_kernel_times_and_traffic.json")
+        if os.path.exists(tfile):
+            with open(tfile) as fh:
+                blob = json.load(fh)
+            cf = blob.get("conv_family", {})
+            traffic = round(cf.get("fetch_GB_per_step_x2corrected", 0.0) + cf.get("write_GB_per_step", 0.0), 2)
+            ra = blob.get("roi_align", {})
+            if ra:
+                hbm_traffic = round(ra.get("fetch_GB_per_step_x2corrected", 0.0) + ra.get("write_GB_per_step", 0.0), 2)
+            traffic_source = f"profiles/{tag}_kernel_times_and_traffic.json (scripts/profile_round.sh: --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+            break
     algo_bytes = sum(nb for _, _, _, _, nb in prof)
     roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic,
                     traffic_unit="GB of HBM traffic per step of the same kernel family (all its launches)", traffic_source=traffic_source,
                     algorithmic_GB_per_step=round(algo_bytes / 1e9, 2),
                     kernel="conv_igemm64_kernel family (implicit-GEMM conv + FC)", launches_per_step=len(prof),
                     flops_per_step=mfma_flops, kernel_ms_per_step=round(mfma_ms, 3))
+    # HBM group: RoIAlign + proposal selection + the three NMS passes. NMS is not HBM-bound (n <= a few thousand
+    # boxes per segment, a serial greedy scan): its bytes are folded in, so the aggregate is dominated by RoIAlign, and its time
+    # and upper bound of IoU pairs (sum over segments of n^2 / 2) are reported per pass.
+    hbm_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1, _ in prof_hbm)
+    hbm_bytes = sum(nb for _, nb, _, _, _ in prof_hbm)
+    kernels = []
+    for name, nb, e0, e1, info in prof_hbm:
+        ms_ = e0.elapsed_time(e1)
+        k = dict(kernel=name, ms=round(ms_, 4), algorithmic_GB=round(nb / 1e9, 4), GBps=round(nb / ms_ / 1e6, 1), frac_of_hbm_peak=round(nb / ms_ / 1e6 / HBM_PEAK_GBS, 4))
+        if name.startswith("nms_topk") and info is not None:
+            seg = info.detach().cpu().double()
+            pairs = float((seg * seg / 2).sum())
+            k.update(boxes=int(seg.sum()), max_segment=int(seg.max()), iou_pairs_upper_bound=pairs, Gpairs_per_s=round(pairs / ms_ / 1e6, 3))
+        kernels.append(k)
+    hbm_gbs = hbm_bytes / hbm_ms / 1e6 if hbm_ms > 0 else 0.0
+    roofline_hbm = dict(bound="hbm", group="RoIAlign + proposal selection + NMS (SURVEY.md 8d)", achieved=round(hbm_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(hbm_gbs / HBM_PEAK_GBS, 4), algorithmic_GB_per_step=round(hbm_bytes / 1e9, 3), kernel_ms_per_step=round(hbm_ms, 3),
+                        traffic=hbm_traffic, traffic_unit="GB of HBM traffic per step of roi_align_kernel (FETCH_SIZE x2 + WRITE_SIZE)", kernels=kernels)
     if args.layers and rank == 0:
         for name, f, e0, e1, nb in prof:
             ms_ = e0.elapsed_time(e1)
@@ -192,7 +316,9 @@ def main():
             a[1] += f
         for k, (ms, f) in agg.items():
             print(f"  {k:40s} {ms:8.3f} ms  {f / ms / 1e9 if ms else 0:8.1f} TFLOP/s", file=sys.stderr)
-        print(f"  MFMA kernels total {mfma_ms:.3f} ms of {elapsed / args.steps * 1e3:.3f} ms/step", file=sys.stderr)
+        for k in kernels:
+            print(f"  {k['kernel']:40s} {k['ms']:8.3f} ms  {k['GBps']:8.1f} GB/s", file=sys.stderr)
+        print(f"  MFMA kernels total {mfma_ms:.3f} ms, HBM group {hbm_ms:.3f} ms of {elapsed / args.steps * 1e3:.3f} ms/step", file=sys.stderr)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -203,12 +329,19 @@ def main():
             "config": {"workload": "VOC-COCO openset_rcnn_R50_FPN_128k.yaml, inference-only, 3x800x1333 uint8 BGR -> padded 800x1344, "
                                    "1000 proposals/level (4273/img), 1000 dets/img, 50+50 final",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world} (images sharded, no collective)",
-                       "weights": "random-init (seed 0), FrozenBN folded", "detections_last_step": n_det,
+                       "weights": "random-init (seed 0), FrozenBN folded; PLN encoder bias calibrated for a known/unknown mix at UNK_THR 0.23",
+                       "detections_last_step": n_det, "unknown_detections_last_step": n_unknown, "known_detections_last_step": n_det - n_unknown,
                        "micro_batch_streams": args.streams, "hipgraph": bool(args.graph)},
-            "roofline": roofline,
+            "roofline": roofline, "roofline_hbm": roofline_hbm,
         }
+        if world == 1 and not args.no_train_step:
+            del eng
+            if args.graph:
+                del graph, gout
+            torch.cuda.empty_cache()
+            line["train_step"] = train_step_leg(params, tdt, dev, images, image_hw, args.train_steps, 2)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(params, args.cpu_batch, args.cpu_iters)
+            line["cpu_baseline"] = cpu_baseline(params, args.cpu_batch, one_thread=True)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

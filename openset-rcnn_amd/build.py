@@ -22,6 +22,7 @@ SOURCES = {
     "osr_preproc_pool.hip": ["-ffp-contract=off"],
     "osr_conv_gemm.hip": [],
     "osr_conv_gemm64.hip": [],
+    "osr_conv_f32.hip": [],
     "osr_rpn.hip": ["-ffp-contract=off"],
     "osr_roi_align.hip": ["-ffp-contract=off"],
     "osr_det_tail.hip": ["-ffp-contract=off"],

@@ -260,6 +260,8 @@ static osr_status conv_launch(const ConvArgs& a0, hipStream_t st) {
     return OSR_OK;
 }
 
+osr_status osr_conv_f32_run(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* residual, void* out,
+                            hipStream_t st);
 int osr_conv64_eligible(const osr_conv_params* p, long long in_bytes, long long w_bytes);
 osr_status osr_conv64_run(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* residual, const void* mask,
                           void* out, long long in_bytes, long long w_bytes, hipStream_t st);
@@ -281,12 +283,15 @@ static osr_status conv2d_fwd_impl(const osr_conv_params* p, const void* in, cons
         OSR_REQUIRE(p->res_mode == 0 || p->res_mode == 1, OSR_ERR_INVALID_ARG, "osr_conv2d_fwd_masked: res_mode must be 0 or 1");
     }
     OSR_REQUIRE(p->n >= 1 && p->hi >= 1 && p->wi >= 1 && p->ho >= 1 && p->wo >= 1, OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: bad spatial sizes");
-    OSR_REQUIRE(p->cin >= 32 && p->cin % 32 == 0, OSR_ERR_UNSUPPORTED, "osr_conv2d_fwd: cin must be a multiple of 32, got %d", p->cin);
-    OSR_REQUIRE(p->cout >= 8 && p->cout % 8 == 0, OSR_ERR_UNSUPPORTED, "osr_conv2d_fwd: cout must be a multiple of 8, got %d", p->cout);
+    const bool f32_mode = p->in_dtype == OSR_F32;  // parity mode: fp32 storage and products (osr_conv_f32.hip)
+    OSR_REQUIRE(f32_mode || (p->cin >= 32 && p->cin % 32 == 0), OSR_ERR_UNSUPPORTED, "osr_conv2d_fwd: cin must be a multiple of 32, got %d", p->cin);
+    OSR_REQUIRE(f32_mode || (p->cout >= 8 && p->cout % 8 == 0), OSR_ERR_UNSUPPORTED, "osr_conv2d_fwd: cout must be a multiple of 8, got %d", p->cout);
+    OSR_REQUIRE(p->cout >= 1, OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: cout must be positive");
     OSR_REQUIRE(p->kh >= 1 && p->kw >= 1 && p->kh <= 16 && p->kw <= 16 && p->stride_h >= 1 && p->stride_w >= 1 && p->pad_h >= 0 && p->pad_w >= 0,
                 OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: bad kernel geometry");
-    OSR_REQUIRE(p->in_dtype == OSR_F16 || p->in_dtype == OSR_BF16, OSR_ERR_UNSUPPORTED, "osr_conv2d_fwd: in_dtype must be f16/bf16");
+    OSR_REQUIRE(osr_dtype_ok(p->in_dtype), OSR_ERR_UNSUPPORTED, "osr_conv2d_fwd: in_dtype must be f16/bf16 (fast path) or f32 (parity mode)");
     OSR_REQUIRE(osr_dtype_ok(p->out_dtype), OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: bad out_dtype");
+    OSR_REQUIRE(!(f32_mode && masked), OSR_ERR_UNSUPPORTED, "osr_conv2d_fwd_masked: f16/bf16 only");
     OSR_REQUIRE(p->res_mode >= 0 && p->res_mode <= 3 && (p->res_mode == 0 || residual), OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: bad res_mode / residual");
     OSR_REQUIRE(p->pad_mode == 0 || p->pad_mode == 1, OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: bad pad_mode");
     if (p->pad_mode == 0) {
@@ -294,6 +299,11 @@ static osr_status conv2d_fwd_impl(const osr_conv_params* p, const void* in, cons
         // forms is either inside [0,hi)x[0,wi) or rejected by the bounds check
         OSR_REQUIRE((p->hi + 2 * p->pad_h - p->kh) / p->stride_h + 1 == p->ho && (p->wi + 2 * p->pad_w - p->kw) / p->stride_w + 1 == p->wo,
                     OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: ho/wo inconsistent with hi/wi/kernel/stride/pad");
+    }
+    if (f32_mode) {
+        OSR_REQUIRE((((uintptr_t)in | (uintptr_t)weight | (uintptr_t)out | (uintptr_t)bias | (uintptr_t)residual) & 15) == 0, OSR_ERR_INVALID_ARG,
+                    "osr_conv2d_fwd: pointers must be 16-byte aligned");
+        return osr_conv_f32_run(p, in, weight, bias, residual, out, (hipStream_t)stream);
     }
     OSR_REQUIRE(p->in_stride_w % 4 == 0 && p->in_stride_h % 8 == 0 && p->in_stride_n % 8 == 0, OSR_ERR_INVALID_ARG,
                 "osr_conv2d_fwd: input strides must keep 16-byte alignment (w %% 4, h/n %% 8; w %% 8 unless the stem view)");

@@ -34,7 +34,7 @@ extern "C" osr_status osr_preprocess(const void* src, int32_t src_is_u8, int32_t
                                      const float mean[3], const float stdv[3], void* dst, int32_t dst_dtype, void* stream) {
     OSR_REQUIRE(src && dst && mean && stdv, OSR_ERR_INVALID_ARG, "osr_preprocess: null pointer");
     OSR_REQUIRE(n >= 1 && h >= 1 && w >= 1 && hp >= h && wp >= w, OSR_ERR_INVALID_ARG, "osr_preprocess: bad sizes");
-    OSR_REQUIRE(dst_dtype == OSR_F16 || dst_dtype == OSR_BF16, OSR_ERR_UNSUPPORTED, "osr_preprocess: dst must be f16/bf16");
+    OSR_REQUIRE(osr_dtype_ok(dst_dtype), OSR_ERR_UNSUPPORTED, "osr_preprocess: dst must be f16/bf16/f32");
     const int hd = hp + 6, wd = osr_stem_padded_width(wp);
     const long long total = (long long)n * hd * wd;
     long long blocks = (total + 255) / 256;
@@ -42,8 +42,8 @@ extern "C" osr_status osr_preprocess(const void* src, int32_t src_is_u8, int32_t
     hipStream_t st = (hipStream_t)stream;
 #define OSR_PP(TS, TD) hipLaunchKernelGGL((preprocess_kernel<TS, TD>), dim3((unsigned)blocks), dim3(256), 0, st, (const TS*)src, n, h, w, hd, wd, \
                                           mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2], (TD*)dst)
-    if (src_is_u8) { if (dst_dtype == OSR_F16) OSR_PP(unsigned char, f16_t); else OSR_PP(unsigned char, bf16_t); }
-    else           { if (dst_dtype == OSR_F16) OSR_PP(float, f16_t); else OSR_PP(float, bf16_t); }
+    if (src_is_u8) { if (dst_dtype == OSR_F16) OSR_PP(unsigned char, f16_t); else if (dst_dtype == OSR_BF16) OSR_PP(unsigned char, bf16_t); else OSR_PP(unsigned char, float); }
+    else           { if (dst_dtype == OSR_F16) OSR_PP(float, f16_t); else if (dst_dtype == OSR_BF16) OSR_PP(float, bf16_t); else OSR_PP(float, float); }
 #undef OSR_PP
     OSR_CHECK_LAUNCH("osr_preprocess");
     return OSR_OK;
@@ -82,19 +82,20 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, 
 extern "C" osr_status osr_maxpool3x3s2(const void* in, int32_t n, int32_t hi, int32_t wi, int32_t c, void* out, int32_t dtype, void* stream) {
     OSR_REQUIRE(in && out, OSR_ERR_INVALID_ARG, "osr_maxpool3x3s2: null pointer");
     OSR_REQUIRE(n >= 1 && hi >= 1 && wi >= 1 && c >= 8 && c % 8 == 0, OSR_ERR_INVALID_ARG, "osr_maxpool3x3s2: bad sizes (c %% 8 == 0)");
-    OSR_REQUIRE(dtype == OSR_F16 || dtype == OSR_BF16, OSR_ERR_UNSUPPORTED, "osr_maxpool3x3s2: f16/bf16 only");
+    OSR_REQUIRE(osr_dtype_ok(dtype), OSR_ERR_UNSUPPORTED, "osr_maxpool3x3s2: bad dtype");
     const int ho = (hi - 1) / 2 + 1, wo = (wi - 1) / 2 + 1;
     const long long total = (long long)n * ho * wo * (c / 8);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == OSR_F16) hipLaunchKernelGGL(maxpool_kernel<f16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const f16_t*)in, n, hi, wi, c, ho, wo, (f16_t*)out);
+    else if (dtype == OSR_F32) hipLaunchKernelGGL(maxpool_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)in, n, hi, wi, c, ho, wo, (float*)out);
     else hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)in, n, hi, wi, c, ho, wo, (bf16_t*)out);
     OSR_CHECK_LAUNCH("osr_maxpool3x3s2");
     return OSR_OK;
 }
 
-// ---- stride-2 subsample (p6), NHWC, 16 B per lane; dtype-agnostic 2-byte elements ----
+// ---- stride-2 subsample (p6), NHWC, 16 B per lane; element-size agnostic (c8 = 16-byte chunks per pixel) ----
 __global__ __launch_bounds__(256) void subsample_kernel(const uint4* __restrict__ in, int n, int hi, int wi, int c8, int ho, int wo, uint4* __restrict__ out) {
     const long long total = (long long)n * ho * wo * c8;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -107,12 +108,13 @@ __global__ __launch_bounds__(256) void subsample_kernel(const uint4* __restrict_
 extern "C" osr_status osr_subsample2(const void* in, int32_t n, int32_t hi, int32_t wi, int32_t c, void* out, int32_t dtype, void* stream) {
     OSR_REQUIRE(in && out, OSR_ERR_INVALID_ARG, "osr_subsample2: null pointer");
     OSR_REQUIRE(n >= 1 && hi >= 1 && wi >= 1 && c >= 8 && c % 8 == 0, OSR_ERR_INVALID_ARG, "osr_subsample2: bad sizes (c %% 8 == 0)");
-    OSR_REQUIRE(dtype == OSR_F16 || dtype == OSR_BF16, OSR_ERR_UNSUPPORTED, "osr_subsample2: f16/bf16 only");
+    OSR_REQUIRE(osr_dtype_ok(dtype), OSR_ERR_UNSUPPORTED, "osr_subsample2: bad dtype");
     const int ho = (hi - 1) / 2 + 1, wo = (wi - 1) / 2 + 1;
-    const long long total = (long long)n * ho * wo * (c / 8);
+    const int c8 = c * osr_dtype_size(dtype) / 16;  // 16-byte chunks per pixel
+    const long long total = (long long)n * ho * wo * c8;
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(subsample_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)in, n, hi, wi, c / 8, ho, wo, (uint4*)out);
+    hipLaunchKernelGGL(subsample_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)in, n, hi, wi, c8, ho, wo, (uint4*)out);
     OSR_CHECK_LAUNCH("osr_subsample2");
     return OSR_OK;
 }

@@ -37,7 +37,28 @@ DEFAULT_CFG = dict(
 )
 
 
+def check_supported_losses(cfg: dict) -> None:
+    """What the loss kernels implement -- exactly what both Openset yaml files select: the "iou" box loss of the CF-RPN
+    (box_regression_w_iou.py:49-61) and smooth_l1 with beta 0 (= L1) for centerness, RoI box deltas and IoU. Any other
+    MODEL.RPN.BBOX_REG_LOSS_TYPE / *_LOSS_TYPE / *_SMOOTH_L1_BETA is refused here instead of silently training another loss."""
+    lt = cfg.get("loss_types")
+    if not lt:
+        return
+    if lt["rpn_box"][0] != "iou":
+        raise NotImplementedError(f"MODEL.RPN.BBOX_REG_LOSS_TYPE '{lt['rpn_box'][0]}': the HIP CF-RPN loss implements \"iou\" "
+                                  "(box_regression_w_iou.py:49-61), as both Openset yaml files select")
+    for key, name in (("rpn_ctr", "MODEL.RPN.CTR_REG_LOSS_TYPE"), ("roi_box", "MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE"), ("roi_iou", "MODEL.ROI_BOX_HEAD.IOU_REG_LOSS_TYPE")):
+        typ, beta = lt[key]
+        if typ != "smooth_l1" or beta != 0.0:
+            raise NotImplementedError(f"{name} '{typ}' with beta {beta}: the HIP losses implement smooth_l1 with beta 0 (= L1), the yaml default")
+
+
 class OpensetRCNNEngine:
+    """dtype: storage type of activations and MFMA operands. torch.float16 / torch.bfloat16 = the fast path (fp32 accumulation,
+    fp32 heads from the box features on). torch.float32 = PARITY MODE: every tensor and every product in fp32 (osr_conv_f32.hip,
+    1/16 of the fp16 matrix rate), the arithmetic the reference itself runs in -- boxes, scores and embeddings then agree with the
+    fp32 oracle to summation order (tests/test_e2e_parity.py)."""
+
     def __init__(self, params: Dict[str, torch.Tensor], cfg: Optional[dict] = None, dtype: torch.dtype = torch.float16,
                  device: str = "cuda", class_map: Optional[torch.Tensor] = None):
         self.cfg = dict(DEFAULT_CFG)
@@ -76,6 +97,7 @@ class OpensetRCNNEngine:
         self._lv_cache = {}
         self._streams = []
         self.profile = None  # set to a list to collect (name, algorithmic flops, start event, end event) per MFMA launch
+        self.profile_hbm = None  # set to a list to collect (name, algorithmic bytes, start event, end event, info) of the HBM-group kernels
         if self.has_rpn:
             self.rpn_wd = f32("proposal_generator.rpn_head.anchor_deltas.weight").view(-1, 256)
             self.rpn_bd = f32("proposal_generator.rpn_head.anchor_deltas.bias")
@@ -83,7 +105,7 @@ class OpensetRCNNEngine:
             self.rpn_bc = f32("proposal_generator.rpn_head.centerness.bias")
             self.rpn_wtail = torch.cat((self.rpn_wd, self.rpn_wc)).contiguous()
             self.rpn_btail = torch.cat((self.rpn_bd, self.rpn_bc)).contiguous()
-            self.fuse_rpn_head = True
+            self.fuse_rpn_head = dtype != torch.float32  # (the fused head kernel is an fp16/bf16 MFMA kernel; fp32 = parity mode)
             sizes = c["anchor_sizes"]
             self.cell_anchors = torch.tensor([[[-s / 2.0, -s / 2.0, s / 2.0, s / 2.0]] for s in sizes], dtype=torch.float32, device=dev)
         if not self.has_roi:
@@ -173,6 +195,18 @@ class OpensetRCNNEngine:
         self.profile.append(("proposal_generator.rpn_head.conv+tail", 2.0 * rows * 256 * (2304 + 5), e0, e1,
                              f.numel() * 2 + w.numel() * 2 + rows * 20))
 
+    def _hbm(self, name, fn, nbytes, info=None):
+        """Run fn(); with profile_hbm set, bracket it with HIP events on the launch stream and record its ALGORITHMIC bytes
+        (unique bytes read + bytes written, no credit for re-reads)."""
+        if self.profile_hbm is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.profile_hbm.append((name, float(nbytes() if callable(nbytes) else nbytes), e0, e1, info(out) if info else None))
+        return out
+
     # ---- CF-RPN ---------------------------------------------------------------------------------------------
     def _levels(self, shapes, n):
         key = (tuple(shapes), n)
@@ -201,8 +235,10 @@ class OpensetRCNNEngine:
                 self._conv(f, "proposal_generator.rpn_head.conv", 1, 1, relu=True, out=t_all[off:off + r])
                 off += r
             deltas, ctr = ops.cfrpn_head_tail(t_all, self.rpn_wd, self.rpn_bd, self.rpn_wc, self.rpn_bc)
-        sel = ops.rpn_select(self._levels(shapes, n), self.cell_anchors, ctr, deltas, n, image_hw,
-                             self.cfg["pre_nms_topk_test"] if topk is None else topk, self.cfg["min_box_size"])
+        k = self.cfg["pre_nms_topk_test"] if topk is None else topk
+        # algorithmic bytes: every centerness score once + the k selected anchors' deltas + the padded outputs
+        sel = self._hbm("rpn_select", lambda: ops.rpn_select(self._levels(shapes, n), self.cell_anchors, ctr, deltas, n, image_hw, k, self.cfg["min_box_size"]),
+                        lambda: ctr.numel() * 4 + n * sum(min(k, h * w) for h, w in shapes) * (16 + 16 + 4 + 4 + 4))
         sel.update(pred_deltas=deltas, pred_ctr=ctr, levels=self._levels(shapes, n))
         if keep is not None:
             keep.update(rpn_t=t_all, rpn_deltas=deltas, rpn_ctr=ctr, rpn_shapes=shapes)
@@ -213,15 +249,21 @@ class OpensetRCNNEngine:
         c = self.cfg
         n, cap = sel["boxes"].shape[0], sel["cap"]
         boxes = sel["boxes"].view(-1, 4)
-        pooled = ops.roi_align([feats[k] for k in ("p2", "p3", "p4", "p5")], c["pooler_scales"], boxes, sel["batch_idx"],
-                               c["pooler_resolution"], self.dtype, c["canonical_level"], c["canonical_size"], 2)
+        fl = [feats[k] for k in ("p2", "p3", "p4", "p5")]
+        es = fl[0].element_size()
+        # algorithmic bytes: the pyramid once + the pooled output once + the RoIs
+        pooled = self._hbm("roi_align", lambda: ops.roi_align(fl, c["pooler_scales"], boxes, sel["batch_idx"], c["pooler_resolution"], self.dtype,
+                                                               c["canonical_level"], c["canonical_size"], 2),
+                           lambda: sum(f.numel() for f in fl) * es + boxes.shape[0] * (c["pooler_resolution"] ** 2 * 256 * es + 20))
         m = pooled.shape[0]
         h1 = self._linear(pooled.view(m, -1), self.fc1_w, self.fc1_b, True, name="roi_heads.box_head.fc1")
         box_feats = self._linear(h1, self.fc2_w, self.fc2_b, True, torch.float32, name="roi_heads.box_head.fc2")
         pt = ops.box_predictor_tail(box_feats, self.pred_w, self.pred_b, boxes, sel["scores"].view(-1), sel["batch_idx"], image_hw,
                                     c["bbox_reg_weights"], 0 if c["mean_type"] == "geometric" else 1, c["obj_score_thresh"])
         topk1 = c["detections_per_image"]
-        keep1, cnt1 = ops.nms_topk(pt["boxes"], pt["score"], None, pt["cand"], n, cap, sel["counts"], c["nms_thresh_test"], topk1)
+        keep1, cnt1 = self._hbm("nms_topk(first stage: sort, thr 1.0)", lambda: ops.nms_topk(pt["boxes"], pt["score"], None, pt["cand"], n, cap, sel["counts"],
+                                                                                              c["nms_thresh_test"], topk1),
+                                n * cap * 24, lambda o: sel["counts"])
         det_boxes = ops.gather_rows(pt["boxes"], cap, keep1, cnt1)
         det_scores = ops.gather_rows(pt["score"], cap, keep1, cnt1)
         det_feats = ops.gather_rows(box_feats, cap, keep1, cnt1)
@@ -233,10 +275,12 @@ class OpensetRCNNEngine:
         # class_map (GraspNet) remaps known ids at the very end; the known/unknown split uses the un-mapped unknown id
         cands = ops.softmax_candidates(logits, c["num_known"], det_boxes.view(-1, 4), det_scores.view(-1), pcls, cnt1, n, topk1,
                                        c["unknown_id"], c["known_score_thresh"], c["unknown_score_thresh"])
-        kk, kc = ops.nms_topk(cands["k_boxes"], cands["k_scores"], cands["k_cls"], None, n, topk1 * c["num_known"], cands["k_count"],
-                              c["known_nms_thresh"], c["known_topk"])
-        uk, uc = ops.nms_topk(cands["u_boxes"], cands["u_scores"], None, None, n, topk1, cands["u_count"], c["unknown_nms_thresh"],
-                              c["unknown_topk"])
+        kk, kc = self._hbm("nms_topk(known, per class)", lambda: ops.nms_topk(cands["k_boxes"], cands["k_scores"], cands["k_cls"], None, n, topk1 * c["num_known"],
+                                                                              cands["k_count"], c["known_nms_thresh"], c["known_topk"]),
+                           lambda: int(cands["k_count"].sum()) * 24, lambda o: cands["k_count"])
+        uk, uc = self._hbm("nms_topk(unknown, class-agnostic)", lambda: ops.nms_topk(cands["u_boxes"], cands["u_scores"], None, None, n, topk1, cands["u_count"],
+                                                                                     c["unknown_nms_thresh"], c["unknown_topk"]),
+                           lambda: int(cands["u_count"].sum()) * 20, lambda o: cands["u_count"])
         ob, osc, ocl, on = ops.assemble_detections(cands, kk, kc, uk, uc, n, c["unknown_id"], self.class_map)
         if keep is not None:
             keep.update(pooled=pooled, h1=h1, box_feats=box_feats, pred=pt, keep1=keep1, cnt1=cnt1, det_boxes=det_boxes,
@@ -327,6 +371,7 @@ class OpensetRCNNEngine:
         """ClsFreeRPN.label_and_sample_anchors + .losses (classification_free_rpn.py:320-491) on the head outputs `sel` carries
         (level-major pred_deltas / pred_ctr). Returns (6 floats: loss_rpn_loc, loss_rpn_ctr, 4 anchor counts; state dict that the
         backward needs: labels, obj_labels, matched_boxes, ctr_target)."""
+        check_supported_losses(self.cfg)
         c, lv = self.cfg, sel["levels"]
         midx, miou, lab, olab = ops.rpn_match_anchors(lv, self.cell_anchors, n, gt_boxes, gt_count, c["rpn_iou_thresholds"],
                                                       c["rpn_iou_thresholds_objectness"])
@@ -344,6 +389,7 @@ class OpensetRCNNEngine:
         """OpensetROIHeads.label_and_sample_proposals + _forward_box in training mode (osrcnn_roi_heads.py:137-230,282-318):
         proposals are fixed inputs (predict_proposals runs under no_grad, classification_free_rpn.py:575). Returns (losses of the
         four heads as a dict of GPU scalars + 'roi_counts', state dict with every activation the backward reads)."""
+        check_supported_losses(self.cfg)
         c = self.cfg
         smp = ops.roi_match_and_sample(prop_boxes, prop_scores, prop_counts, gt_boxes, gt_classes, gt_count, keys_roi,
                                        c["num_classes"], c["roi_batch_size"], c["roi_positive_fraction"], c["roi_iou_threshold"])

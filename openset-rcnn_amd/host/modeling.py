@@ -395,15 +395,6 @@ class SoftMaxClassifier(nn.Module):
 def engine_cfg_from(cfg: CfgNode) -> dict:
     """yaml keys -> engine hyper-parameters."""
     rh, bh, rpn = cfg.MODEL.ROI_HEADS, cfg.MODEL.ROI_BOX_HEAD, cfg.MODEL.RPN
-    # what the loss kernels implement (the two shipped yaml files select exactly these; anything else would silently train another loss)
-    if cfg.MODEL.PROPOSAL_GENERATOR.NAME == "ClsFreeRPN" and rpn.BBOX_REG_LOSS_TYPE != "iou":
-        raise NotImplementedError(f"MODEL.RPN.BBOX_REG_LOSS_TYPE '{rpn.BBOX_REG_LOSS_TYPE}': the HIP CF-RPN loss implements \"iou\" "
-                                  "(box_regression_w_iou.py:49-61), as both Openset yaml files select")
-    for key, typ, beta in (("MODEL.RPN.CTR_REG_LOSS_TYPE", rpn.CTR_REG_LOSS_TYPE, rpn.CTR_SMOOTH_L1_BETA),
-                           ("MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE", bh.BBOX_REG_LOSS_TYPE, bh.SMOOTH_L1_BETA),
-                           ("MODEL.ROI_BOX_HEAD.IOU_REG_LOSS_TYPE", bh.IOU_REG_LOSS_TYPE, bh.IOU_SMOOTH_L1_BETA)):
-        if typ != "smooth_l1" or float(beta) != 0.0:
-            raise NotImplementedError(f"{key} '{typ}' with beta {beta}: the HIP losses implement smooth_l1 with beta 0 (= L1), the yaml default")
     return dict(
         pixel_mean=tuple(cfg.MODEL.PIXEL_MEAN), pixel_std=tuple(cfg.MODEL.PIXEL_STD),
         anchor_sizes=tuple(float(s[0]) for s in cfg.MODEL.ANCHOR_GENERATOR.SIZES),
@@ -423,6 +414,9 @@ def engine_cfg_from(cfg: CfgNode) -> dict:
         roi_batch_size=rh.BATCH_SIZE_PER_IMAGE, roi_positive_fraction=rh.POSITIVE_FRACTION, roi_iou_threshold=float(rh.IOU_THRESHOLDS[0]),
         box_reg_weight=bh.BBOX_REG_LOSS_WEIGHT, iou_reg_weight=bh.IOU_REG_LOSS_WEIGHT, pln_alpha=cfg.MODEL.PLN.ALPHA, pln_beta=cfg.MODEL.PLN.BETA,
         pln_iou_threshold=cfg.MODEL.PLN.IOU_THRESHOLD, pln_loss_weight=cfg.MODEL.PLN.LOSS_WEIGHT, cls_loss_weight=bh.CLS_LOSS_WEIGHT,
+        # checked by engine.check_supported_losses when a loss is first computed (inference never needs them)
+        loss_types=dict(rpn_box=(rpn.BBOX_REG_LOSS_TYPE, float(rpn.SMOOTH_L1_BETA)), rpn_ctr=(rpn.CTR_REG_LOSS_TYPE, float(rpn.CTR_SMOOTH_L1_BETA)),
+                        roi_box=(bh.BBOX_REG_LOSS_TYPE, float(bh.SMOOTH_L1_BETA)), roi_iou=(bh.IOU_REG_LOSS_TYPE, float(bh.IOU_SMOOTH_L1_BETA))),
     )
 
 

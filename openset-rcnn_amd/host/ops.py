@@ -57,6 +57,9 @@ def preprocess(images: torch.Tensor, hp: int, wp: int, mean, std, dtype=torch.fl
 
 
 _CONCURRENCY = [1]
+# bench.py's train_step leg sets this to a dict {"conv": 0.0, "wgrad": 0.0}: algorithmic FLOPs (2*M*K*N of the layer definition)
+# of every MFMA conv / FC launch (forward and data-gradient launches both go through conv2d) and of every weight-gradient launch
+FLOP_COUNT = None
 
 
 class concurrent_streams:
@@ -102,6 +105,8 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, stride: in
     else:
         _need(out, out_dtype, "out")
         assert out.numel() == n * ho * wo * cout
+    if FLOP_COUNT is not None:
+        FLOP_COUNT["conv"] += 2.0 * n * ho * wo * cout * kh * kw * cin
     p = _new_conv_params()
     p.n, p.hi, p.wi, p.cin, p.ho, p.wo, p.cout = n, hi, wi, cin, ho, wo, cout
     p.kh, p.kw, p.stride_h, p.stride_w, p.pad_h, p.pad_w = kh, kw, stride, stride, pad, pad
@@ -145,6 +150,8 @@ def stem_conv(xpad: torch.Tensor, w_view: torch.Tensor, bias: torch.Tensor, hp: 
     kh = w_view.shape[1]
     ho, wo = hp // 2, wp // 2
     out = torch.empty((n, ho, wo, cout), dtype=xpad.dtype, device=xpad.device)
+    if FLOP_COUNT is not None:
+        FLOP_COUNT["conv"] += 2.0 * n * ho * wo * cout * 147  # 7*7*3 real taps
     p = _new_conv_params()
     p.n, p.hi, p.wi, p.cin, p.ho, p.wo, p.cout = n, hd, wd, 32, ho, wo, cout
     p.kh, p.kw, p.stride_h, p.stride_w, p.pad_h, p.pad_w = kh, 1, 2, 2, 0, 0
@@ -590,6 +597,8 @@ def conv2d_dgrad(dy: torch.Tensor, w_dgrad: torch.Tensor, x_hw: Tuple[int, int],
         raise OsrError("strided backward-data is implemented for 1x1 layers only (the reference's R-50 strides in the 1x1)")
     if (hi - 1) // stride + 1 != ho or (wi - 1) // stride + 1 != wo:
         raise OsrError("x_hw inconsistent with dy and the stride")
+    if FLOP_COUNT is not None:
+        FLOP_COUNT["conv"] += 2.0 * n * ho * wo * cout * cin
     dx = torch.zeros((n, hi, wi, cin), dtype=out_dtype, device=dy.device)
     p = _conv_params(n, ho, wo, cout, ho, wo, cin, 1, 1, 1, 0, dy.dtype, out_dtype)
     p.out_stride_n, p.out_stride_h, p.out_stride_w = hi * wi * cin, stride * wi * cin, stride * cin
@@ -624,6 +633,8 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: in
     n2, ho, wo, cout = dy.shape
     if n2 != n or (hi + 2 * pad - kh) // stride + 1 != ho or (wi + 2 * pad - kw) // stride + 1 != wo:
         raise OsrError("dy shape inconsistent with x and the kernel geometry")
+    if FLOP_COUNT is not None:
+        FLOP_COUNT["wgrad"] += 2.0 * n * ho * wo * cout * kh * kw * cin
     p = _conv_params(n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, x.dtype, x.dtype)
     if dw is None:
         dw = torch.empty((cout, kh, kw, cin), dtype=torch.float32, device=x.device)

@@ -107,3 +107,23 @@ def pack_dgrad_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """(cout,cin,kh,kw) -> (cin,kh,kw,cout), spatially flipped: the backward-data pass of a stride-1 convolution is the
     forward convolution of dy with these weights and padding k-1-pad; for a 1x1 layer it is the transposed matrix."""
     return w.flip(2, 3).permute(1, 2, 3, 0).contiguous().to(dtype)
+
+
+def with_known_unknown_mix(params: Dict[str, torch.Tensor], embeddings: torch.Tensor, unk_thr: float = 0.23, known_fraction: float = 0.5,
+                           proto: int = 0) -> Dict[str, torch.Tensor]:
+    """Synthetic-weights helper (benchmarks / tests; no checkpoint is reachable offline). Random prototypes put every embedding
+    ~0.85-1.0 away from all of them, so PLN.inference (prototype_learning_network.py:213-223) calls every detection "unknown" and
+    the known-class leg (softmax over <= 20 000 candidates, per-class NMS) idles. This returns a copy of `params` whose PLN
+    encoder bias is c * P_hat[proto]: with emb = W f + b, cos(emb, P_hat) = c / sqrt(c^2 + |W f|^2) (W f is nearly orthogonal to
+    one fixed direction of 256), so the detections whose |W f| is below c * sqrt(1 / (1 - unk_thr)^2 - 1) become known. `c` is
+    set from the `known_fraction` quantile of |embeddings| (rows = embeddings of a run with zero encoder bias, valid rows only).
+    UNK_THR itself stays the yaml's value."""
+    out = dict(params)
+    p = params["roi_heads.dml.representatives"].float()
+    ph = p[proto] / p[proto].norm().clamp(min=1e-12)
+    norms = embeddings.detach().float().cpu().norm(dim=1)
+    q = float(torch.quantile(norms, known_fraction))
+    cos_thr = 1.0 - unk_thr
+    c = q / math.sqrt(1.0 / (cos_thr * cos_thr) - 1.0)
+    out["roi_heads.dml.encoder.bias"] = (c * ph).contiguous()
+    return out

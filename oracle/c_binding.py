@@ -67,3 +67,8 @@ def batched_nms(boxes: np.ndarray, scores: np.ndarray, cls: np.ndarray, thr: flo
     keep = np.zeros(max(b.shape[0], 1), dtype=np.int64)
     k = lib().osr_oracle_batched_nms(_p(b), _p(s), _p(c), ctypes.c_int64(b.shape[0]), ctypes.c_float(thr), _p(keep))
     return keep[:k]
+
+
+def set_threads(k: int) -> None:
+    """OpenMP thread count of the C half (bench.py's cpu_baseline times a 1-thread and an all-core point)."""
+    lib().omp_set_num_threads(int(k))

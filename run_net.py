@@ -44,7 +44,8 @@ def parse_args(argv=None):
     ap.add_argument("--test-batch", type=int, default=1,
                     help="images per inference launch. 1 = the reference's evaluation (each image padded to a multiple of 32 on its own); larger "
                          "batches are faster but pad every image to the largest one of its batch, which changes features near the padded border")
-    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="storage dtype of activations / MFMA operands")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"],
+                    help="storage dtype of activations / MFMA operands; f32 = parity mode (inference only: the reference's own arithmetic, ~10x slower)")
     ap.add_argument("opts", default=None, nargs=argparse.REMAINDER, help="KEY VALUE config overrides")
     args = ap.parse_args(argv)
     if args.resume_test and args.opendet_benchmark:
@@ -270,7 +271,9 @@ def main(argv=None) -> int:
     cfgm.MODEL.DEVICE = f"cuda:{local_rank}"
     cfgm.freeze()
     model = build_model(cfgm, class_id_for(cfg, D))
-    model.kernel_dtype = torch.float16 if args.dtype == "f16" else torch.bfloat16
+    model.kernel_dtype = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
+    if args.dtype == "f32" and not args.eval_only:
+        raise SystemExit("--dtype f32 is the inference parity mode; train with f16 or bf16 (fp32 masters, fp32 accumulation)")
     start, opt_state = resume_or_load(cfg, model, args.resume)
     model.eval()
     if not args.eval_only:

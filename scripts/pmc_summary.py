@@ -29,7 +29,7 @@ def counter_sum(path, steps):
 
 
 def main():
-    out_dir, steps = sys.argv[1], int(sys.argv[2])
+    out_dir, steps = sys.argv[1], float(sys.argv[2])
     stats = {}
     for f in glob.glob(out_dir + "/stats/**/*kernel_stats.csv", recursive=True):
         for row in csv.DictReader(open(f)):
@@ -49,11 +49,12 @@ def main():
     conv = [v for k, v in kernels.items() if k.startswith("conv_igemm")]
     print(json.dumps(dict(
         note="scripts/profile_round.sh: rocprofv3 --kernel-trace --stats, then --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of "
-             "`bench.py --steps 5 --warmup 2 --no-cpu-baseline --streams 1 --no-graph` (`steps` passes of the path each: 2 warm-up + 5 timed + the attribution passes); FETCH_SIZE doubled per "
+             "`bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train-step --streams 1 --no-graph` (`steps` passes of the path each: 2 warm-up + 5 timed + the attribution passes + the 4-image calibration pass); FETCH_SIZE doubled per "
              "MI355X_MICROARCH.md; GB per 16-image step",
         conv_family=dict(ms_per_step=round(sum(v["ms_per_step"] for v in conv), 3),
                          fetch_GB_per_step_x2corrected=round(sum(v["fetch_GB_per_step_x2corrected"] for v in conv), 3),
                          write_GB_per_step=round(sum(v["write_GB_per_step"] for v in conv), 3)),
+        roi_align=next((v for k, v in kernels.items() if k.startswith("roi_align")), {}),
         kernels=kernels), indent=1))
 
 

@@ -37,12 +37,14 @@ def test_scheduler_mirror_follows_warmup_multistep(osr):
 
 
 def test_unsupported_loss_types_are_rejected_not_silently_replaced(osr):
+    from openset_rcnn_amd.host.engine import check_supported_losses
     from openset_rcnn_amd.host.modeling import engine_cfg_from
     assert engine_cfg_from(_cfg(osr))["rpn_loc_weight"] == 0.5
+    check_supported_losses(engine_cfg_from(_cfg(osr)))  # the yaml's choice passes
     for opt in (["MODEL.RPN.BBOX_REG_LOSS_TYPE", "giou"], ["MODEL.RPN.BBOX_REG_LOSS_TYPE", "smooth_l1"], ["MODEL.RPN.CTR_SMOOTH_L1_BETA", "0.1"],
                 ["MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE", "giou"], ["MODEL.ROI_BOX_HEAD.IOU_SMOOTH_L1_BETA", "1.0"]):
-        with pytest.raises(NotImplementedError):
-            engine_cfg_from(_cfg(osr, opt))
+        with pytest.raises(NotImplementedError):  # raised when a loss is first computed (engine.*_losses_forward), never at inference
+            check_supported_losses(engine_cfg_from(_cfg(osr, opt)))
     # RPN.LOSS_WEIGHT multiplies both CF-RPN losses (classification_free_rpn.py:273-276)
     assert engine_cfg_from(_cfg(osr, ["MODEL.RPN.LOSS_WEIGHT", "2.0"]))["rpn_ctr_weight"] == 1.0
 
