@@ -151,6 +151,18 @@ osr_status osr_rpn_select(const osr_rpn_levels* lv, const float* cell_anchors /*
                           int32_t* counts, int32_t* status_flags, void* workspace, int64_t workspace_bytes,
                           void* stream);
 
+/* osr_rpn_select with the decode rule and an extra output selectable -- what the stock detectron2 RPN of
+ * /root/reference/configs/Base-RCNN-FPN.yaml:9-21 (BASELINE config 1) needs next to the CF-RPN:
+ * decode_mode 0 = [d2] Box2BoxTransformLinear (ltrb, the CF-RPN; reg_weights ignored), 1 = [d2] Box2BoxTransform with
+ * reg_weights (dx,dy,dw,dh; dw/dh clamped at log(1000/16)) -- MODEL.RPN.BBOX_REG_WEIGHTS. `ctr` is then the objectness LOGIT
+ * (top-k on the raw value, as [d2] find_top_rpn_proposals does). level_out (nullable): (n,cap) pyramid level of every kept
+ * slot (-1 padding): the category of the per-level batched NMS that follows (osr_nms_topk, thr MODEL.RPN.NMS_THRESH). */
+osr_status osr_rpn_select_ex(const osr_rpn_levels* lv, const float* cell_anchors, const float* ctr, const float* deltas,
+                             int32_t n, const int32_t* image_hw, int32_t pre_nms_topk, float min_box_size,
+                             int32_t decode_mode, const float reg_weights[4], float* boxes, float* scores,
+                             int32_t* src_index, int32_t* batch_idx, int32_t* level_out, int32_t* counts,
+                             int32_t* status_flags, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * RoIAlign over the pyramid: [d2] ROIPooler.forward (level = floor(4+log2(sqrt(area)/224+1e-8)) clamped to
  * [min,max]) -> torchvision roi_align(aligned=True, sampling_ratio=0) (osrcnn_roi_heads.py:108-113,306).
@@ -235,6 +247,20 @@ osr_status osr_softmax_candidates(const float* logits, int32_t num_known, const 
                                   float unknown_thresh, float* k_boxes, float* k_scores, int32_t* k_cls, int32_t* k_det,
                                   int32_t* k_count, float* u_boxes, float* u_scores, int32_t* u_det, int32_t* u_count,
                                   void* stream);
+
+/* [d2] FastRCNNOutputLayers.inference -> fast_rcnn_inference_single_image up to (not including) the NMS, for the stock
+ * StandardROIHeads of /root/reference/configs/Base-RCNN-FPN.yaml:22-28 (BASELINE config 1). logits (n*seg_rows, K+1),
+ * deltas (n*seg_rows, R*4) with R = num_bbox_reg_classes (K, or 1 when class-agnostic), prop_boxes (n, seg_rows, 4) padded with
+ * prop_count (n) valid rows. Per valid row: softmax; Box2BoxTransform(reg_weights) decode of every class's box; the row is
+ * dropped when any box coordinate or probability is non-finite; boxes clipped to image_hw; every (row, class < K) with
+ * p > score_thresh becomes a candidate, row-major. Outputs padded to seg_rows*K per image: c_boxes (n,cap,4), c_scores,
+ * c_cls, c_row (proposal row of the candidate), c_count (n). Follow with osr_nms_topk(cls = c_cls, thr NMS_THRESH_TEST,
+ * topk DETECTIONS_PER_IMAGE). */
+osr_status osr_fastrcnn_candidates(const float* logits, const float* deltas, int32_t num_classes,
+                                   int32_t num_bbox_reg_classes, const float* prop_boxes, const int32_t* prop_count,
+                                   int32_t n, int32_t seg_rows, const int32_t* image_hw, const float reg_weights[4],
+                                   float score_thresh, float* c_boxes, float* c_scores, int32_t* c_cls, int32_t* c_row,
+                                   int32_t* c_count, void* stream);
 
 /* Final assembly: output order [unknown..., known...] (softmax_classifier.py:328-334), class ids int64
  * (unknown_id for the unknown group, class_map[c] or c for known). out_* padded to (n, u_topk + k_topk). */

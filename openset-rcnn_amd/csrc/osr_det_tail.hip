@@ -492,6 +492,100 @@ extern "C" osr_status osr_softmax_candidates(const float* logits, int32_t num_kn
 }
 
 // ------------------------------------------------------------------------------------------------------
+// [d2] FastRCNNOutputLayers.inference -> fast_rcnn_inference_single_image, everything before the NMS (BASELINE config 1:
+// Base-RCNN-FPN.yaml's StandardROIHeads): softmax over K+1 logits, class-specific Box2BoxTransform decode (K*4 deltas per
+// row; 4 when class-agnostic), rows with a non-finite box or probability dropped, clip, (row, class) pairs with
+// p > score_thresh emitted in row-major order (= nonzero()). Block per image, thread per proposal row.
+// ------------------------------------------------------------------------------------------------------
+#define FR_MAX_CLASSES 128
+
+__global__ __launch_bounds__(1024) void fastrcnn_cand_kernel(const float* __restrict__ logits, const float* __restrict__ deltas, int K, int kbox,
+                                                             const float* __restrict__ prop_boxes, const int* __restrict__ prop_count,
+                                                             int seg_rows, const int* __restrict__ image_hw, float4 rw, float score_thresh,
+                                                             float* __restrict__ c_boxes, float* __restrict__ c_scores, int* __restrict__ c_cls,
+                                                             int* __restrict__ c_row, int* __restrict__ c_count) {
+    __shared__ int s_scan[32];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    int cnt = prop_count[img];
+    if (cnt > seg_rows) cnt = seg_rows;
+    const long long ccap = (long long)seg_rows * K;
+    const float ih = (float)image_hw[img * 2], iw = (float)image_hw[img * 2 + 1];
+    const float kClamp = 4.135166556742356f;  // log(1000 / 16)
+    int run = 0;
+    for (int j0 = 0; j0 < seg_rows; j0 += blockDim.x) {
+        const int j = j0 + tid;
+        const long long r = (long long)img * seg_rows + j;
+        int nk = 0;
+        float mx = 0.f, sum = 1.f;
+        float4 pb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < cnt) {
+            pb = *reinterpret_cast<const float4*>(prop_boxes + r * 4);
+            const float* lg = logits + r * (K + 1);
+            mx = lg[0];
+            for (int c = 1; c <= K; ++c) mx = fmaxf(mx, lg[c]);
+            sum = 0.f;
+            for (int c = 0; c <= K; ++c) sum += expf(lg[c] - mx);
+            bool ok = true;
+            for (int c = 0; c <= K; ++c) ok = ok && osr_finite(expf(lg[c] - mx) / sum);
+            // every class's decoded box must be finite, or the whole row is dropped (valid_mask over dim 1)
+            const float w = pb.z - pb.x, h = pb.w - pb.y, cx = pb.x + 0.5f * w, cy = pb.y + 0.5f * h;
+            const float* dl = deltas + r * (long long)kbox * 4;
+            for (int c = 0; c < kbox && ok; ++c) {
+                const float dx = dl[c * 4] / rw.x, dy = dl[c * 4 + 1] / rw.y, dw = fminf(dl[c * 4 + 2] / rw.z, kClamp), dh = fminf(dl[c * 4 + 3] / rw.w, kClamp);
+                const float pcx = dx * w + cx, pcy = dy * h + cy, pw = expf(dw) * w, ph = expf(dh) * h;
+                ok = osr_finite(pcx - 0.5f * pw) && osr_finite(pcy - 0.5f * ph) && osr_finite(pcx + 0.5f * pw) && osr_finite(pcy + 0.5f * ph) &&
+                     dl[c * 4 + 2] == dl[c * 4 + 2] && dl[c * 4 + 3] == dl[c * 4 + 3];  // (fminf drops a NaN delta; torch.clamp keeps it)
+            }
+            if (ok)
+                for (int c = 0; c < K; ++c) nk += (expf(lg[c] - mx) / sum) > score_thresh;
+        }
+        int tot;
+        const int pos = run + osr_block_excl_scan(nk, s_scan, &tot);
+        if (nk) {
+            const float* lg = logits + r * (K + 1);
+            const float* dl = deltas + r * (long long)kbox * 4;
+            const float w = pb.z - pb.x, h = pb.w - pb.y, cx = pb.x + 0.5f * w, cy = pb.y + 0.5f * h;
+            int o = pos;
+            for (int c = 0; c < K; ++c) {
+                const float p = expf(lg[c] - mx) / sum;
+                if (p > score_thresh) {
+                    const int cb = kbox > 1 ? c : 0;
+                    const float dx = dl[cb * 4] / rw.x, dy = dl[cb * 4 + 1] / rw.y, dw = fminf(dl[cb * 4 + 2] / rw.z, kClamp), dh = fminf(dl[cb * 4 + 3] / rw.w, kClamp);
+                    const float pcx = dx * w + cx, pcy = dy * h + cy, pw = expf(dw) * w, ph = expf(dh) * h;
+                    float4 b = make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
+                    b.x = fminf(fmaxf(b.x, 0.f), iw); b.y = fminf(fmaxf(b.y, 0.f), ih);
+                    b.z = fminf(fmaxf(b.z, 0.f), iw); b.w = fminf(fmaxf(b.w, 0.f), ih);
+                    const long long q = (long long)img * ccap + o;
+                    *reinterpret_cast<float4*>(c_boxes + q * 4) = b;
+                    c_scores[q] = p; c_cls[q] = c; c_row[q] = j;
+                    ++o;
+                }
+            }
+        }
+        run += tot;
+    }
+    if (tid == 0) c_count[img] = run;
+}
+
+extern "C" osr_status osr_fastrcnn_candidates(const float* logits, const float* deltas, int32_t num_classes, int32_t num_bbox_reg_classes,
+                                              const float* prop_boxes, const int32_t* prop_count, int32_t n, int32_t seg_rows,
+                                              const int32_t* image_hw, const float reg_weights[4], float score_thresh, float* c_boxes,
+                                              float* c_scores, int32_t* c_cls, int32_t* c_row, int32_t* c_count, void* stream) {
+    OSR_REQUIRE(logits && deltas && prop_boxes && prop_count && image_hw && reg_weights && c_boxes && c_scores && c_cls && c_row && c_count,
+                OSR_ERR_INVALID_ARG, "osr_fastrcnn_candidates: null pointer");
+    OSR_REQUIRE(n >= 1 && seg_rows >= 1 && num_classes >= 1 && num_classes <= FR_MAX_CLASSES && (num_bbox_reg_classes == 1 || num_bbox_reg_classes == num_classes),
+                OSR_ERR_INVALID_ARG, "osr_fastrcnn_candidates: bad sizes (1..%d classes; box regression class-agnostic or per class)", FR_MAX_CLASSES);
+    OSR_REQUIRE(reg_weights[0] > 0.f && reg_weights[1] > 0.f && reg_weights[2] > 0.f && reg_weights[3] > 0.f, OSR_ERR_INVALID_ARG,
+                "osr_fastrcnn_candidates: regression weights must be positive");
+    OSR_REQUIRE((((uintptr_t)prop_boxes | (uintptr_t)c_boxes) & 15) == 0, OSR_ERR_INVALID_ARG, "osr_fastrcnn_candidates: box arrays must be 16-byte aligned");
+    hipLaunchKernelGGL(fastrcnn_cand_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, logits, deltas, num_classes, num_bbox_reg_classes, prop_boxes,
+                       prop_count, seg_rows, image_hw, make_float4(reg_weights[0], reg_weights[1], reg_weights[2], reg_weights[3]), score_thresh, c_boxes,
+                       c_scores, c_cls, c_row, c_count);
+    OSR_CHECK_LAUNCH("osr_fastrcnn_candidates");
+    return OSR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // final assembly: [unknown..., known...]
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__ k_boxes, const float* __restrict__ k_scores,

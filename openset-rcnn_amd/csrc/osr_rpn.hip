@@ -115,8 +115,8 @@ __device__ __forceinline__ void bitonic_desc(unsigned long long* buf, int n) {
 __global__ __launch_bounds__(SEL_THREADS) void rpn_select_kernel(SelLevels lv, const float* __restrict__ cell_anchors,
                                                                  const float* __restrict__ ctr, const float* __restrict__ deltas,
                                                                  int n_img, const int* __restrict__ image_hw, float min_box_size,
-                                                                 float* __restrict__ st_box, float* __restrict__ st_score,
-                                                                 int* __restrict__ st_src, int* __restrict__ st_flag,
+                                                                 int decode_mode, float4 rw, float* __restrict__ st_box,
+                                                                 float* __restrict__ st_score, int* __restrict__ st_src, int* __restrict__ st_flag,
                                                                  int* __restrict__ status_flags) {
     const int l = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
     const int A = lv.num_anchors, W = lv.w[l];
@@ -214,12 +214,23 @@ __global__ __launch_bounds__(SEL_THREADS) void rpn_select_kernel(SelLevels lv, c
         const float sx = (float)(cell % W) * fstride, sy = (float)(cell / W) * fstride;
         const float* ca = cell_anchors + ((long long)l * A + a) * 4;
         const float ax1 = sx + ca[0], ay1 = sy + ca[1], ax2 = sx + ca[2], ay2 = sy + ca[3];
-        // [d2] Box2BoxTransformLinear(normalize_by_size=True).apply_deltas
-        const float cx = 0.5f * (ax1 + ax2), cy = 0.5f * (ay1 + ay2);
         const float aw = ax2 - ax1, ah = ay2 - ay1;
-        const float dl_ = fmaxf(d.x, 0.f) * aw, dt_ = fmaxf(d.y, 0.f) * ah, dr_ = fmaxf(d.z, 0.f) * aw, db_ = fmaxf(d.w, 0.f) * ah;
-        float x1 = cx - dl_, y1 = cy - dt_, x2 = cx + dr_, y2 = cy + db_;
-        // relu(NaN) must stay NaN like torch's: fmaxf drops NaN, so test the raw deltas too
+        float x1, y1, x2, y2;
+        if (decode_mode == 0) {
+            // [d2] Box2BoxTransformLinear(normalize_by_size=True).apply_deltas (the CF-RPN, classification_free_rpn.py:607)
+            const float cx = 0.5f * (ax1 + ax2), cy = 0.5f * (ay1 + ay2);
+            const float dl_ = fmaxf(d.x, 0.f) * aw, dt_ = fmaxf(d.y, 0.f) * ah, dr_ = fmaxf(d.z, 0.f) * aw, db_ = fmaxf(d.w, 0.f) * ah;
+            x1 = cx - dl_; y1 = cy - dt_; x2 = cx + dr_; y2 = cy + db_;
+        } else {
+            // [d2] Box2BoxTransform(weights).apply_deltas (the stock RPN of Base-RCNN-FPN.yaml: weights 1,1,1,1): dw, dh clamped
+            // from above at log(1000/16)
+            const float cx = ax1 + 0.5f * aw, cy = ay1 + 0.5f * ah;
+            const float kClamp = 4.135166556742356f;
+            const float dx = d.x / rw.x, dy = d.y / rw.y, dw = fminf(d.z / rw.z, kClamp), dh = fminf(d.w / rw.w, kClamp);
+            const float pcx = dx * aw + cx, pcy = dy * ah + cy, pw = expf(dw) * aw, ph = expf(dh) * ah;
+            x1 = pcx - 0.5f * pw; y1 = pcy - 0.5f * ph; x2 = pcx + 0.5f * pw; y2 = pcy + 0.5f * ph;
+        }
+        // relu(NaN) / clamp(NaN) must stay NaN like torch's: fmaxf / fminf drop NaN, so test the raw deltas too
         const bool dnan = (d.x != d.x) || (d.y != d.y) || (d.z != d.z) || (d.w != d.w);
         const bool valid = osr_finite(x1) && osr_finite(y1) && osr_finite(x2) && osr_finite(y2) && osr_finite(s) && !dnan;
         bad |= !valid;
@@ -240,7 +251,8 @@ __global__ __launch_bounds__(SEL_THREADS) void rpn_compact_kernel(int cap, const
                                                                   const float* __restrict__ st_score, const int* __restrict__ st_src,
                                                                   const int* __restrict__ st_flag, float* __restrict__ boxes,
                                                                   float* __restrict__ scores, int* __restrict__ src_index,
-                                                                  int* __restrict__ batch_idx, int* __restrict__ counts) {
+                                                                  int* __restrict__ batch_idx, int* __restrict__ counts, SelLevels lv,
+                                                                  int* __restrict__ level_out) {
     const int img = blockIdx.x, tid = threadIdx.x;
     __shared__ int s_scan[32];
     const long long base = (long long)img * cap;
@@ -255,6 +267,11 @@ __global__ __launch_bounds__(SEL_THREADS) void rpn_compact_kernel(int cap, const
             scores[base + pos] = st_score[base + i];
             src_index[base + pos] = st_src[base + i];
             batch_idx[base + pos] = img;
+            if (level_out) {  // slot i of the staging array belongs to the level whose [koff, koff + klevel) holds it
+                int l = 0;
+                while (l + 1 < lv.num_levels && i >= lv.koff[l + 1]) ++l;
+                level_out[base + pos] = l;
+            }
         }
         running += tot;
     }
@@ -263,6 +280,7 @@ __global__ __launch_bounds__(SEL_THREADS) void rpn_compact_kernel(int cap, const
         scores[base + i] = 0.f;
         src_index[base + i] = -1;
         batch_idx[base + i] = -1;
+        if (level_out) level_out[base + i] = -1;
     }
     if (tid == 0) counts[img] = running;
 }
@@ -300,15 +318,18 @@ extern "C" int64_t osr_rpn_select_workspace_bytes(const osr_rpn_levels* lv, int3
     return (int64_t)n * s.cap * (4 * 4 + 4 + 4 + 4);
 }
 
-extern "C" osr_status osr_rpn_select(const osr_rpn_levels* lv, const float* cell_anchors, const float* ctr, const float* deltas,
-                                     int32_t n, const int32_t* image_hw, int32_t pre_nms_topk, float min_box_size, float* boxes,
-                                     float* scores, int32_t* src_index, int32_t* batch_idx, int32_t* counts, int32_t* status_flags,
-                                     void* workspace, int64_t workspace_bytes, void* stream) {
+extern "C" osr_status osr_rpn_select_ex(const osr_rpn_levels* lv, const float* cell_anchors, const float* ctr, const float* deltas,
+                                        int32_t n, const int32_t* image_hw, int32_t pre_nms_topk, float min_box_size, int32_t decode_mode,
+                                        const float reg_weights[4], float* boxes, float* scores, int32_t* src_index, int32_t* batch_idx,
+                                        int32_t* level_out, int32_t* counts, int32_t* status_flags, void* workspace, int64_t workspace_bytes,
+                                        void* stream) {
     SelLevels s;
     OSR_REQUIRE(fill_levels(lv, pre_nms_topk, &s), OSR_ERR_INVALID_ARG, "osr_rpn_select: bad level table / topk (1..%d)", SEL_MAXK);
     OSR_REQUIRE(cell_anchors && ctr && deltas && image_hw && boxes && scores && src_index && batch_idx && counts && status_flags && workspace,
                 OSR_ERR_INVALID_ARG, "osr_rpn_select: null pointer");
     OSR_REQUIRE(n >= 1 && n <= 65535, OSR_ERR_INVALID_ARG, "osr_rpn_select: n out of range");
+    OSR_REQUIRE(decode_mode == 0 || (decode_mode == 1 && reg_weights && reg_weights[0] > 0.f && reg_weights[1] > 0.f && reg_weights[2] > 0.f && reg_weights[3] > 0.f),
+                OSR_ERR_INVALID_ARG, "osr_rpn_select: decode_mode 0 (ltrb) or 1 (Box2BoxTransform with positive weights)");
     const int64_t need = (int64_t)n * s.cap * 28;
     OSR_REQUIRE(workspace_bytes >= need, OSR_ERR_WORKSPACE, "osr_rpn_select: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
     OSR_REQUIRE(((uintptr_t)workspace & 15) == 0, OSR_ERR_INVALID_ARG, "osr_rpn_select: workspace must be 16-byte aligned");
@@ -319,11 +340,20 @@ extern "C" osr_status osr_rpn_select(const osr_rpn_levels* lv, const float* cell
     int* st_flag = (int*)(ws + (int64_t)n * s.cap * 24);
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(status_flags, 0, sizeof(int32_t), st) != hipSuccess) { osr_set_error("osr_rpn_select: memset failed"); return OSR_ERR_LAUNCH; }
+    const float4 rw = decode_mode == 1 ? make_float4(reg_weights[0], reg_weights[1], reg_weights[2], reg_weights[3]) : make_float4(1.f, 1.f, 1.f, 1.f);
     hipLaunchKernelGGL(rpn_select_kernel, dim3(s.num_levels, n), dim3(SEL_THREADS), 0, st, s, cell_anchors, ctr, deltas, n, image_hw,
-                       min_box_size, st_box, st_score, st_src, st_flag, status_flags);
+                       min_box_size, decode_mode, rw, st_box, st_score, st_src, st_flag, status_flags);
     OSR_CHECK_LAUNCH("osr_rpn_select(select)");
     hipLaunchKernelGGL(rpn_compact_kernel, dim3(n), dim3(SEL_THREADS), 0, st, s.cap, st_box, st_score, st_src, st_flag, boxes, scores,
-                       src_index, batch_idx, counts);
+                       src_index, batch_idx, counts, s, level_out);
     OSR_CHECK_LAUNCH("osr_rpn_select(compact)");
     return OSR_OK;
+}
+
+extern "C" osr_status osr_rpn_select(const osr_rpn_levels* lv, const float* cell_anchors, const float* ctr, const float* deltas,
+                                     int32_t n, const int32_t* image_hw, int32_t pre_nms_topk, float min_box_size, float* boxes,
+                                     float* scores, int32_t* src_index, int32_t* batch_idx, int32_t* counts, int32_t* status_flags,
+                                     void* workspace, int64_t workspace_bytes, void* stream) {
+    return osr_rpn_select_ex(lv, cell_anchors, ctr, deltas, n, image_hw, pre_nms_topk, min_box_size, 0, nullptr, boxes, scores, src_index, batch_idx,
+                             nullptr, counts, status_flags, workspace, workspace_bytes, stream);
 }

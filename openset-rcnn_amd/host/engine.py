@@ -67,23 +67,9 @@ class OpensetRCNNEngine:
         self.dtype = dtype
         self.device = torch.device(device)
         dev = self.device
-        w: Dict[str, torch.Tensor] = {}
-        for k, v in params.items():
-            if not k.endswith(".weight") or v.dim() != 4 or k.startswith("proposal_generator.rpn_head.anchor") or \
-                    k.startswith("proposal_generator.rpn_head.centerness"):
-                continue
-            pre = k[: -len(".weight")]
-            if pre == "backbone.bottom_up.stem.conv1":
-                w[pre + ".w"] = pack_stem_weight(v, dtype).to(dev)
-            else:
-                w[pre + ".w"] = pack_conv_weight(v, dtype).to(dev)
-            w[pre + ".b"] = params[pre + ".bias"].float().contiguous().to(dev)
+        self.w = self._pack_convs(params)
         c = self.cfg
-        f32 = lambda k: params[k].float().contiguous().to(dev)  # noqa: E731
         self.has_backbone = "backbone.bottom_up.stem.conv1.weight" in params
-        self.has_rpn = "proposal_generator.rpn_head.conv.weight" in params
-        self.has_roi = "roi_heads.box_head.fc1.weight" in params
-        self.w = w
         self.class_map = None if class_map is None else class_map.to(torch.int64).to(dev)
         # training-side id_map of the GraspNet configuration (prototype_learning_network.py:80-95, softmax_classifier.py:214-229):
         # dataset class id -> index in the sorted known list, background (NUM_CLASSES) -> NUM_KNOWN, anything else -> -1
@@ -98,6 +84,29 @@ class OpensetRCNNEngine:
         self._streams = []
         self.profile = None  # set to a list to collect (name, algorithmic flops, start event, end event) per MFMA launch
         self.profile_hbm = None  # set to a list to collect (name, algorithmic bytes, start event, end event, info) of the HBM-group kernels
+        self._init_rpn(params)
+        self._init_roi_heads(params)
+
+    def _pack_convs(self, params) -> Dict[str, torch.Tensor]:
+        """Every 4-d conv weight (backbone, FPN, RPN 3x3) repacked to [cout][kh][kw][cin] in the storage dtype + its fp32 bias; the
+        1x1 output convs of the RPN heads stay fp32 matrices (handled by _init_rpn)."""
+        w: Dict[str, torch.Tensor] = {}
+        dev, dtype = self.device, self.dtype
+        for k, v in params.items():
+            if not k.endswith(".weight") or v.dim() != 4 or (k.startswith("proposal_generator.rpn_head.") and not k.startswith("proposal_generator.rpn_head.conv.")):
+                continue
+            pre = k[: -len(".weight")]
+            if pre == "backbone.bottom_up.stem.conv1":
+                w[pre + ".w"] = pack_stem_weight(v, dtype).to(dev)
+            else:
+                w[pre + ".w"] = pack_conv_weight(v, dtype).to(dev)
+            w[pre + ".b"] = params[pre + ".bias"].float().contiguous().to(dev)
+        return w
+
+    def _init_rpn(self, params) -> None:
+        dev, c = self.device, self.cfg
+        f32 = lambda k: params[k].float().contiguous().to(dev)  # noqa: E731
+        self.has_rpn = "proposal_generator.rpn_head.centerness.weight" in params
         if self.has_rpn:
             self.rpn_wd = f32("proposal_generator.rpn_head.anchor_deltas.weight").view(-1, 256)
             self.rpn_bd = f32("proposal_generator.rpn_head.anchor_deltas.bias")
@@ -105,9 +114,14 @@ class OpensetRCNNEngine:
             self.rpn_bc = f32("proposal_generator.rpn_head.centerness.bias")
             self.rpn_wtail = torch.cat((self.rpn_wd, self.rpn_wc)).contiguous()
             self.rpn_btail = torch.cat((self.rpn_bd, self.rpn_bc)).contiguous()
-            self.fuse_rpn_head = dtype != torch.float32  # (the fused head kernel is an fp16/bf16 MFMA kernel; fp32 = parity mode)
+            self.fuse_rpn_head = self.dtype != torch.float32  # (the fused head kernel is an fp16/bf16 MFMA kernel; fp32 = parity mode)
             sizes = c["anchor_sizes"]
             self.cell_anchors = torch.tensor([[[-s / 2.0, -s / 2.0, s / 2.0, s / 2.0]] for s in sizes], dtype=torch.float32, device=dev)
+
+    def _init_roi_heads(self, params) -> None:
+        dev, c, dtype = self.device, self.cfg, self.dtype
+        f32 = lambda k: params[k].float().contiguous().to(dev)  # noqa: E731
+        self.has_roi = "roi_heads.box_predictor.iou_pred.weight" in params
         if not self.has_roi:
             return
         self.fc1_w = pack_fc1_weight(params["roi_heads.box_head.fc1.weight"], 256, c["pooler_resolution"], dtype).to(dev)

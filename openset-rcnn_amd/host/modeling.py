@@ -26,6 +26,7 @@ from torch import nn
 from . import ops
 from .config import CfgNode
 from .engine import DEFAULT_CFG, OpensetRCNNEngine
+from .engine_std import StandardRCNNEngine
 from .structures import Boxes, ImageList, Instances, ShapeSpec
 from .weights import R50_BLOCKS, R50_MID, fold_frozen_bn
 
@@ -114,6 +115,7 @@ def _to_nhwc(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 class _EngineOwner(nn.Module):
     """Lazily packs this module's parameters (under canonical names) into an OpensetRCNNEngine."""
     _prefix = ""
+    _engine_cls = OpensetRCNNEngine
 
     def __init__(self):
         super().__init__()
@@ -132,7 +134,10 @@ class _EngineOwner(nn.Module):
             if dev.type != "cuda":
                 raise ops.OsrError("the model must be on the GPU (model.to('cuda')): the HIP path has no CPU fallback")
             sd = fold_frozen_bn({k: v.cpu() for k, v in sd.items()})
-            self._eng = OpensetRCNNEngine(sd, self._eng_cfg, self.kernel_dtype, str(dev), self._class_map)
+            if self._engine_cls is OpensetRCNNEngine:
+                self._eng = OpensetRCNNEngine(sd, self._eng_cfg, self.kernel_dtype, str(dev), self._class_map)
+            else:
+                self._eng = self._engine_cls(sd, self._eng_cfg, self.kernel_dtype, str(dev))
         return self._eng
 
     def refresh(self):
@@ -337,6 +342,70 @@ class ClsFreeRPN(nn.Module):
         return out, losses
 
 
+@RPN_HEAD_REGISTRY.register()
+class StandardRPNHead(_EngineOwner):
+    """[d2] StandardRPNHead (RPN.HEAD_NAME default; Base-RCNN-FPN.yaml leaves it): 3x3 conv + ReLU, `objectness_logits` 1x1 (A) and
+    `anchor_deltas` 1x1 (A*4); init N(0, 0.01), zero bias. forward(features) -> (list[(N,A,Hi,Wi)] logits, list[(N,A*4,Hi,Wi)] deltas)
+    -- [d2]'s order: logits first."""
+    _prefix = "proposal_generator.rpn_head."
+    _engine_cls = StandardRCNNEngine
+
+    def __init__(self, cfg: CfgNode, input_shape: List[ShapeSpec]):
+        super().__init__()
+        in_channels = input_shape[0].channels
+        assert len(set(s.channels for s in input_shape)) == 1, "Each level must have the same channel!"
+        assert list(cfg.MODEL.RPN.CONV_DIMS) == [-1] and in_channels == 256
+        self.num_anchors = len(cfg.MODEL.ANCHOR_GENERATOR.ASPECT_RATIOS[0]) * len(cfg.MODEL.ANCHOR_GENERATOR.SIZES[0])
+        self.conv = _Conv3x3ReLU(in_channels, in_channels)
+        self.objectness_logits = nn.Conv2d(in_channels, self.num_anchors, kernel_size=1)
+        self.anchor_deltas = nn.Conv2d(in_channels, self.num_anchors * 4, kernel_size=1)
+        for m in (self.conv, self.objectness_logits, self.anchor_deltas):
+            nn.init.normal_(m.weight, std=0.01)
+            nn.init.constant_(m.bias, 0)
+
+    def forward(self, features: List[torch.Tensor]):
+        eng = self.engine()
+        logits, deltas = [], []
+        for x in features:
+            n, _, h, w = x.shape
+            t = ops.conv2d(_to_nhwc(x, eng.dtype), eng.w["proposal_generator.rpn_head.conv.w"], eng.w["proposal_generator.rpn_head.conv.b"], 1, 1, True,
+                           out_dtype=torch.float32).view(-1, 256)
+            logits.append(ops.gemm_f32(t, eng.rpn_wo, eng.rpn_bo).view(n, h, w, -1).permute(0, 3, 1, 2))
+            deltas.append(ops.gemm_f32(t, eng.rpn_wd, eng.rpn_bd).view(n, h, w, -1).permute(0, 3, 1, 2))
+        return logits, deltas
+
+
+@PROPOSAL_GENERATOR_REGISTRY.register()
+class RPN(nn.Module):
+    """[d2] RPN (PROPOSAL_GENERATOR.NAME default, Base-RCNN-FPN.yaml:9-21), inference branch: anchors with the yaml's aspect
+    ratios, StandardRPNHead, Box2BoxTransform(RPN.BBOX_REG_WEIGHTS) decode, per-level top PRE_NMS_TOPK, NMS at RPN.NMS_THRESH per
+    level, first POST_NMS_TOPK. forward(images, features, gt_instances=None) -> (list[Instances{proposal_boxes,
+    objectness_logits}], {}). Training of the stock RPN (BCE objectness + smooth-L1 deltas) is not on the Openset hot path."""
+
+    def __init__(self, cfg: CfgNode, input_shape: Dict[str, ShapeSpec]):
+        super().__init__()
+        self.in_features = list(cfg.MODEL.RPN.IN_FEATURES)
+        shapes = [input_shape[f] for f in self.in_features]
+        self.rpn_head = RPN_HEAD_REGISTRY.get(cfg.MODEL.RPN.HEAD_NAME)(cfg, shapes)
+        self.rpn_head._eng_cfg = engine_cfg_from(cfg)
+
+    def forward(self, images: ImageList, features: Dict[str, torch.Tensor], gt_instances: Optional[List[Instances]] = None):
+        if self.training:
+            raise NotImplementedError("the stock RPN's training branch is outside the Openset hot path (SURVEY.md 8a): train ClsFreeRPN configs")
+        eng = self.rpn_head.engine()
+        feats = {k: _to_nhwc(features[k], eng.dtype) for k in self.in_features}
+        hw = torch.tensor(images.image_sizes, dtype=torch.int32, device=feats[self.in_features[0]].device)
+        sel = eng._rpn(feats, hw)
+        counts = sel["counts"].cpu().tolist()
+        out = []
+        for i, size in enumerate(images.image_sizes):
+            r = Instances(size)
+            r.proposal_boxes = Boxes(sel["boxes"][i, : counts[i]])
+            r.objectness_logits = sel["scores"][i, : counts[i]]
+            out.append(r)
+        return out, {}
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # RoI heads
 # ---------------------------------------------------------------------------------------------------------------
@@ -414,6 +483,11 @@ def engine_cfg_from(cfg: CfgNode) -> dict:
         roi_batch_size=rh.BATCH_SIZE_PER_IMAGE, roi_positive_fraction=rh.POSITIVE_FRACTION, roi_iou_threshold=float(rh.IOU_THRESHOLDS[0]),
         box_reg_weight=bh.BBOX_REG_LOSS_WEIGHT, iou_reg_weight=bh.IOU_REG_LOSS_WEIGHT, pln_alpha=cfg.MODEL.PLN.ALPHA, pln_beta=cfg.MODEL.PLN.BETA,
         pln_iou_threshold=cfg.MODEL.PLN.IOU_THRESHOLD, pln_loss_weight=cfg.MODEL.PLN.LOSS_WEIGHT, cls_loss_weight=bh.CLS_LOSS_WEIGHT,
+        # the stock detectron2 modules of Base-RCNN-FPN.yaml (BASELINE config 1; engine_std.StandardRCNNEngine)
+        anchor_ratios=tuple(float(r) for r in cfg.MODEL.ANCHOR_GENERATOR.ASPECT_RATIOS[0]), post_nms_topk_test=cfg.MODEL.RPN.POST_NMS_TOPK_TEST,
+        rpn_nms_thresh=cfg.MODEL.RPN.NMS_THRESH, rpn_bbox_reg_weights=tuple(cfg.MODEL.RPN.BBOX_REG_WEIGHTS), std_num_classes=rh.NUM_CLASSES,
+        score_thresh_test=rh.SCORE_THRESH_TEST, std_nms_thresh_test=rh.NMS_THRESH_TEST, std_detections_per_image=cfg.TEST.DETECTIONS_PER_IMAGE,
+        cls_agnostic_bbox_reg=bool(bh.CLS_AGNOSTIC_BBOX_REG),
         # checked by engine.check_supported_losses when a loss is first computed (inference never needs them)
         loss_types=dict(rpn_box=(rpn.BBOX_REG_LOSS_TYPE, float(rpn.SMOOTH_L1_BETA)), rpn_ctr=(rpn.CTR_REG_LOSS_TYPE, float(rpn.CTR_SMOOTH_L1_BETA)),
                         roi_box=(bh.BBOX_REG_LOSS_TYPE, float(bh.SMOOTH_L1_BETA)), roi_iou=(bh.IOU_REG_LOSS_TYPE, float(bh.IOU_SMOOTH_L1_BETA))),
@@ -511,6 +585,58 @@ class OpensetROIHeads(_EngineOwner):
         return out, {}
 
 
+class FastRCNNOutputLayers(nn.Module):
+    """[d2] FastRCNNOutputLayers: cls_score (K+1) and bbox_pred (4, or 4K when not class-agnostic); init std 0.01 / 0.001."""
+
+    def __init__(self, cfg: CfgNode, input_shape: ShapeSpec):
+        super().__init__()
+        k = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+        self.cls_score = nn.Linear(input_shape.channels, k + 1)
+        self.bbox_pred = nn.Linear(input_shape.channels, 4 if cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG else 4 * k)
+        nn.init.normal_(self.cls_score.weight, std=0.01)
+        nn.init.normal_(self.bbox_pred.weight, std=0.001)
+        for l in (self.cls_score, self.bbox_pred):
+            nn.init.constant_(l.bias, 0)
+
+
+@ROI_HEADS_REGISTRY.register()
+class StandardROIHeads(_EngineOwner):
+    """[d2] StandardROIHeads (Base-RCNN-FPN.yaml:22-28), box branch, inference: ROIPooler(7x7, ROIAlignV2) -> FastRCNNConvFCHead ->
+    FastRCNNOutputLayers.inference (softmax, Box2BoxTransform(10,10,5,5), SCORE_THRESH_TEST, per-class NMS_THRESH_TEST,
+    TEST.DETECTIONS_PER_IMAGE). forward(images, features, proposals, targets=None) -> (list[Instances{pred_boxes, scores,
+    pred_classes}], {})."""
+    _prefix = "roi_heads."
+    _engine_cls = StandardRCNNEngine
+
+    def __init__(self, cfg: CfgNode, input_shape: Dict[str, ShapeSpec], class_id=None):
+        super().__init__()
+        assert not cfg.MODEL.MASK_ON and not cfg.MODEL.KEYPOINT_ON, "box branch only (the Openset path has no mask / keypoint heads)"
+        self.in_features = self.box_in_features = list(cfg.MODEL.ROI_HEADS.IN_FEATURES)
+        res = cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION
+        assert cfg.MODEL.ROI_BOX_HEAD.POOLER_TYPE == "ROIAlignV2" and cfg.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO == 0
+        ch = input_shape[self.in_features[0]].channels
+        self.box_head = ROI_BOX_HEAD_REGISTRY.get(cfg.MODEL.ROI_BOX_HEAD.NAME)(cfg, ShapeSpec(channels=ch, height=res, width=res))
+        self.box_predictor = FastRCNNOutputLayers(cfg, self.box_head.output_shape)
+        self._eng_cfg = engine_cfg_from(cfg)
+        self._eng_cfg["pooler_scales"] = tuple(1.0 / input_shape[k].stride for k in self.in_features)
+
+    def forward(self, images: ImageList, features: Dict[str, torch.Tensor], proposals: List[Instances], targets=None):
+        del images
+        if self.training:
+            raise NotImplementedError("the stock ROI heads' training branch is outside the Openset hot path (SURVEY.md 8a): train OpensetROIHeads configs")
+        eng = self.engine()
+        n = len(proposals)
+        boxes, scores, bidx, counts, cap = OpensetROIHeads._pack_proposals(proposals)
+        sel = dict(boxes=boxes, scores=scores, batch_idx=bidx.view(-1), counts=counts, cap=cap)
+        hw = torch.tensor([p.image_size for p in proposals], dtype=torch.int32, device=boxes.device)
+        feats = {k: _to_nhwc(features[k], eng.dtype) for k in self.in_features}
+        res = OpensetRCNNEngine.to_instances(eng._roi_heads(feats, sel, hw), n)
+        out = []
+        for r, p in zip(res, proposals):
+            out.append(Instances(p.image_size, pred_boxes=Boxes(r["pred_boxes"]), scores=r["scores"], pred_classes=r["pred_classes"]))
+        return out, {}
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # meta architecture
 # ---------------------------------------------------------------------------------------------------------------
@@ -541,6 +667,9 @@ class GeneralizedRCNN(_EngineOwner):
         self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1), False)
         self._eng_cfg = engine_cfg_from(cfg)
         self._class_map = class_id
+        self._engine_cls = StandardRCNNEngine if isinstance(self.roi_heads, StandardROIHeads) else OpensetRCNNEngine
+        if self._engine_cls is StandardRCNNEngine:
+            self._eng_cfg["pooler_scales"] = self.roi_heads._eng_cfg["pooler_scales"]
         self._trainer = None
         self._hook: Optional[torch.Tensor] = None
         self.sampler_generator = torch.Generator().manual_seed(max(int(cfg.SEED), 0))  # uniform keys replacing torch.randperm (H6)

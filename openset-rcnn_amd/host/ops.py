@@ -252,8 +252,12 @@ def make_rpn_levels(shapes: Sequence[Tuple[int, int]], strides: Sequence[int], n
 
 
 def rpn_select(lv: RpnLevels, cell_anchors: torch.Tensor, ctr: torch.Tensor, deltas: torch.Tensor, n: int,
-               image_hw: torch.Tensor, pre_nms_topk: int, min_box_size: float = 0.0):
-    """ctr/deltas: level-major concatenation (see osr.h). Returns dict of padded outputs."""
+               image_hw: torch.Tensor, pre_nms_topk: int, min_box_size: float = 0.0, b2b_weights: Optional[Sequence[float]] = None):
+    """ctr/deltas: level-major concatenation (see osr.h). Returns dict of padded outputs. b2b_weights: decode with
+    [d2] Box2BoxTransform(weights) instead of the CF-RPN's ltrb rule and also return the pyramid level of every slot (the stock
+    RPN of Base-RCNN-FPN.yaml, osr_rpn_select_ex)."""
+    if b2b_weights is not None:
+        return _rpn_select_ex(lv, cell_anchors, ctr, deltas, n, image_hw, pre_nms_topk, min_box_size, b2b_weights)
     lib = _lib.load()
     _need(cell_anchors, torch.float32, "cell_anchors"); _need(ctr, torch.float32, "ctr"); _need(deltas, torch.float32, "deltas")
     _need(image_hw, torch.int32, "image_hw")
@@ -272,6 +276,50 @@ def rpn_select(lv: RpnLevels, cell_anchors: torch.Tensor, ctr: torch.Tensor, del
     check(lib.osr_rpn_select(C.byref(lv), _p(cell_anchors), _p(ctr), _p(deltas), n, _p(image_hw), pre_nms_topk, float(min_box_size),
                              _p(boxes), _p(scores), _p(src), _p(bidx), _p(counts), _p(flags), _p(ws), wsb, _stream()), "osr_rpn_select")
     return dict(boxes=boxes, scores=scores, src_index=src, batch_idx=bidx, counts=counts, status_flags=flags, cap=cap)
+
+
+def _rpn_select_ex(lv, cell_anchors, ctr, deltas, n, image_hw, pre_nms_topk, min_box_size, weights):
+    lib = _lib.load()
+    _need(cell_anchors, torch.float32, "cell_anchors"); _need(ctr, torch.float32, "scores"); _need(deltas, torch.float32, "deltas")
+    _need(image_hw, torch.int32, "image_hw")
+    cap = lib.osr_rpn_select_capacity(C.byref(lv), pre_nms_topk)
+    if cap < 0:
+        check(cap, "osr_rpn_select_capacity")
+    wsb = lib.osr_rpn_select_workspace_bytes(C.byref(lv), n, pre_nms_topk)
+    dev = ctr.device
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    boxes = torch.empty((n, cap, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((n, cap), dtype=torch.float32, device=dev)
+    src = torch.empty((n, cap), dtype=torch.int32, device=dev)
+    level = torch.empty((n, cap), dtype=torch.int32, device=dev)
+    bidx = torch.empty((n * cap,), dtype=torch.int32, device=dev)
+    counts = torch.empty((n,), dtype=torch.int32, device=dev)
+    flags = torch.zeros((1,), dtype=torch.int32, device=dev)
+    rw = (C.c_float * 4)(*[float(v) for v in weights])
+    check(lib.osr_rpn_select_ex(C.byref(lv), _p(cell_anchors), _p(ctr), _p(deltas), n, _p(image_hw), pre_nms_topk, float(min_box_size), 1, rw,
+                                _p(boxes), _p(scores), _p(src), _p(bidx), _p(level), _p(counts), _p(flags), _p(ws), wsb, _stream()), "osr_rpn_select_ex")
+    return dict(boxes=boxes, scores=scores, src_index=src, batch_idx=bidx, level=level, counts=counts, status_flags=flags, cap=cap)
+
+
+def fastrcnn_candidates(logits, deltas, prop_boxes, prop_count, image_hw, num_classes: int, reg_weights=(10.0, 10.0, 5.0, 5.0),
+                        score_thresh: float = 0.05):
+    """[d2] fast_rcnn_inference_single_image before its NMS. logits (n*rows, K+1), deltas (n*rows, K*4 or 4), prop_boxes (n,rows,4)."""
+    lib = _lib.load()
+    _need(logits, torch.float32, "logits"); _need(deltas, torch.float32, "deltas"); _need(prop_boxes, torch.float32, "prop_boxes")
+    _need(prop_count, torch.int32, "prop_count"); _need(image_hw, torch.int32, "image_hw")
+    n, rows = prop_boxes.shape[0], prop_boxes.shape[1]
+    kbox = deltas.shape[1] // 4
+    if logits.shape != (n * rows, num_classes + 1) or deltas.shape[0] != n * rows or kbox not in (1, num_classes):
+        raise OsrError(f"fastrcnn_candidates: logits {tuple(logits.shape)} / deltas {tuple(deltas.shape)} do not fit {n} x {rows} rows, {num_classes} classes")
+    dev, cap = logits.device, rows * num_classes
+    o = dict(boxes=torch.empty((n, cap, 4), dtype=torch.float32, device=dev), scores=torch.empty((n, cap), dtype=torch.float32, device=dev),
+             cls=torch.empty((n, cap), dtype=torch.int32, device=dev), row=torch.empty((n, cap), dtype=torch.int32, device=dev),
+             count=torch.empty((n,), dtype=torch.int32, device=dev), cap=cap)
+    rw = (C.c_float * 4)(*[float(v) for v in reg_weights])
+    check(lib.osr_fastrcnn_candidates(_p(logits), _p(deltas), num_classes, kbox, _p(prop_boxes), _p(prop_count), n, rows, _p(image_hw), rw,
+                                      float(score_thresh), _p(o["boxes"]), _p(o["scores"]), _p(o["cls"]), _p(o["row"]), _p(o["count"]), _stream()),
+          "osr_fastrcnn_candidates")
+    return o
 
 
 def roi_align(feats: List[torch.Tensor], scales: Sequence[float], boxes: torch.Tensor, batch_idx: torch.Tensor,

@@ -127,3 +127,28 @@ def with_known_unknown_mix(params: Dict[str, torch.Tensor], embeddings: torch.Te
     c = q / math.sqrt(1.0 / (cos_thr * cos_thr) - 1.0)
     out["roi_heads.dml.encoder.bias"] = (c * ph).contiguous()
     return out
+
+
+def random_standard_params(seed: int = 0, num_classes: int = 80, num_anchors: int = 3, cls_agnostic: bool = True, fc_dim: int = 1024) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic parameters (BN-folded backbone of random_params + the stock detectron2 heads of Base-RCNN-FPN.yaml):
+    StandardRPNHead (conv, objectness_logits (A), anchor_deltas (4A)) and FastRCNNOutputLayers (cls_score (K+1), bbox_pred (4 or
+    4K)), scaled so that logits and deltas spread (the [d2] initialisers, std 0.01 / 0.001, give near-constant outputs and
+    degenerate top-k / NMS ties)."""
+    p = {k: v for k, v in random_params(seed).items() if k.startswith("backbone.")}
+    g = torch.Generator().manual_seed(seed + 2000)
+    p["proposal_generator.rpn_head.conv.weight"] = torch.randn(256, 256, 3, 3, generator=g) * 0.02
+    p["proposal_generator.rpn_head.conv.bias"] = torch.zeros(256)
+    p["proposal_generator.rpn_head.objectness_logits.weight"] = torch.randn(num_anchors, 256, 1, 1, generator=g) * 0.5
+    p["proposal_generator.rpn_head.objectness_logits.bias"] = torch.zeros(num_anchors)
+    p["proposal_generator.rpn_head.anchor_deltas.weight"] = torch.randn(num_anchors * 4, 256, 1, 1, generator=g) * 0.1
+    p["proposal_generator.rpn_head.anchor_deltas.bias"] = torch.zeros(num_anchors * 4)
+    in_dim = 256 * 49
+    p["roi_heads.box_head.fc1.weight"] = torch.randn(fc_dim, in_dim, generator=g) * math.sqrt(2.0 / in_dim)
+    p["roi_heads.box_head.fc1.bias"] = torch.randn(fc_dim, generator=g) * 0.02
+    p["roi_heads.box_head.fc2.weight"] = torch.randn(fc_dim, fc_dim, generator=g) * math.sqrt(2.0 / fc_dim)
+    p["roi_heads.box_head.fc2.bias"] = torch.randn(fc_dim, generator=g) * 0.02
+    p["roi_heads.box_predictor.cls_score.weight"] = torch.randn(num_classes + 1, fc_dim, generator=g) * 0.15
+    p["roi_heads.box_predictor.cls_score.bias"] = torch.zeros(num_classes + 1)
+    p["roi_heads.box_predictor.bbox_pred.weight"] = torch.randn(4 if cls_agnostic else 4 * num_classes, fc_dim, generator=g) * 0.03
+    p["roi_heads.box_predictor.bbox_pred.bias"] = torch.zeros(4 if cls_agnostic else 4 * num_classes)
+    return p

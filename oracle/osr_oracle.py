@@ -934,3 +934,126 @@ def softmax_ce_loss(logits, gt_classes, num_classes=81, num_known=20, weight=0.9
     t = id_map[gt_classes]
     keep = t >= 0
     return weight * F.cross_entropy(logits[keep], t[keep], reduction="mean") if bool(keep.any()) else logits.sum() * 0
+
+
+# --------------------------------------------------------------------------------------
+# BASELINE config 1: the stock detectron2 modules /root/reference/configs/Base-RCNN-FPN.yaml names on its own
+# (PROPOSAL_GENERATOR "RPN" + "StandardRPNHead", ROI_HEADS "StandardROIHeads" + FastRCNNOutputLayers). None of their code is in
+# /root/reference: everything below restates detectron2 v0.6's published algorithms [d2-mem] at the yaml's call sites
+# (Base-RCNN-FPN.yaml:9-33), with the same tie rule as the rest of this file.
+# --------------------------------------------------------------------------------------
+
+BASE_RCNN_CFG = dict(
+    anchor_sizes=(32, 64, 128, 256, 512), anchor_ratios=(0.5, 1.0, 2.0), pre_nms_topk_test=1000, post_nms_topk_test=1000,
+    rpn_nms_thresh=0.7, rpn_bbox_reg_weights=(1.0, 1.0, 1.0, 1.0), min_box_size=0.0, num_classes=80, bbox_reg_weights=(10.0, 10.0, 5.0, 5.0),
+    score_thresh_test=0.05, nms_thresh_test=0.5, detections_per_image=100,
+)
+
+
+def b2b_apply_deltas_multi(deltas: torch.Tensor, boxes: torch.Tensor, weights=(10.0, 10.0, 5.0, 5.0)) -> torch.Tensor:
+    """[d2-mem] Box2BoxTransform.apply_deltas for (R, k*4) deltas (class-specific regression): the same arithmetic as
+    b2b_apply_deltas for each of the k groups of 4, output (R, k*4)."""
+    r, k4 = deltas.shape
+    out = b2b_apply_deltas(deltas.reshape(-1, 4), boxes.unsqueeze(1).expand(r, k4 // 4, 4).reshape(-1, 4), weights)
+    return out.view(r, k4)
+
+
+def standard_rpn_head(feat: torch.Tensor, p: Dict[str, torch.Tensor], prefix="proposal_generator.rpn_head"):
+    """[d2-mem] StandardRPNHead.forward for one level: t = relu(conv3x3(x)); objectness_logits = conv1x1(t) (A channels),
+    anchor_deltas = conv1x1(t) (A*4 channels). Returns (deltas (N,4A,H,W), logits (N,A,H,W))."""
+    t = F.relu(F.conv2d(feat, p[prefix + ".conv.weight"], p[prefix + ".conv.bias"], padding=1))
+    return (F.conv2d(t, p[prefix + ".anchor_deltas.weight"], p[prefix + ".anchor_deltas.bias"]),
+            F.conv2d(t, p[prefix + ".objectness_logits.weight"], p[prefix + ".objectness_logits.bias"]))
+
+
+def standard_find_top_rpn_proposals(proposals: List[torch.Tensor], logits: List[torch.Tensor], image_sizes, nms_thresh: float,
+                                    pre_nms_topk: int, post_nms_topk: int, min_box_size: float = 0.0, training: bool = False):
+    """[d2-mem] detectron2.modeling.proposal_generator.proposal_utils.find_top_rpn_proposals: per level top-k of the objectness
+    logits, concatenation with level ids, per image: finite filter, clip, drop empty boxes, batched NMS with the LEVEL as the
+    category (thr 0.7), first post_nms_topk of the score-descending keep list. Returns per image (boxes, logits, level ids)."""
+    n_img = len(image_sizes)
+    tk_s, tk_b, lvl = [], [], []
+    for level_id, (prop_l, sc_l) in enumerate(zip(proposals, logits)):
+        k = min(sc_l.shape[1], pre_nms_topk)
+        v, idx = stable_topk(sc_l, k)
+        tk_s.append(v)
+        tk_b.append(prop_l[torch.arange(n_img)[:, None], idx])
+        lvl.append(torch.full((k,), level_id, dtype=torch.int64))
+    tk_s, tk_b, lvl = torch.cat(tk_s, 1), torch.cat(tk_b, 1), torch.cat(lvl)
+    results = []
+    for n, size in enumerate(image_sizes):
+        b, s, lv = tk_b[n], tk_s[n], lvl
+        valid = torch.isfinite(b).all(dim=1) & torch.isfinite(s)
+        if not bool(valid.all()):
+            if training:
+                raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")
+            b, s, lv = b[valid], s[valid], lv[valid]
+        b = box_clip(b, size)
+        keep = box_nonempty(b, min_box_size)
+        b, s, lv = b[keep], s[keep], lv[keep]
+        kept = torch.from_numpy(batched_nms_ref(b.numpy(), s.numpy(), lv.numpy(), nms_thresh))[:post_nms_topk]
+        results.append((b[kept], s[kept], lv[kept]))
+    return results
+
+
+def standard_rpn_inference(feats: Dict[str, torch.Tensor], image_sizes, p, cfg=BASE_RCNN_CFG):
+    """[d2-mem] RPN.forward, inference branch: anchors (3 aspect ratios per cell), StandardRPNHead, (N,A*4,H,W)->(N,H*W*A,4) /
+    (N,A,H,W)->(N,H*W*A) flattening, Box2BoxTransform(weights 1,1,1,1) decode, find_top_rpn_proposals."""
+    fl = [feats[k] for k in ("p2", "p3", "p4", "p5", "p6")]
+    anchors = anchor_grid([tuple(f.shape[-2:]) for f in fl], sizes=cfg["anchor_sizes"], ratios=cfg["anchor_ratios"])
+    ds, ls = [], []
+    for f in fl:
+        d, l = standard_rpn_head(f, p)
+        ds.append(d)
+        ls.append(l)
+    ds, ls = flatten_head_outputs(ds, ls)
+    n = ds[0].shape[0]
+    props = [b2b_apply_deltas(d.reshape(-1, 4), a.unsqueeze(0).expand(n, -1, -1).reshape(-1, 4), cfg["rpn_bbox_reg_weights"]).view(n, -1, 4)
+             for d, a in zip(ds, anchors)]
+    res = standard_find_top_rpn_proposals(props, ls, image_sizes, cfg["rpn_nms_thresh"], cfg["pre_nms_topk_test"], cfg["post_nms_topk_test"],
+                                          cfg["min_box_size"])
+    return res, dict(deltas=ds, logits=ls, anchors=anchors, decoded=props)
+
+
+def fast_rcnn_output_inference(x: torch.Tensor, proposals: torch.Tensor, image_size, p, cfg=BASE_RCNN_CFG, prefix="roi_heads.box_predictor"):
+    """[d2-mem] FastRCNNOutputLayers.inference for one image: scores = cls_score(x) (K+1 logits), deltas = bbox_pred(x) (K*4,
+    class-specific), predict_probs = softmax, predict_boxes = Box2BoxTransform(10,10,5,5).apply_deltas, then
+    fast_rcnn_inference_single_image: rows with a non-finite box or score dropped, background column dropped, boxes clipped,
+    (row, class) pairs with score > SCORE_THRESH_TEST kept, per-class NMS (0.5), first DETECTIONS_PER_IMAGE of the keep list.
+    Returns (boxes, scores, classes, (row, class) of every kept detection)."""
+    logits = F.linear(x, p[prefix + ".cls_score.weight"], p[prefix + ".cls_score.bias"])
+    deltas = F.linear(x, p[prefix + ".bbox_pred.weight"], p[prefix + ".bbox_pred.bias"])
+    probs = F.softmax(logits, dim=-1)
+    boxes = b2b_apply_deltas_multi(deltas, proposals, cfg["bbox_reg_weights"])
+    valid = torch.isfinite(boxes).all(dim=1) & torch.isfinite(probs).all(dim=1)
+    rows = torch.arange(boxes.shape[0])
+    if not bool(valid.all()):
+        boxes, probs, rows = boxes[valid], probs[valid], rows[valid]
+    probs = probs[:, :-1]
+    k = boxes.shape[1] // 4
+    boxes = box_clip(boxes.reshape(-1, 4), image_size).view(-1, k, 4)
+    mask = probs > cfg["score_thresh_test"]
+    inds = mask.nonzero()
+    b = boxes[inds[:, 0], inds[:, 1]] if k > 1 else boxes[inds[:, 0], 0]
+    s = probs[mask]
+    keep = torch.from_numpy(batched_nms_ref(b.numpy(), s.numpy(), inds[:, 1].numpy(), cfg["nms_thresh_test"]))[: cfg["detections_per_image"]]
+    return b[keep], s[keep], inds[keep, 1], torch.stack((rows[inds[keep, 0]], inds[keep, 1]), dim=1)
+
+
+def standard_roi_heads_inference(feats, proposals, image_sizes, p, cfg=BASE_RCNN_CFG, roi_align_fn=None):
+    """[d2-mem] StandardROIHeads._forward_box, inference branch: ROIPooler (7x7, ROIAlignV2) -> FastRCNNConvFCHead ->
+    FastRCNNOutputLayers.inference. ``proposals``: per image (boxes, logits, ...)."""
+    fl = [feats[k] for k in ("p2", "p3", "p4", "p5")]
+    x = box_head(roi_pooler_ref(fl, [pr[0] for pr in proposals], roi_align_fn=roi_align_fn), p)
+    counts = [len(pr[0]) for pr in proposals]
+    return [fast_rcnn_output_inference(xi, pr[0], size, p, cfg) for xi, pr, size in zip(x.split(counts), proposals, image_sizes)], x
+
+
+def standard_detector_inference(images: Sequence[torch.Tensor], params, cfg=BASE_RCNN_CFG, roi_align_fn=None, image_sizes=None):
+    """[d2-mem] GeneralizedRCNN.inference for Base-RCNN-FPN.yaml (no final rescale: inputs are at network resolution)."""
+    batch, sizes = preprocess_images(images)
+    sizes = image_sizes or sizes
+    feats = resnet_fpn_forward(batch, params)
+    props, _ = standard_rpn_inference(feats, sizes, params, cfg)
+    res, _ = standard_roi_heads_inference(feats, props, sizes, params, cfg, roi_align_fn)
+    return res, props

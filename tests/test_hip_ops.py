@@ -332,6 +332,47 @@ def test_roi_align_extreme_aspect_footprints(ops):
     assert_close(out2, CO.roi_align(f2, torch.cat((z.float().unsqueeze(1), b2), 1), 0.25), rtol=1e-4, atol=1e-5, name="roi_align overflow")
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16], ids=["f32", "f16"])
+def test_roi_align_row_streaming_kernel_every_path(ops, dt):
+    """The 256-channel kernel (LDS-DMA row streaming, osr_roi_align.hip: roi_align_rows_kernel): sliding window over the bin rows,
+    the fixed-window passes for boxes flatter than a few pixels, rows longer than one / two / many 16-pixel chunks, bins narrower
+    than a pixel on the x axis, footprints clipped by every border, degenerate boxes, and the per-sample loop on table overflow."""
+    gg = g(29)
+    f = torch.randn(2, 256, 60, 500, generator=gg).to(dt)
+    boxes = torch.tensor([
+        [4.0, 100.0, 1300.0, 112.0],     # 324 x 3 px footprint: 21 chunks per row, rows in all seven bin rows -> fixed windows
+        [300.0, 2.0, 330.0, 230.0],      # 7 x 57 px: one short chunk per row, tall bins, sliding window
+        [10.0, 10.0, 700.0, 200.0],      # big box: 25-column bins, several chunks per row
+        [50.3, 60.2, 51.1, 61.0],        # a fifth of a pixel: every bin samples the same pixels on both axes
+        [-40.0, -30.0, 90.0, 50.0],      # crosses the top-left border (clamped samples, samples below -1 dropped)
+        [1900.0, 200.0, 2100.0, 260.0],  # crosses the bottom-right border
+        [0.0, 0.0, 2000.0, 240.0],       # the whole map: 72-column bins -> table overflow -> per-sample loop
+        [600.0, 100.0, 640.0, 103.0],    # 10 x 0.75 px
+        [700.0, 50.0, 764.0, 114.0],     # 16 x 16 px: exactly one chunk per row
+        [701.0, 51.0, 769.5, 113.0],     # 17 columns: a second chunk holding one pixel
+        [100.0, 100.0, 100.0, 100.0],    # zero area
+        [5000.0, 5000.0, 5100.0, 5100.0],  # entirely outside: every sample invalid -> zeros
+        [820.0, 20.0, 1020.0, 26.0],     # 50 x 1.5 px: three passes over two rows
+    ])
+    bidx = torch.tensor([0, 1, 0, 1, 0, 1, 1, 0, 1, 0, 1, 0, 1], dtype=torch.int32)
+    gb = torch.rand(40, 4, generator=gg)
+    ctr = gb[:, :2] * torch.tensor([2000.0, 240.0])
+    size = torch.exp(gb[:, 2:] * 5.5)
+    boxes = torch.cat((boxes, torch.cat((ctr - size / 2, ctr + size / 2), dim=1)))
+    bidx = torch.cat((bidx, torch.randint(0, 2, (40,), generator=gg, dtype=torch.int32)))
+    bidx[20] = -1
+    for odt in ((torch.float32,) if dt == torch.float32 else (torch.float32, torch.float16)):
+        out = ops.roi_align([nhwc(f).to(DEV)], (0.25,), boxes.to(DEV), bidx.to(DEV), 7, odt, min_level=2).cpu().float().permute(0, 3, 1, 2)
+        valid = bidx >= 0
+        ref = torch.zeros_like(out)
+        ref[valid] = CO.roi_align(f.float(), torch.cat((bidx[valid].float().unsqueeze(1), boxes[valid]), 1), 0.25)
+        assert float(out[20].abs().max()) == 0.0 and float(out[11].abs().max()) == 0.0
+        if odt == torch.float32:
+            assert_close(out, ref, rtol=1e-4, atol=1e-5, name="roi_align rows")
+        else:
+            assert_close(out, ref, rtol=2.0 ** -10, atol=2e-3, name="roi_align rows f16 out")
+
+
 def test_roi_align_linear_ramp_is_exact(ops):
     ys, xs = torch.meshgrid(torch.arange(50.0), torch.arange(84.0), indexing="ij")
     f = (0.5 * xs - 0.25 * ys + 3.0).view(1, 1, 50, 84).expand(1, 4, 50, 84).contiguous()

@@ -198,11 +198,14 @@ def test_losses_forward_through_the_mirror(osr, tmp_path):
         inst.gt_boxes = Boxes(torch.tensor([[20.0, 30.0, 120.0, 150.0], [150.0, 40.0, 280.0, 190.0]])[: 2 - i])
         inst.gt_classes = torch.tensor([3, 17])[: 2 - i]
         inputs.append({"image": torch.randint(0, 256, (3, 200, 300), generator=g, dtype=torch.uint8), "instances": inst})
-    with pytest.raises(NotImplementedError):
-        model(inputs)  # gradients are not available: the training-mode call must not silently return detached losses
+    model.sampler_generator.manual_seed(9)
+    ld = model(inputs)  # training mode: the loss dict of train.py:135; its sum's .backward() runs the explicit HIP backward
+    assert all(v.grad_fn is not None for v in ld.values())
     l1 = model.losses_forward(inputs, torch.Generator().manual_seed(9))
     l2 = model.losses_forward(inputs, torch.Generator().manual_seed(9))
-    assert set(l1) == {"loss_rpn_loc", "loss_rpn_ctr", "loss_box_reg", "loss_iou", "loss_dml", "loss_cls"}
+    assert set(l1) == {"loss_rpn_loc", "loss_rpn_ctr", "loss_box_reg", "loss_iou", "loss_dml", "loss_cls"} == set(ld)
+    for k in l1:  # same keys, same sampled sets (the trainer's unfused RPN head gives the fused head's values)
+        assert float(ld[k]) == pytest.approx(float(l1[k]), rel=1e-5, abs=1e-7), k
     for k in l1:
         assert torch.isfinite(l1[k]).all() and float(l1[k]) > 0 and torch.equal(l1[k], l2[k]), k  # reproducible bit for bit
 

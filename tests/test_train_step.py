@@ -3,7 +3,8 @@ forward, evaluated on the SAME sampled anchors / proposals (taken from the HIP r
 sets), and a few SGD iterations on a fixed batch.
 
 Tolerance: the HIP path stores activations and activation gradients in fp16 (loss-scaled) and runs ~50 layers deep; the oracle is
-fp32 with fp16-rounded weights and activations. Per parameter tensor: cosine similarity >= 0.98 and norm within 6 %."""
+fp32 with fp16-rounded weights and activations. Per parameter tensor: cosine similarity >= 0.999 and norm within 1 % (measured:
+>= 0.9997 and within 0.4 %)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -130,7 +131,7 @@ def test_gradients_match_autograd_on_the_same_samples(setup):
         cos = float(F.cosine_similarity(got.flatten(), want.flatten(), dim=0))
         ratio = float(got.norm() / want.norm().clamp(min=1e-20))
         report.append(f"{k:48s} cos {cos:.4f}  |got|/|ref| {ratio:.3f}  |ref| {float(want.norm()):.3e}")
-        if not (cos >= 0.98 and 0.94 <= ratio <= 1.06):
+        if not (cos >= 0.999 and 0.99 <= ratio <= 1.01):  # measured: cos >= 0.9997, norms within 0.4 %
             bad.append(report[-1])
     print("\n".join(report))
     assert not bad, "gradient mismatch:\n" + "\n".join(bad)
