@@ -74,11 +74,11 @@ def test_cell_anchors_and_oracle_known_answers(osr):
     (bx, sc, lv), = O.standard_find_top_rpn_proposals(props, logits, [(100, 100)], 0.7, 1000, 1000)
     assert sc.tolist() == [2.0, 0.5] and lv.tolist() == [0, 1]
     # class-agnostic deltas, two rows: softmax + threshold + per-class NMS; the background column never becomes a detection
-    p = {"roi_heads.box_predictor.cls_score.weight": torch.zeros(3, 4), "roi_heads.box_predictor.cls_score.bias": torch.tensor([2.0, 0.0, 5.0]),
+    p = {"roi_heads.box_predictor.cls_score.weight": torch.zeros(3, 4), "roi_heads.box_predictor.cls_score.bias": torch.tensor([3.0, 0.0, 4.0]),
          "roi_heads.box_predictor.bbox_pred.weight": torch.zeros(4, 4), "roi_heads.box_predictor.bbox_pred.bias": torch.zeros(4)}
     cfg = dict(O.BASE_RCNN_CFG, num_classes=2)
     bb, ss, cc, rc = O.fast_rcnn_output_inference(torch.zeros(2, 4), torch.tensor([[0.0, 0.0, 10.0, 10.0], [1.0, 0.0, 10.0, 10.0]]), (50, 50), p, cfg)
-    assert cc.tolist() == [0] and rc.tolist() == [[0, 0]] and float(ss[0]) == pytest.approx(float(F.softmax(torch.tensor([2.0, 0.0, 5.0]), 0)[0]))
+    assert cc.tolist() == [0] and rc.tolist() == [[0, 0]] and float(ss[0]) == pytest.approx(float(F.softmax(torch.tensor([3.0, 0.0, 4.0]), 0)[0]))  # class 1 (p = 0.013) is below SCORE_THRESH_TEST
 
 
 @pytest.fixture()
