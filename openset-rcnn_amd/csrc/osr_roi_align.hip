@@ -17,9 +17,20 @@
 // preconditions (bins narrower than a pixel, >6 rows per bin row, >64 footprint columns) take the per-bin separable
 // loop, and table overflow (bins wider than 13 px) the per-sample 4-tap loop.
 #include "osr_common.h"
+#include <stdlib.h>
 
-#define RA_MAXC 64  // table columns per bin (a 1333 px wide box on p2: 336 / 7 + 2 columns per bin)
-#define RA_MAXX 352 // columns of the whole RoI footprint handled by the column-sum path (p2 of a 1344 px wide batch: 336)
+// Table sizes set the LDS footprint of a wave and with it the occupancy: 4.9 KB per wave -> the kernel is limited by its 85
+// VGPRs (5 waves per SIMD) instead of by LDS (4 with the 64 / 352 tables of round 1: 1.51 -> 1.34 ms on the bench's proposals).
+#ifndef RA_MAXC
+#define RA_MAXC 32  // table columns per bin. Bins of this model's pyramid are at most 7 px wide (28 px RoIs on p2 .. 1333 px on p5);
+                    // a wider bin (single-level pyramids in the tests) takes the per-sample loop
+#endif
+#ifndef RA_MAXX
+#define RA_MAXX 192 // steps of the streamed (shorter) side of the footprint on the column-sum path; beyond: the per-bin loop
+#endif
+#ifndef RA_DEPTH
+#define RA_DEPTH 2  // register sets of the software pipeline of ra_bin_row (4 measured: no gain, the kernel is not latency-bound)
+#endif
 
 struct RoiAlignArgs {
     const void* data[4];
@@ -168,8 +179,7 @@ struct RaWaveLds {
 };
 
 #ifndef RA_WPB
-#define RA_WPB 4  // waves (= RoIs) per workgroup (1, 2 and 4 measured within 1.5 % end to end: RoI cost varies ~10x with
-                  // the footprint, but the slots a finished wave leaves idle inside a workgroup turned out not to matter)
+#define RA_WPB 2  // waves (= RoIs) per workgroup (2: -3 % against 4 once the small tables let five waves per SIMD in)
 #endif
 #ifndef RA_PG
 #define RA_PG 1    // columns per pipelined step
@@ -227,6 +237,22 @@ __device__ __forceinline__ void ra_bin_row(const TI* __restrict__ rp, size_t row
             }                                                                                              \
         }                                                                                                  \
     }
+#if RA_DEPTH == 4
+    Raw4<TI> vc[RA_PG][NY], vd[RA_PG][NY];
+    RA_ISSUE(va, 0);
+    RA_ISSUE(vb, RA_PG);
+    RA_ISSUE(vc, 2 * RA_PG);
+    for (int xg = 0; xg < ncol; xg += 4 * RA_PG) {
+        RA_ISSUE(vd, xg + 3 * RA_PG);
+        RA_CONSUME(va, xg);
+        RA_ISSUE(va, xg + 4 * RA_PG);
+        RA_CONSUME(vb, xg + RA_PG);
+        RA_ISSUE(vb, xg + 5 * RA_PG);
+        RA_CONSUME(vc, xg + 2 * RA_PG);
+        RA_ISSUE(vc, xg + 6 * RA_PG);
+        RA_CONSUME(vd, xg + 3 * RA_PG);
+    }
+#else
     RA_ISSUE(va, 0);
     for (int xg = 0; xg < ncol; xg += 2 * RA_PG) {
         RA_ISSUE(vb, xg + RA_PG);
@@ -234,6 +260,7 @@ __device__ __forceinline__ void ra_bin_row(const TI* __restrict__ rp, size_t row
         RA_ISSUE(va, xg + 2 * RA_PG);
         RA_CONSUME(vb, xg + RA_PG);
     }
+#endif
     while (bcur < P) RA_FLUSH2();
 #undef RA_ISSUE
 #undef RA_CONSUME
@@ -297,8 +324,11 @@ __device__ __forceinline__ void ra_bin_row_tall(const TI* __restrict__ rp, size_
 // other axis, walks the footprint one pixel column (or row) at a time: the pixels of the step that fall into the bin are
 // reduced with the bin's weights (software pipelined, the next step's loads in flight) and the sum goes into a 3-bin
 // sliding window of register accumulators along the streamed axis.
+#ifndef RA_MINW
+#define RA_MINW 1  // waves per SIMD the register allocation must allow (occupancy is otherwise limited by the LDS tables)
+#endif
 template <class TI, class TO>
-__global__ __launch_bounds__(RA_WPB * 64) void roi_align_kernel(RoiAlignArgs a) {
+__global__ __launch_bounds__(RA_WPB * 64, RA_MINW) void roi_align_kernel(RoiAlignArgs a) {
     __shared__ RaWaveLds s_all[RA_WPB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -507,324 +537,6 @@ __global__ __launch_bounds__(RA_WPB * 64) void roi_align_kernel(RoiAlignArgs a) 
     }
 }
 
-// ------------------------------------------------------------------------------------------------------
-// Row-streaming RoIAlign for c == 256 (the pyramid of this model): what the column-sum kernel above turned out to be bound by
-// is LATENCY, not bandwidth -- each of its ~7 x (footprint width) steps waits for a load round trip through L2 (stores only:
-// 0.25 ms, the whole kernel: 1.5 ms for 54 k RoIs of ~320 pixels; scripts/exp_roi2.py). This kernel visits every footprint pixel
-// ONCE and never waits per pixel:
-//   * the footprint is streamed row by row in chunks of RR_CHUNK pixels (8 KB, contiguous in NHWC) by LDS-DMA
-//     (buffer_load ... lds, no registers in between) into a per-wave double buffer: the loads of chunk k+1 are in flight while
-//     chunk k is reduced, one counted s_waitcnt per chunk;
-//   * x contraction from LDS, bin by bin (7 static bins, dynamic pixel range per bin): T[bx] += wx[bx][x] * f[x]; a pixel
-//     shared by two bins is read twice from LDS (256 B/clk) instead of twice from L2 -- no "at most three bins per pixel"
-//     precondition on this axis, so boxes narrower than a pixel need no special path;
-//   * y contraction in registers: a 3-bin-row sliding window acc[3][7] += wy[by][y] * T; a finished bin row is scaled by
-//     1 / count and stored. RoIs whose rows touch more than three bin rows (boxes flatter than ~3 pixels) run three passes with
-//     fixed windows {0-2, 3-5, 6} over their few rows instead of sliding.
-// Same arithmetic as the reference loop up to fp32 summation order; validity / clamp rules are per axis (weight tables, built
-// exactly as above). Table overflow (a bin wider than RA_MAXC pixels) keeps the per-sample loop.
-// ------------------------------------------------------------------------------------------------------
-template <class TI> struct RrCfg { static constexpr int CHUNK = 16, PXB = 512; };   // pixels per chunk, bytes per pixel (256 channels)
-template <> struct RrCfg<float> { static constexpr int CHUNK = 8, PXB = 1024; };
-#define RR_WPB 2   // waves (= RoIs) per workgroup: 2 x 20 KB of LDS, 4 workgroups = 8 waves per CU
-
-template <class TI>
-struct RrWaveLds {
-    unsigned char px[2][RrCfg<TI>::CHUNK * RrCfg<TI>::PXB];  // two chunk buffers, LDS-DMA destination ([pixel][channel], as in memory)
-    float w[2][7][RA_MAXC];                                  // [axis: 0 = y, 1 = x][bin][pixel of the bin's footprint]
-    int lo[2][8], n[2][8];
-};
-
-typedef __attribute__((address_space(3))) void rr_lds_void_t;
-
-template <class TI> struct RrPix;  // this lane's 4 channels of one staged pixel
-template <> struct RrPix<f16_t> {
-    typedef f16_t h4 __attribute__((ext_vector_type(4)));
-    static __device__ __forceinline__ void load(const unsigned char* p, int lane, float f[4]) {
-        const h4 t = *reinterpret_cast<const h4*>(p + lane * 8);
-        f[0] = (float)t[0]; f[1] = (float)t[1]; f[2] = (float)t[2]; f[3] = (float)t[3];
-    }
-};
-template <> struct RrPix<bf16_t> {
-    static __device__ __forceinline__ void load(const unsigned char* p, int lane, float f[4]) {
-        const uint2 t = *reinterpret_cast<const uint2*>(p + lane * 8);
-        f[0] = __uint_as_float(t.x << 16); f[1] = __uint_as_float(t.x & 0xffff0000u);
-        f[2] = __uint_as_float(t.y << 16); f[3] = __uint_as_float(t.y & 0xffff0000u);
-    }
-};
-template <> struct RrPix<float> {
-    static __device__ __forceinline__ void load(const unsigned char* p, int lane, float f[4]) {
-        const float4 t = *reinterpret_cast<const float4*>(p + lane * 16);
-        f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
-    }
-};
-
-template <class TI, class TO>
-__global__ __launch_bounds__(RR_WPB * 64) void roi_align_rows_kernel(RoiAlignArgs a) {
-    constexpr int CHUNK = RrCfg<TI>::CHUNK, PXB = RrCfg<TI>::PXB, NDMA = CHUNK * PXB / 1024;  // 1-KiB LDS-DMA instructions per chunk
-    __shared__ __attribute__((aligned(1024))) RrWaveLds<TI> s_all[RR_WPB];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    long long r;
-    {   // XCD-aware order (see roi_align_kernel)
-        const int nwg = gridDim.x, bq = blockIdx.x, q = nwg >> 3, rr = nwg & 7, xcd = bq & 7, idx = bq >> 3;
-        const int t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
-        r = (long long)t * RR_WPB + wid;
-    }
-    if (r >= a.m) return;
-    RrWaveLds<TI>& S = s_all[wid];
-    constexpr int P = 7, C = 256;
-    TO* out = reinterpret_cast<TO*>(a.out) + (size_t)r * P * P * C + lane * 4;
-
-    const int b = a.batch_idx[r];
-    if (b < 0) {  // padding row: zeros
-        const float z[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < P * P; ++i) store4<TO>(out + (size_t)i * C, z);
-        return;
-    }
-    const float bx1 = a.boxes[r * 4 + 0], by1 = a.boxes[r * 4 + 1], bx2 = a.boxes[r * 4 + 2], by2 = a.boxes[r * 4 + 3];
-    // [d2] assign_boxes_to_levels, evaluated in fp32 exactly as written there
-    float sz = sqrtf((bx2 - bx1) * (by2 - by1));
-    float lvf = floorf((float)a.canonical_level + log2f(sz / (float)a.canonical_size + 1e-8f));
-    float lmin = (float)a.min_level, lmax = (float)(a.min_level + a.num_levels - 1);
-    lvf = fminf(fmaxf(lvf, lmin), lmax);  // NaN (degenerate area) -> lmin via fmaxf
-    const int lv = __builtin_amdgcn_readfirstlane((int)lvf - a.min_level);
-    // (static selects instead of a.h[lv]: a runtime index into the by-value argument struct would move it to scratch)
-    const int H = lv == 0 ? a.h[0] : lv == 1 ? a.h[1] : lv == 2 ? a.h[2] : a.h[3];
-    const int W = lv == 0 ? a.w[0] : lv == 1 ? a.w[1] : lv == 2 ? a.w[2] : a.w[3];
-    const float scale = lv == 0 ? a.scale[0] : lv == 1 ? a.scale[1] : lv == 2 ? a.scale[2] : a.scale[3];
-    const void* lbase = lv == 0 ? a.data[0] : lv == 1 ? a.data[1] : lv == 2 ? a.data[2] : a.data[3];
-    const TI* feat = reinterpret_cast<const TI*>(lbase) + (size_t)b * H * W * C;
-
-    const float sw = bx1 * scale - 0.5f, sh = by1 * scale - 0.5f;
-    const float ew = bx2 * scale - 0.5f, eh = by2 * scale - 0.5f;
-    const float rw = ew - sw, rh = eh - sh;
-    const float bw = rw / (float)P, bh = rh / (float)P;
-    const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
-    const float count = (float)max(gh * gw, 1);
-
-    // ---- per-axis weight tables: entry (axis, bin, col) sums the samples that touch its pixel (as in roi_align_kernel) ----
-    bool overflow = false;
-    const int tcols = min(RA_MAXC, max(max(gh, gw), 1) + 3);
-    for (int e = lane; e < 2 * 7 * tcols; e += 64) {
-        const int axis = e / (7 * tcols), bin = (e / tcols) % 7, col = e % tcols;
-        const float start = axis ? sw : sh, bs = axis ? bw : bh;
-        const int grid = axis ? gw : gh, size = axis ? W : H;
-        int first = -1, last = -1;
-        float acc = 0.f;
-        for (int i = 0; i < grid; ++i) {
-            int lo, hi; float wl, wh;
-            if (!axis_sample(start, bin, bs, i, grid, size, &lo, &hi, &wl, &wh)) continue;
-            if (first < 0) first = lo;
-            last = hi;
-            if (lo - first == col) acc += wl;
-            if (hi - first == col) acc += wh;
-        }
-        S.w[axis][bin][col] = acc;
-        if (col == 0) {
-            const int n = first < 0 ? 0 : last - first + 1;
-            S.lo[axis][bin] = first < 0 ? 0 : first;
-            S.n[axis][bin] = n;
-            overflow |= n > tcols;
-        }
-    }
-    const bool fallback = __any(overflow);
-    ra_wave_sync();
-
-    if (fallback) {  // a bin wider than the table: per-sample 4-tap loop (one lane = 4 channels)
-        const TI* fl = feat + lane * 4;
-        for (int ph = 0; ph < P; ++ph)
-            for (int pw = 0; pw < P; ++pw) {
-                float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int iy = 0; iy < gh; ++iy) {
-                    int yl, yh; float hy, ly;
-                    if (!axis_sample(sh, ph, bh, iy, gh, H, &yl, &yh, &hy, &ly)) continue;
-                    for (int ix = 0; ix < gw; ++ix) {
-                        int xl, xh; float hx, lx;
-                        if (!axis_sample(sw, pw, bw, ix, gw, W, &xl, &xh, &hx, &lx)) continue;
-                        float v1[4], v2[4], v3[4], v4[4];
-                        load4<TI>(fl + ((size_t)yl * W + xl) * C, v1);
-                        load4<TI>(fl + ((size_t)yl * W + xh) * C, v2);
-                        load4<TI>(fl + ((size_t)yh * W + xl) * C, v3);
-                        load4<TI>(fl + ((size_t)yh * W + xh) * C, v4);
-                        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) acc[k] += w1 * v1[k] + w2 * v2[k] + w3 * v3[k] + w4 * v4[k];
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc[k] = acc[k] / count;
-                store4<TO>(out + (size_t)(ph * P + pw) * C, acc);
-            }
-        return;
-    }
-
-    // ---- footprint extent and the sliding-window precondition of the y axis (lanes 0..6 hold one bin each) ----
-    int ylo_l = 0x7fffffff, yhi_l = 0, xlo_l = 0x7fffffff, xhi_l = 0;
-    bool bad = false;
-    if (lane < P) {
-        const int lo = S.lo[0][lane], n = S.n[0][lane];
-        if (n > 0) { ylo_l = lo; yhi_l = lo + n; }
-        if (lane + 1 < P && n > 0 && S.n[0][lane + 1] > 0 && (S.lo[0][lane + 1] < lo || S.lo[0][lane + 1] + S.n[0][lane + 1] < lo + n)) bad = true;  // bins not ordered
-        if (lane + 3 < P && n > 0 && S.n[0][lane + 3] > 0 && S.lo[0][lane + 3] < lo + n) bad = true;                  // a row in more than three bin rows
-        if (n == 0) bad = true;                                                                                         // an empty bin row: fixed windows handle it
-        const int lx = S.lo[1][lane], nx = S.n[1][lane];
-        if (nx > 0) { xlo_l = lx; xhi_l = lx + nx; }
-    }
-#pragma unroll
-    for (int d = 1; d < 8; d <<= 1) {
-        ylo_l = min(ylo_l, __shfl_xor(ylo_l, d, 64)); yhi_l = max(yhi_l, __shfl_xor(yhi_l, d, 64));
-        xlo_l = min(xlo_l, __shfl_xor(xlo_l, d, 64)); xhi_l = max(xhi_l, __shfl_xor(xhi_l, d, 64));
-    }
-    const int ys0 = __builtin_amdgcn_readfirstlane(ylo_l), ye0 = __builtin_amdgcn_readfirstlane(yhi_l);
-    const int xs0 = __builtin_amdgcn_readfirstlane(xlo_l), xe0 = __builtin_amdgcn_readfirstlane(xhi_l);
-    const bool slide = !__any(bad);
-    const bool empty = ys0 == 0x7fffffff || xs0 == 0x7fffffff;  // no valid sample on an axis: every bin is zero
-    const int nrow = empty ? 0 : ye0 - ys0, ncol = empty ? 0 : xe0 - xs0;
-    const int nchunk = (ncol + CHUNK - 1) / CHUNK;
-    const float inv_count = 1.0f / count;
-
-    // per-bin x ranges as scalars (7 + 7 SGPRs)
-    int xlo[P], xn[P];
-#pragma unroll
-    for (int bb = 0; bb < P; ++bb) {
-        xlo[bb] = __builtin_amdgcn_readfirstlane(S.lo[1][bb]);
-        xn[bb] = __builtin_amdgcn_readfirstlane(S.n[1][bb]);
-    }
-
-    const unsigned feat_bytes = (unsigned)((size_t)H * W * C * sizeof(TI));
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<TI*>(feat), 0, feat_bytes, 0x00020000);
-    // chunk (row y, pixels x0 .. x0 + CHUNK): one contiguous CHUNK * PXB bytes of the row; lane l moves bytes [16 l, 16 l + 16) of each KiB
-#define RR_ISSUE(buf_, y_, x0_)                                                                                          \
-    {                                                                                                                    \
-        const unsigned base_ = (unsigned)(((size_t)(y_) * W + (x0_)) * PXB) + (unsigned)lane * 16u;                      \
-        const int need_ = min(CHUNK, xe0 - (x0_)) * PXB;  /* bytes of the chunk inside the footprint */                   \
-        _Pragma("unroll") for (int i_ = 0; i_ < NDMA; ++i_) {                                                            \
-            const unsigned off_ = i_ * 1024 < need_ ? base_ + i_ * 1024u : 0x80000000u;  /* beyond: no traffic, zeros */ \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (rr_lds_void_t*)(S.px[buf_] + i_ * 1024), 16, off_, 0, 0, 0);    \
-        }                                                                                                                \
-    }
-
-    const int npass = slide ? 1 : 3;
-    for (int pass = 0; pass < npass; ++pass) {
-        int wb = slide ? 0 : pass * 3;  // bin row held in acc[0]
-        float acc[3][P][4];
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-#pragma unroll
-            for (int j = 0; j < P; ++j)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc[d][j][k] = 0.f;
-#define RR_FLUSH()                                                                                     \
-    {                                                                                                  \
-        if (wb < P) {                                                                                  \
-            _Pragma("unroll") for (int j = 0; j < P; ++j) {                                            \
-                float t_[4];                                                                           \
-                _Pragma("unroll") for (int k = 0; k < 4; ++k) t_[k] = acc[0][j][k] * inv_count;        \
-                store4<TO>(out + (size_t)(wb * P + j) * C, t_);                                        \
-            }                                                                                          \
-        }                                                                                              \
-        _Pragma("unroll") for (int j = 0; j < P; ++j)                                                  \
-            _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                            \
-                acc[0][j][k] = acc[1][j][k]; acc[1][j][k] = acc[2][j][k]; acc[2][j][k] = 0.f;          \
-            }                                                                                          \
-        ++wb;                                                                                          \
-    }
-        if (nrow > 0 && nchunk > 0) {
-            int buf = 0;
-            RR_ISSUE(0, ys0, xs0);
-            for (int yi = 0; yi < nrow; ++yi) {
-                const int y = ys0 + yi;
-                if (slide) {  // bin rows that end above this pixel row are complete
-                    while (wb < P) {
-                        const int l0 = __builtin_amdgcn_readfirstlane(S.lo[0][wb]), n0 = __builtin_amdgcn_readfirstlane(S.n[0][wb]);
-                        if (n0 != 0 && y < l0 + n0) break;
-                        RR_FLUSH();
-                    }
-                }
-                float T[P][4];
-#pragma unroll
-                for (int j = 0; j < P; ++j)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) T[j][k] = 0.f;
-                for (int ci = 0; ci < nchunk; ++ci) {
-                    const int x0 = xs0 + ci * CHUNK;
-                    // prefetch the next chunk (next piece of this row, or the start of the next row), then wait for this one
-                    const bool last = ci + 1 == nchunk && yi + 1 == nrow;
-                    if (!last) {
-                        const int ny = ci + 1 < nchunk ? y : y + 1, nx0 = ci + 1 < nchunk ? x0 + CHUNK : xs0;
-                        RR_ISSUE(buf ^ 1, ny, nx0);
-                        if constexpr (NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    } else {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    const unsigned char* pb = S.px[buf];
-                    // x contraction of the chunk, bin by bin: pixels [max(lo, x0), min(lo + n, x0 + CHUNK))
-#pragma unroll
-                    for (int j = 0; j < P; ++j) {
-                        const int p0 = max(xlo[j], x0), p1 = min(xlo[j] + xn[j], x0 + CHUNK);
-                        // four pixels per trip: their eight LDS reads are issued back to back and waited for once (a one-pixel loop
-                        // exposes the LDS latency per pixel); slots past the bin re-read its last pixel with weight zero
-                        for (int p = p0; p < p1; p += 4) {
-                            float wv[4], f[4][4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const int q = min(p + u, p1 - 1);
-                                wv[u] = S.w[1][j][q - xlo[j]];
-                                RrPix<TI>::load(pb + (q - x0) * PXB, lane, f[u]);
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const float wq = p + u < p1 ? wv[u] : 0.f;
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) T[j][k] = __builtin_fmaf(wq, f[u][k], T[j][k]);
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();  // every read of this buffer is issued before the DMA after next targets it
-                    buf ^= 1;
-                }
-                // y contraction: this pixel row into the (up to) three bin rows of the window
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const int by = wb + d;
-                    float wy = 0.f;
-                    if (by < P) {
-                        const int l0 = __builtin_amdgcn_readfirstlane(S.lo[0][by]), n0 = __builtin_amdgcn_readfirstlane(S.n[0][by]);
-                        if (y >= l0 && y < l0 + n0) wy = S.w[0][by][y - l0];
-                    }
-                    wy = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(wy)));
-                    if (wy != 0.f) {
-#pragma unroll
-                        for (int j = 0; j < P; ++j)
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) acc[d][j][k] = __builtin_fmaf(wy, T[j][k], acc[d][j][k]);
-                    }
-                }
-            }
-        }
-        // flush what the window still holds: everything up to the last bin row (sliding), or this pass's three bin rows
-        const int wend = slide ? P : min(P, pass * 3 + 3);
-        while (wb < wend) RR_FLUSH();
-#undef RR_FLUSH
-    }
-#undef RR_ISSUE
-}
-
-template <class TI>
-static osr_status launch_rows(const RoiAlignArgs& a, int out_dtype, hipStream_t st) {
-    dim3 grid((unsigned)((a.m + RR_WPB - 1) / RR_WPB)), block(RR_WPB * 64);
-    switch (out_dtype) {
-        case OSR_F32: hipLaunchKernelGGL((roi_align_rows_kernel<TI, float>), grid, block, 0, st, a); break;
-        case OSR_F16: hipLaunchKernelGGL((roi_align_rows_kernel<TI, f16_t>), grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL((roi_align_rows_kernel<TI, bf16_t>), grid, block, 0, st, a); break;
-    }
-    OSR_CHECK_LAUNCH("osr_roi_align_fwd(rows)");
-    return OSR_OK;
-}
-
 template <class TI>
 static osr_status launch_out(const RoiAlignArgs& a, int out_dtype, hipStream_t st) {
     dim3 grid((unsigned)((a.m + RA_WPB - 1) / RA_WPB)), block(RA_WPB * 64);
@@ -859,16 +571,6 @@ extern "C" osr_status osr_roi_align_fwd(const osr_pyramid* f, int32_t feat_dtype
     a.pooled = pooled; a.canonical_level = canonical_level; a.canonical_size = canonical_size; a.min_level = min_level;
     a.out = out;
     hipStream_t st = (hipStream_t)stream;
-    bool rows_ok = f->c == 256 && pooled == 7;  // the row-streaming kernel: this model's pyramid (256 channels, 7 x 7 bins), levels < 4 GiB
-    for (int l = 0; l < f->num_levels; ++l)
-        rows_ok = rows_ok && (long long)f->h[l] * f->w[l] * 256 * osr_dtype_size(feat_dtype) < (1ll << 31) && (((uintptr_t)f->data[l]) & 15) == 0;
-    if (rows_ok) {
-        switch (feat_dtype) {
-            case OSR_F32: return launch_rows<float>(a, out_dtype, st);
-            case OSR_F16: return launch_rows<f16_t>(a, out_dtype, st);
-            default: return launch_rows<bf16_t>(a, out_dtype, st);
-        }
-    }
     switch (feat_dtype) {
         case OSR_F32: return launch_out<float>(a, out_dtype, st);
         case OSR_F16: return launch_out<f16_t>(a, out_dtype, st);

@@ -333,10 +333,10 @@ def test_roi_align_extreme_aspect_footprints(ops):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16], ids=["f32", "f16"])
-def test_roi_align_row_streaming_kernel_every_path(ops, dt):
-    """The 256-channel kernel (LDS-DMA row streaming, osr_roi_align.hip: roi_align_rows_kernel): sliding window over the bin rows,
-    the fixed-window passes for boxes flatter than a few pixels, rows longer than one / two / many 16-pixel chunks, bins narrower
-    than a pixel on the x axis, footprints clipped by every border, degenerate boxes, and the per-sample loop on table overflow."""
+def test_roi_align_256_channels_every_path(ops, dt):
+    """The model's own channel count (one 512-byte pixel per wave-load) through every path of the kernel: footprints streamed along
+    either axis, wider than the 192-step window tables (per-bin loop), bins wider than the 32-column weight tables (per-sample
+    loop), bins narrower than a pixel, footprints clipped by every border, degenerate and out-of-image boxes, padding rows."""
     gg = g(29)
     f = torch.randn(2, 256, 60, 500, generator=gg).to(dt)
     boxes = torch.tensor([
