@@ -454,6 +454,12 @@ osr_status osr_sgd_step(float* param, const float* grad, float* momentum_buf, in
                         float weight_decay, float grad_scale, const float* row_scale, int64_t row_elems, void* lowp_copy,
                         int32_t lowp_dtype, const int32_t* apply_flag, void* stream);
 
+/* Backward-data weight of a convolution, (cout,kh,kw,cin) -> (cin,kh,kw,cout) spatially flipped (the forward MFMA kernel run on
+ * it with padding k-1-pad is the data gradient; a 1x1 layer / FC matrix is transposed). Run once per SGD step on the refreshed
+ * working copies. dtype: element type of both tensors (f16/bf16/f32). out must not alias weight. */
+osr_status osr_pack_dgrad_weight(const void* weight, void* out, int32_t cout, int32_t kh, int32_t kw, int32_t cin,
+                                 int32_t dtype, void* stream);
+
 /* Overflow guard: *flag (device int32, preset to 1 by the caller) is cleared when any of the n floats of x is inf or NaN.
  * The reference trains in fp32 and has no such step (train.py:135-146); the fp16 gradients of this build do, and an
  * overflowed iteration must not reach the fp32 masters or a checkpoint. x 16-byte aligned. Asynchronous, no host sync. */

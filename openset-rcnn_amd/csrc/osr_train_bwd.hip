@@ -666,3 +666,40 @@ extern "C" osr_status osr_check_finite(const float* x, int64_t n, int32_t* flag,
     OSR_CHECK_LAUNCH("osr_check_finite");
     return OSR_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------------
+// Backward-data weight of a convolution from its forward weight, once per SGD step (instead of flip + permute + copy kernels of
+// the tensor library every iteration): dst[ci][kh-1-y][kw-1-x][co] = src[co][y][x][ci]. For 1x1 layers and FC matrices this is
+// the plain transpose. 32 x 32 tiles through LDS, both sides coalesced; 2- or 4-byte elements.
+// ------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void pack_dgrad_kernel(const T* __restrict__ src, T* __restrict__ dst, int cout, int kh, int kw, int cin) {
+    __shared__ T tile[32][33];
+    const int tap = blockIdx.z, y = tap / kw, x = tap % kw;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const long long taps = (long long)kh * kw;
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        if (co < cout && ci < cin) tile[r][tx] = src[((long long)co * taps + tap) * cin + ci];
+    }
+    __syncthreads();
+    const int ftap = (kh - 1 - y) * kw + (kw - 1 - x);
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (ci < cin && co < cout) dst[((long long)ci * taps + ftap) * cout + co] = tile[tx][r];
+    }
+}
+
+extern "C" osr_status osr_pack_dgrad_weight(const void* weight, void* out, int32_t cout, int32_t kh, int32_t kw, int32_t cin, int32_t dtype, void* stream) {
+    OSR_REQUIRE(weight && out && weight != out, OSR_ERR_INVALID_ARG, "osr_pack_dgrad_weight: null or aliased pointers");
+    OSR_REQUIRE(cout >= 1 && cin >= 1 && kh >= 1 && kw >= 1 && kh * kw <= 65535 && osr_dtype_ok(dtype), OSR_ERR_INVALID_ARG, "osr_pack_dgrad_weight: bad sizes / dtype");
+    const dim3 grid((cin + 31) / 32, (cout + 31) / 32, kh * kw);
+    OSR_REQUIRE(grid.y <= 65535, OSR_ERR_UNSUPPORTED, "osr_pack_dgrad_weight: cout too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == OSR_F32) hipLaunchKernelGGL(pack_dgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)weight, (float*)out, cout, kh, kw, cin);
+    else hipLaunchKernelGGL(pack_dgrad_kernel<unsigned short>, grid, dim3(256), 0, st, (const unsigned short*)weight, (unsigned short*)out, cout, kh, kw, cin);
+    OSR_CHECK_LAUNCH("osr_pack_dgrad_weight");
+    return OSR_OK;
+}

@@ -110,6 +110,7 @@ PROTOTYPES = {
     "osr_pool_bwd": (I32, [P, I32, I32, P, P, I32, I32, I32, I32, I32, I32, P]),
     "osr_sgd_step": (I32, [P, P, P, I64, F32, F32, F32, F32, P, I64, P, I32, P, P]),
     "osr_check_finite": (I32, [P, I64, P, P]),
+    "osr_pack_dgrad_weight": (I32, [P, P, I32, I32, I32, I32, I32, P]),
 }
 
 _lib = None

@@ -636,7 +636,7 @@ def conv2d_dgrad(dy: torch.Tensor, w_dgrad: torch.Tensor, x_hw: Tuple[int, int],
         raise OsrError("conv2d_dgrad takes a mask or an addend, not both")
     aux, mode = (mask, 3) if mask is not None else ((add, 1) if add is not None else (None, 0))
     out_dtype = out_dtype or dy.dtype
-    zero_bias = torch.zeros((cin,), dtype=torch.float32, device=dy.device)
+    zero_bias = _zero_bias(cin, dy.device)
     if stride == 1:
         if (hi + 2 * pad - kh) + 1 != ho or (wi + 2 * pad - kw) + 1 != wo:
             raise OsrError("x_hw inconsistent with dy and the kernel geometry")
@@ -832,6 +832,37 @@ def pool_bwd(src: torch.Tensor, out_hw: Tuple[int, int], base: Optional[torch.Te
     out = torch.empty((n, ho, wo, c), dtype=src.dtype, device=src.device)
     check(lib.osr_pool_bwd(_p(src), hs, ws_, _p(base), _p(out), n, ho, wo, c, mode, _DT[src.dtype], _stream()), "osr_pool_bwd")
     return out
+
+
+def pack_dgrad_weight(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(cout,kh,kw,cin) -> (cin,kh,kw,cout) spatially flipped (a 2-d (n,k) matrix is transposed to (k,n)); out: reuse this buffer."""
+    lib = _lib.load()
+    _need(w, name="w")
+    if w.dim() == 2:
+        cout, cin, kh, kw = w.shape[0], w.shape[1], 1, 1
+        shape = (cin, cout)
+    else:
+        cout, kh, kw, cin = w.shape
+        shape = (cin, kh, kw, cout)
+    if out is None:
+        out = torch.empty(shape, dtype=w.dtype, device=w.device)
+    else:
+        _need(out, w.dtype, "out")
+        if out.numel() != w.numel():
+            raise OsrError("pack_dgrad_weight: out has the wrong size")
+    check(lib.osr_pack_dgrad_weight(_p(w), _p(out), cout, kh, kw, cin, _DT[w.dtype], _stream()), "osr_pack_dgrad_weight")
+    return out
+
+
+_ZERO_BIAS = {}
+
+
+def _zero_bias(n: int, device) -> torch.Tensor:
+    """A shared all-zero fp32 bias (the data-gradient launches have none): allocated and filled once per (size, device)."""
+    key = (n, str(device))
+    if key not in _ZERO_BIAS:
+        _ZERO_BIAS[key] = torch.zeros((n,), dtype=torch.float32, device=device)
+    return _ZERO_BIAS[key]
 
 
 def check_finite_(x: torch.Tensor, flag: torch.Tensor) -> torch.Tensor:

@@ -34,11 +34,6 @@ def warmup_multistep_lr(iteration: int, base_lr: float, steps: Tuple[int, ...], 
     return lr
 
 
-def _dgrad_pack(w_lp: torch.Tensor) -> torch.Tensor:
-    """(cout,kh,kw,cin) packed forward weight -> (cin,kh,kw,cout) flipped: the weight of the backward-data convolution."""
-    return w_lp.flip(1, 2).permute(3, 1, 2, 0).contiguous()
-
-
 class OpensetRCNNTrainer:
     def __init__(self, params: Dict[str, torch.Tensor], cfg: Optional[dict] = None, dtype: torch.dtype = torch.float16, device: str = "cuda",
                  lr: float = 0.005, momentum: float = 0.9, weight_decay: float = 1e-4, loss_scale: float = 1024.0, freeze_at: int = 2,
@@ -127,14 +122,21 @@ class OpensetRCNNTrainer:
         """Everything that is a function of the parameters and read by a kernel: backward-data weights, transposed fp32 heads,
         normalised prototypes."""
         e = self.eng
-        self.wd = {n: _dgrad_pack(e.w[n + ".w"]) for n in self.conv_names}
-        self.wd["fc1"] = e.fc1_w.t().contiguous().view(e.fc1_w.shape[1], 1, 1, e.fc1_w.shape[0])
-        self.wd["fc2"] = e.fc2_w.t().contiguous().view(e.fc2_w.shape[1], 1, 1, e.fc2_w.shape[0])
-        pad = lambda w, k: torch.nn.functional.pad(w, (0, 0, 0, k - w.shape[0]))  # noqa: E731  rows -> k (zero rows)
-        self.t_cls = pad(e.cls_w, 32).t().contiguous()      # (1024, 32): d rec = d logits(padded to 32) . W_cls
-        self.t_pred = pad(e.pred_w, 16).t().contiguous()    # (1024, 16)
-        self.t_dec = e.dec_w.t().contiguous()                # (256, 1024): d emb = d rec . W_dec
-        self.t_enc = e.enc_w.t().contiguous()                # (1024, 256): d box_feats = d emb . W_enc
+        wd = getattr(self, "wd", {})  # the buffers are allocated once and refilled in place every step (osr_pack_dgrad_weight)
+        for n in self.conv_names:
+            wd[n] = ops.pack_dgrad_weight(e.w[n + ".w"], wd.get(n))
+        wd["fc1"] = ops.pack_dgrad_weight(e.fc1_w, wd.get("fc1")).view(e.fc1_w.shape[1], 1, 1, e.fc1_w.shape[0])
+        wd["fc2"] = ops.pack_dgrad_weight(e.fc2_w, wd.get("fc2")).view(e.fc2_w.shape[1], 1, 1, e.fc2_w.shape[0])
+        self.wd = wd
+        if not hasattr(self, "t_cls"):  # zero-padded transposes of the narrow fp32 heads: the padding rows are written once
+            self.t_cls = torch.zeros((e.cls_w.shape[1], 32), dtype=torch.float32, device=e.device)    # (1024, 32): d rec = d logits(padded to 32) . W_cls
+            self.t_pred = torch.zeros((e.pred_w.shape[1], 16), dtype=torch.float32, device=e.device)  # (1024, 16)
+            self.t_dec = torch.empty((e.dec_w.shape[1], e.dec_w.shape[0]), dtype=torch.float32, device=e.device)  # (256, 1024): d emb = d rec . W_dec
+            self.t_enc = torch.empty((e.enc_w.shape[1], e.enc_w.shape[0]), dtype=torch.float32, device=e.device)  # (1024, 256): d box_feats = d emb . W_enc
+        self.t_cls[:, : e.cls_w.shape[0]].copy_(e.cls_w.t())
+        self.t_pred[:, : e.pred_w.shape[0]].copy_(e.pred_w.t())
+        ops.pack_dgrad_weight(e.dec_w, self.t_dec)
+        ops.pack_dgrad_weight(e.enc_w, self.t_enc)
         e.protos = ops.l2_normalize_rows(self.master["protos"])
 
     # ---- forward with saved activations -------------------------------------------------------------------------

@@ -145,3 +145,54 @@ def test_train_checkpoint_resume_and_evaluate_on_a_toy_dataset(osr, toy_voc_root
     assert not torch.equal(blob["model"][k], blob2["model"][k])
     # evaluation only, from the checkpoint file
     assert run_net.main(common + ["--eval-only"] + opts + ["MODEL.WEIGHTS", os.path.join(out, "model_final.pth")]) == 0
+
+
+@pytest.fixture()
+def toy_graspnet_root(tmp_path):
+    """GraspNet layout of the reference (datasets/graspnet_os/{annotations,images}): four 96x128 JPEGs, the 88-category table with
+    the reference's known names among them, annotations of known and unknown categories; the same images serve every split."""
+    import json
+    from PIL import Image
+    from openset_rcnn_amd.host.datasets import GRASPNET_KNOWN_CATEGORIES, GRASPNET_SPLITS
+    root = tmp_path / "datasets" / "graspnet_os"
+    (root / "annotations").mkdir(parents=True)
+    (root / "images").mkdir(parents=True)
+    g = np.random.default_rng(1)
+    names = []
+    known = iter(GRASPNET_KNOWN_CATEGORIES)
+    for i in range(88):  # known categories at every third slot, so that dataset ids and known indices differ (class_map is not identity)
+        names.append(next(known) if i % 3 == 1 and len([n for n in names if n in GRASPNET_KNOWN_CATEGORIES]) < 28 else f"other_{i}")
+    cats = [dict(id=i + 1, name=n) for i, n in enumerate(names)]
+    kid = [c["id"] for c in cats if c["name"] in GRASPNET_KNOWN_CATEGORIES]
+    uid = [c["id"] for c in cats if c["name"] not in GRASPNET_KNOWN_CATEGORIES]
+    images, anns = [], []
+    for i in range(4):
+        Image.fromarray(g.integers(0, 256, (96, 128, 3), dtype=np.uint8)).save(root / "images" / f"{i}.jpg")
+        images.append(dict(id=i + 1, file_name=f"{i}.jpg", height=96, width=128))
+        for j, (cid, box) in enumerate(((kid[i], [8, 10, 50, 60]), (kid[i + 4], [64, 20, 56, 64]), (uid[i], [30, 40, 40, 40]))):
+            anns.append(dict(id=len(anns) + 1, image_id=i + 1, category_id=cid, bbox=box, area=box[2] * box[3], iscrowd=0))
+    blob = json.dumps(dict(images=images, annotations=anns, categories=cats))
+    for jf in GRASPNET_SPLITS.values():
+        (root / "annotations" / jf).write_text(blob)
+    return str(tmp_path / "datasets")
+
+
+@pytest.mark.gpu
+def test_graspnet_configuration_trains_and_evaluates_on_a_coco_layout_toy_set(osr, toy_graspnet_root, tmp_path, monkeypatch):
+    """SURVEY.md 8f rank 4 end to end: configs/graspnet.yaml (28 known of 88 classes, the sparse class_id map of
+    prototype_learning_network.py:80-95, COCO-layout registration, the open-set COCO-style evaluator) through run_net.py."""
+    monkeypatch.setenv("DETECTRON2_DATASETS", toy_graspnet_root)
+    out = str(tmp_path / "out")
+    common = ["--config-file", os.path.join(ROOT, "configs", "graspnet.yaml"), "--test-batch", "2"]
+    opts = ["OUTPUT_DIR", out, "SEED", "5", "DATASETS.TEST", "('graspnet_test_1',)", "SOLVER.IMS_PER_BATCH", "2", "SOLVER.BASE_LR", "0.00005",
+            "SOLVER.WARMUP_ITERS", "0", "SOLVER.CHECKPOINT_PERIOD", "0", "SOLVER.MAX_ITER", "2", "INPUT.MIN_SIZE_TRAIN", "(96,)",
+            "INPUT.MAX_SIZE_TRAIN", "128", "INPUT.MIN_SIZE_TEST", "96", "INPUT.MAX_SIZE_TEST", "128"]
+    assert run_net.main(common + opts) == 0
+    blob = torch.load(os.path.join(out, "model_final.pth"), map_location="cpu", weights_only=False)
+    assert blob["iteration"] == 1 and blob["model"]["roi_heads.dml.representatives"].shape == (28, 256)
+    assert blob["model"]["roi_heads.softmaxcls.cls_score.weight"].shape == (29, 1024)
+    assert all(torch.isfinite(v).all() for v in blob["model"].values() if v.is_floating_point())
+    # the evaluator kept the detections file the reference's --resume_test re-scores (os_coco_evaluation.py)
+    inf = os.path.join(out, "inference", "graspnet_test_1", "Final")
+    assert os.path.isdir(inf) and any(f.endswith(".json") for f in os.listdir(inf))
+    assert run_net.main(common + ["--resume_test"] + opts) == 0

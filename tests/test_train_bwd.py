@@ -207,3 +207,30 @@ def test_elementwise_and_sgd(ops):
         ops.sgd_step_(p, (gfold * 32.0).to(DEV), buf, 0.02, 0.9, 1e-2, grad_scale=1.0 / 32.0, row_scale=rs.to(DEV), lowp=lowp)
     assert rel(p, tp.detach()) < 1e-6
     assert torch.equal(lowp.cpu(), (p.cpu() * rs[:, None]).half())
+
+
+def test_pack_dgrad_weight_kernel_and_overflow_flag(ops):
+    """osr_pack_dgrad_weight against the host packing (weights.pack_dgrad_weight: flip + permute), ragged channel counts, both
+    element sizes, in-place refill of a preallocated buffer; osr_check_finite clears its flag on inf / NaN only."""
+    from openset_rcnn_amd.host.weights import pack_conv_weight, pack_dgrad_weight
+    gg = g(77)
+    for cout, cin, k, dt in ((40, 96, 3, torch.float16), (256, 64, 1, torch.bfloat16), (33, 17, 5, torch.float32), (128, 128, 3, torch.float16)):
+        w = torch.randn(cout, cin, k, k, generator=gg)
+        fwd = pack_conv_weight(w, dt).to(DEV)           # (cout,kh,kw,cin): what the forward kernels read
+        want = pack_dgrad_weight(w, dt)                 # (cin,kh,kw,cout), flipped
+        got = ops.pack_dgrad_weight(fwd)
+        assert got.shape == want.shape and torch.equal(got.cpu(), want)
+        buf = torch.zeros_like(got)
+        assert ops.pack_dgrad_weight(fwd, buf) is buf and torch.equal(buf.cpu(), want)
+    m = torch.randn(21, 1024, generator=gg).to(DEV)
+    assert torch.equal(ops.pack_dgrad_weight(m).cpu(), m.t().cpu())
+    flag = torch.ones(1, dtype=torch.int32, device=DEV)
+    x = torch.randn(100003, generator=gg).to(DEV)
+    x = x[: 100000].contiguous()
+    assert int(ops.check_finite_(x, flag)) == 1
+    x[99999] = float("nan")
+    assert int(ops.check_finite_(x, flag)) == 0
+    flag.fill_(1)
+    x[99999] = 0.0
+    x[12345] = float("-inf")
+    assert int(ops.check_finite_(x, flag)) == 0
