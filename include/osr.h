@@ -80,7 +80,15 @@ typedef struct osr_conv_params {
     int32_t out_dtype; /* osr_dtype of out */
     int32_t concurrency; /* scheduling hint: number of streams of the caller that launch onto the GPU at the same time (0 or 1:
                           * this launch has the GPU to itself). Tile selection only; results do not depend on it. */
+    void* workspace;         /* optional (may be null), caller-owned, 16-byte aligned: with at least                      */
+    int64_t workspace_bytes; /* osr_conv2d_fwd_workspace_bytes(p) bytes the partial last dispatch round of a deep-K 1x1 / FC
+                              * layer is cut along K (fixed-order fp32 partial sums: bitwise reproducible, but not bitwise
+                              * equal to the un-split sum) */
 } osr_conv_params;
+
+/* Workspace with which osr_conv2d_fwd splits the tail round of this layer along K; 0 when the layer does not qualify (then a
+ * null workspace costs nothing). Host-side arithmetic only. */
+int64_t osr_conv2d_fwd_workspace_bytes(const osr_conv_params* p);
 
 osr_status osr_conv2d_fwd(const osr_conv_params* p, const void* in, const void* weight, const float* bias,
                           const void* residual, void* out, void* stream);

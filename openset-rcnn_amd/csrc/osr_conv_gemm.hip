@@ -263,6 +263,7 @@ static osr_status conv_launch(const ConvArgs& a0, hipStream_t st) {
 osr_status osr_conv_f32_run(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* residual, void* out,
                             hipStream_t st);
 int osr_conv64_eligible(const osr_conv_params* p, long long in_bytes, long long w_bytes);
+long long osr_conv64_split_workspace_bytes(const osr_conv_params* p);
 osr_status osr_conv64_run(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* residual, const void* mask,
                           void* out, long long in_bytes, long long w_bytes, hipStream_t st);
 
@@ -343,6 +344,11 @@ static osr_status conv2d_fwd_impl(const osr_conv_params* p, const void* in, cons
     }
     osr_set_error("osr_conv2d_fwd: out_dtype must equal in_dtype or be f32");
     return OSR_ERR_UNSUPPORTED;
+}
+
+extern "C" int64_t osr_conv2d_fwd_workspace_bytes(const osr_conv_params* p) {
+    if (!p || (p->in_dtype != OSR_F16 && p->in_dtype != OSR_BF16) || p->n < 1 || p->ho < 1 || p->wo < 1 || p->cin < 64 || p->cout < 8 || p->cout % 8 != 0) return 0;
+    return osr_conv64_split_workspace_bytes(p);
 }
 
 extern "C" osr_status osr_conv2d_fwd(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* residual,

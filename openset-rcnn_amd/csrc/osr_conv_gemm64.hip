@@ -89,6 +89,11 @@ struct Conv64Args {
     float* tail_ctr;
     int tail_lds_off;      // byte offset of the tail weights in LDS
     FastDiv div_howo, div_wo;  // row -> (image, oh, ow); M < 2^31
+    // Split-K of the last, partial dispatch round (deep-K 1x1 / FC layers; conv64_launch_split): a launch covers the linear tiles
+    // [tile0, tile0 + ntile) only; with ksplit > 1 every one of them is taken by ksplit workgroups, each over its own range of K
+    // slices, which write raw fp32 partial sums (no bias / ReLU) into slab s = out + s * split_stride floats.
+    int tile0, ntile, ksplit;
+    long long split_stride;
 #ifdef C64_STAMPS
     unsigned long long* dbg;
 #endif
@@ -145,12 +150,14 @@ __global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI !=
     C64_STAMP(0);
 
     // XCD-aware bijective remap of the linear block id (guide T1)
-    const int nwg = a.tiles_m * a.tiles_n;
+    const int nwg = gridDim.x;
     int t;
     {
         const int b = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    const int ksp = a.ksplit > 1 ? t / a.ntile : 0;  // which K range of the tile (split-K tail launches only)
+    t = a.tile0 + (a.ksplit > 1 ? t % a.ntile : t);
     const int tile_n = t % a.tiles_n, tile_m = t / a.tiles_n;
     const long long m0 = (long long)tile_m * BM;
     const int n0 = tile_n * BN;
@@ -252,7 +259,12 @@ __global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI !=
 #define C64_ROW(r) ((((r) >> 3) & 1) * 16 + (lane >> 4) * 4 + ((r) & 3))
 #define C64_COL(r) ((((r) >> 2) & 1) * 16 + (lane & 15))
 
-    const int nk = a.K / 64;
+    int nk = a.K / 64;
+    if (a.ksplit > 1) {  // this workgroup's share of the K slices (1x1 / FC layers only: the slice index is the channel block)
+        const int k_lo = (int)((long long)ksp * nk / a.ksplit), k_hi = (int)((long long)(ksp + 1) * nk / a.ksplit);
+        c0 = k_lo * 64; kbyte = k_lo * 128; tap_off = (unsigned)(c0 * 2);
+        nk = k_hi - k_lo;
+    }
     C64_ISSUE(0);
     __builtin_amdgcn_sched_barrier(0);
 
@@ -270,8 +282,9 @@ __global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI !=
         for (int jp = 0; jp < TNP; ++jp) {
             const int co = n0 + (wc * TN + jp * 2) * 32 + cseg;
             const int cb = co < p.cout ? co : 0;
-            const float4 b0 = *reinterpret_cast<const float4*>(a.bias + cb);
-            const float4 b1 = *reinterpret_cast<const float4*>(a.bias + cb + 4);
+            const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 b0 = a.ksplit > 1 ? zero4 : *reinterpret_cast<const float4*>(a.bias + cb);
+            const float4 b1 = a.ksplit > 1 ? zero4 : *reinterpret_cast<const float4*>(a.bias + cb + 4);
             bias8[jp][0] = b0.x; bias8[jp][1] = b0.y; bias8[jp][2] = b0.z; bias8[jp][3] = b0.w;
             bias8[jp][4] = b1.x; bias8[jp][5] = b1.y; bias8[jp][6] = b1.z; bias8[jp][7] = b1.w;
         }
@@ -429,7 +442,7 @@ __global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI !=
     // ---- epilogue: wave-private fp32 slab (32 rows x 64 columns, one pair of N tiles at a time) -> 8 channels per lane:
     //      bias + residual / FPN 2x upsample-add + ReLU + convert on 16-byte row segments, coalesced along channels ----
     float* slab = reinterpret_cast<float*>(lds) + wid * 32 * EPI_LD;
-    TO* __restrict__ out = reinterpret_cast<TO*>(a.out);
+    TO* __restrict__ out = reinterpret_cast<TO*>(a.out) + (a.ksplit > 1 ? (long long)ksp * a.split_stride : 0ll);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -525,12 +538,13 @@ static void conv64_launch_tile(Conv64Args& a, hipStream_t st) {
     a.two_stage = TWO;
     a.tiles_m = (int)((a.M + BM - 1) / BM);
     a.tiles_n = (a.p.cout + BN - 1) / BN;
+    if (a.ntile <= 0) { a.tile0 = 0; a.ntile = a.tiles_m * a.tiles_n; a.ksplit = 1; }  // the whole grid in one launch
     const size_t lds = conv64_lds_bytes(BM, BN, TWO, NW);
     if (lds > 64 * 1024) {
         static osr_dev_mask attr{0};
         osr_once_per_device(attr, [] { allow_big_lds(conv_igemm64_kernel<TI, TO, BM, BN, WM, WN, 0, TWO>); });
     }
-    hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, BM, BN, WM, WN, 0, TWO>), dim3((unsigned)a.tiles_m * a.tiles_n), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, BM, BN, WM, WN, 0, TWO>), dim3((unsigned)a.ntile * (a.ksplit > 1 ? a.ksplit : 1)), dim3(NW * 64), lds, st, a);
 }
 
 // Tile choice by a small cost model instead of per-layer thresholds. Measured on MI355X (scripts/ab_tiles.sh): with the
@@ -590,10 +604,98 @@ static int conv64_pick_tile(const Conv64Args& a) {
     return best;
 }
 
+// ---- split-K of the tail round ---------------------------------------------------------------------------------------
+// A grid of T tiles on S = 256 x occ slots runs floor(T / S) full dispatch rounds and one round that is only (T mod S) / S full.
+// For a deep-K 1x1 / FC layer (FC1: 1072 tiles of 256 x 256 on 256 slots, 196 K slices: 4.19 rounds, the fifth one 19 % full)
+// the partial round is cut along K instead: its tiles go to a second launch in which ksplit workgroups share each tile's K loop
+// and write fp32 partial sums, and a small third launch adds them up and applies the epilogue. The partial sums are summed in
+// a fixed order: the result does not depend on timing.
+struct SplitPlan { int tile_id, tail_mtiles, ksplit; long long m_tail0, ws_bytes; };
+
+static bool conv64_plan_split(const Conv64Args& a, SplitPlan* sp) {
+    const osr_conv_params& p = a.p;
+    if (a.stem || p.kh * p.kw != 1 || p.res_mode != 0 || a.mask || p.stride_h != 1 || p.stride_w != 1 || p.pad_h != 0 || p.pad_w != 0) return false;
+    if (p.out_stride_w != p.cout || p.out_stride_h != (long long)p.wo * p.cout || p.out_stride_n != (long long)p.ho * p.wo * p.cout) return false;  // dense output rows
+    const int nk = a.K / 64;
+    if (nk < 48) return false;  // the partial sums (tail rows x cout x 4 B x ksplit, written and read once) must be small beside the K loop
+    const int id = conv64_pick_tile(a);
+    const TileCfg* c = nullptr;
+    for (const TileCfg& k : kTileCfgs) if (k.id == id) c = &k;
+    if (!c) return false;
+    const long long tiles_m = (a.M + c->bm - 1) / c->bm, tiles_n = (p.cout + c->bn - 1) / c->bn, tiles = tiles_m * tiles_n, slots = 256ll * c->occ;
+    const long long full = tiles / slots, rem = tiles % slots;
+    if (full < 1 || rem == 0 || rem * 2 > slots) return false;
+    const long long tail_mt = (rem + tiles_n - 1) / tiles_n;  // whole rows of M tiles
+    long long ks = slots / (tail_mt * tiles_n);
+    if (ks > 8) ks = 8;
+    if (ks > nk / 8) ks = nk / 8;
+    if (ks < 2) return false;
+    sp->tile_id = id; sp->tail_mtiles = (int)tail_mt; sp->ksplit = (int)ks;
+    sp->m_tail0 = (tiles_m - tail_mt) * c->bm;
+    sp->ws_bytes = ks * (a.M - sp->m_tail0) * p.cout * 4;
+    return true;
+}
+
+template <class TO>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, long long split_stride, long long n4, int cout,
+                                                            const float* __restrict__ bias, int relu, TO* __restrict__ out) {
+    // out[i] = act(sum_s ws[s][i] + bias[i % cout]), four elements per thread (cout % 8 == 0)
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 v = *reinterpret_cast<const float4*>(ws + i * 4);
+        for (int s = 1; s < ksplit; ++s) {
+            const float4 u = *reinterpret_cast<const float4*>(ws + s * split_stride + i * 4);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        const float4 b = *reinterpret_cast<const float4*>(bias + (int)((i * 4) % cout));
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        out[i * 4 + 0] = osr_from_float<TO>(v.x); out[i * 4 + 1] = osr_from_float<TO>(v.y);
+        out[i * 4 + 2] = osr_from_float<TO>(v.z); out[i * 4 + 3] = osr_from_float<TO>(v.w);
+    }
+}
+
+template <class TI, class TO> static void conv64_dispatch_tile(int id, Conv64Args& a, hipStream_t st);
+
 template <class TI, class TO>
 static osr_status conv64_launch(Conv64Args& a, hipStream_t st) {
     a.tail_lds_off = 0;
-    switch (conv64_pick_tile(a)) {
+    a.tile0 = 0; a.ntile = 0; a.ksplit = 1; a.split_stride = 0;
+    SplitPlan sp;
+    if (a.p.workspace && conv64_plan_split(a, &sp) && a.p.workspace_bytes >= sp.ws_bytes && (((uintptr_t)a.p.workspace) & 15) == 0) {
+        const TileCfg* c = nullptr;
+        for (const TileCfg& k : kTileCfgs) if (k.id == sp.tile_id) c = &k;
+        const int tiles_m = (int)((a.M + c->bm - 1) / c->bm), tiles_n = (a.p.cout + c->bn - 1) / c->bn;
+        // 1. the full rounds
+        Conv64Args m = a;
+        m.tile0 = 0; m.ntile = (tiles_m - sp.tail_mtiles) * tiles_n; m.ksplit = 1;
+        conv64_dispatch_tile<TI, TO>(sp.tile_id, m, st);
+        // 2. the tail tiles, ksplit workgroups each, raw fp32 partial sums into the workspace slabs (rows relative to m_tail0)
+        const long long tail_rows = a.M - sp.m_tail0;
+        Conv64Args t = a;
+        t.tile0 = m.ntile; t.ntile = sp.tail_mtiles * tiles_n; t.ksplit = sp.ksplit;
+        t.split_stride = tail_rows * a.p.cout;
+        t.out = reinterpret_cast<float*>(a.p.workspace) - sp.m_tail0 * a.p.cout;  // the epilogue adds row * cout: slab row 0 = output row m_tail0
+        t.p.relu = 0; t.p.out_dtype = OSR_F32;
+        conv64_dispatch_tile<TI, float>(sp.tile_id, t, st);
+        // 3. fixed-order sum of the slabs + bias + ReLU + conversion
+        const long long n4 = tail_rows * a.p.cout / 4;
+        long long blocks = (n4 + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel<TO>, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const float*>(a.p.workspace), sp.ksplit,
+                           t.split_stride, n4, a.p.cout, a.bias, a.p.relu, reinterpret_cast<TO*>(a.out) + sp.m_tail0 * a.p.cout);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { osr_set_error("osr_conv2d_fwd(bk64, split-K tail): launch failed: %s", hipGetErrorString(e)); return OSR_ERR_LAUNCH; }
+        return OSR_OK;
+    }
+    conv64_dispatch_tile<TI, TO>(conv64_pick_tile(a), a, st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { osr_set_error("osr_conv2d_fwd(bk64): launch failed: %s", hipGetErrorString(e)); return OSR_ERR_LAUNCH; }
+    return OSR_OK;
+}
+
+template <class TI, class TO>
+static void conv64_dispatch_tile(int id, Conv64Args& a, hipStream_t st) {
+    switch (id) {
         case T128x128_1: conv64_launch_tile<TI, TO, 128, 128, 2, 2, 0>(a, st); break;
         case T128x128_2: conv64_launch_tile<TI, TO, 128, 128, 2, 2, 1>(a, st); break;
         case T256x256_2: conv64_launch_tile<TI, TO, 256, 256, 2, 4, 1>(a, st); break;
@@ -602,17 +704,28 @@ static osr_status conv64_launch(Conv64Args& a, hipStream_t st) {
         case T128x64_1: conv64_launch_tile<TI, TO, 128, 64, 4, 1, 0>(a, st); break;
         default: conv64_launch_tile<TI, TO, 128, 64, 4, 1, 1>(a, st); break;
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { osr_set_error("osr_conv2d_fwd(bk64): launch failed: %s", hipGetErrorString(e)); return OSR_ERR_LAUNCH; }
-    return OSR_OK;
+}
+
+// Bytes of workspace with which osr_conv2d_fwd cuts this layer's partial last dispatch round along K (0: not applicable).
+long long osr_conv64_split_workspace_bytes(const osr_conv_params* p) {
+    Conv64Args a;
+    a.p = *p; a.mask = nullptr;
+    a.M = (long long)p->n * p->ho * p->wo;
+    a.K = p->kh * p->kw * p->cin;
+    a.stem = (p->pad_mode == 1 && p->cin == 32) ? 1 : 0;
+    SplitPlan sp;
+    if (p->cin % 64 != 0 || a.M >= (1ll << 31) - 1024) return 0;
+    return conv64_plan_split(a, &sp) ? sp.ws_bytes : 0;
 }
 
 template <class TI>
 static osr_status cfrpn_fused_launch(Conv64Args& a, hipStream_t st) {
     a.tiles_n = 1;
+    a.tile0 = 0; a.ksplit = 1; a.split_stride = 0;
     if ((a.M + 255) / 256 >= rpn_big_min_tiles() && a.K / 64 >= 8) {
         a.two_stage = 1;
         a.tiles_m = (int)((a.M + 255) / 256);
+        a.ntile = a.tiles_m;
         const size_t t_bytes = (size_t)256 * (256 + 8) * 2, stages = (size_t)2 * (256 + 256) * 128;
         a.tail_lds_off = (int)(t_bytes > stages ? t_bytes : stages);
         const size_t lds = (size_t)a.tail_lds_off + 5 * 256 * 4;
@@ -625,6 +738,7 @@ static osr_status cfrpn_fused_launch(Conv64Args& a, hipStream_t st) {
     }
     a.two_stage = 0;
     a.tiles_m = (int)((a.M + 127) / 128);
+    a.ntile = a.tiles_m;
     const size_t t_bytes = (size_t)128 * (256 + 8) * 2, stage = (size_t)(128 + 256) * 128;
     a.tail_lds_off = (int)(t_bytes > stage ? t_bytes : stage);
     const size_t lds = (size_t)a.tail_lds_off + 5 * 256 * 4;

@@ -33,6 +33,7 @@ class ConvParams(C.Structure):
         ("res_stride_n", C.c_int64), ("res_stride_h", C.c_int64), ("res_stride_w", C.c_int64),
         ("relu", C.c_int32), ("res_mode", C.c_int32), ("pad_mode", C.c_int32),
         ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("concurrency", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -62,6 +63,7 @@ PROTOTYPES = {
     "osr_stem_padded_width": (I32, [I32]),
     "osr_preprocess": (I32, [P, I32, I32, I32, I32, I32, I32, C.POINTER(C.c_float), C.POINTER(C.c_float), P, I32, P]),
     "osr_conv2d_fwd": (I32, [C.POINTER(ConvParams), P, P, P, P, P, P]),
+    "osr_conv2d_fwd_workspace_bytes": (I64, [C.POINTER(ConvParams)]),
     "osr_conv2d_fwd_masked": (I32, [C.POINTER(ConvParams), P, P, P, P, P, P, P]),
     "osr_maxpool3x3s2": (I32, [P, I32, I32, I32, I32, P, I32, P]),
     "osr_subsample2": (I32, [P, I32, I32, I32, I32, P, I32, P]),

@@ -60,6 +60,9 @@ _CONCURRENCY = [1]
 # bench.py's train_step leg sets this to a dict {"conv": 0.0, "wgrad": 0.0}: algorithmic FLOPs (2*M*K*N of the layer definition)
 # of every MFMA conv / FC launch (forward and data-gradient launches both go through conv2d) and of every weight-gradient launch
 FLOP_COUNT = None
+# osr_conv2d_fwd may cut the partial last dispatch round of a deep-K 1x1 / FC layer along K when it is handed a workspace
+# (include/osr.h); False keeps every layer a single launch (A/B runs)
+SPLIT_K_TAIL = True
 
 
 class concurrent_streams:
@@ -130,6 +133,12 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, stride: in
         if st != _lib.ERR_UNSUPPORTED:
             check(st, "osr_conv2d_fwd_masked")
             return out
+    ws = None
+    if SPLIT_K_TAIL and post_mask is None and res_mode == 0 and kh == 1 and kw == 1:
+        wsb = int(lib.osr_conv2d_fwd_workspace_bytes(C.byref(p)))  # > 0: a deep-K 1x1 / FC layer whose last dispatch round is mostly empty
+        if wsb > 0:
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+            p.workspace, p.workspace_bytes = ws.data_ptr(), wsb
     check(lib.osr_conv2d_fwd(C.byref(p), _p(x), _p(weight), _p(bias), _p(residual) if res_mode else None, _p(out), _stream()),
           "osr_conv2d_fwd")
     if post_mask is not None:

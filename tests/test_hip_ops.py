@@ -386,6 +386,42 @@ def test_roi_align_linear_ramp_is_exact(ops):
             assert out[ph, pw].item() == pytest.approx(0.5 * cx - 0.25 * cy + 3.0, rel=1e-5)
 
 
+def test_linear_split_k_tail_round(ops, osr):
+    """Deep-K FC layers whose tile grid leaves a mostly empty last dispatch round are cut along K for that round (three launches:
+    full rounds, ksplit partial-sum launches of the tail tiles, fixed-order reduction + epilogue). Same result as the single launch
+    up to the fp32 summation order of the tail rows, reproducible bit for bit, and equal to the fp64 reference at fp32 accuracy."""
+    gg = g(41)
+    m, k, n = 17000, 3072, 1024  # 67 x 4 tiles of 256 x 256 (or 133 x 8 of 128 x 128) on 256 x occ slots, 48 K slices
+    x = (torch.randn(m, k, generator=gg) * 0.5).half().to(DEV)
+    w = (torch.randn(n, k, generator=gg) / math.sqrt(k)).half().to(DEV)
+    b = torch.randn(n, generator=gg).to(DEV)
+    L = osr._lib
+    p = L.ConvParams()
+    p.n, p.hi, p.wi, p.cin, p.ho, p.wo, p.cout = 1, m, 1, k, m, 1, n
+    p.kh = p.kw = p.stride_h = p.stride_w = 1
+    p.in_stride_n, p.in_stride_h, p.in_stride_w = m * k, k, k
+    p.out_stride_n, p.out_stride_h, p.out_stride_w = m * n, n, n
+    p.in_dtype = p.out_dtype = L.OSR_F16
+    import ctypes
+    assert L.load().osr_conv2d_fwd_workspace_bytes(ctypes.byref(p)) > 0, "this shape must qualify for the split (otherwise the test tests nothing)"
+    try:
+        ops.SPLIT_K_TAIL = False
+        single = ops.linear(x, w, b, relu=True, out_dtype=torch.float32)
+        ops.SPLIT_K_TAIL = True
+        split = ops.linear(x, w, b, relu=True, out_dtype=torch.float32)
+        split2 = ops.linear(x, w, b, relu=True, out_dtype=torch.float32)
+        half = ops.linear(x, w, b, relu=True)
+    finally:
+        ops.SPLIT_K_TAIL = True
+    assert torch.equal(split, split2)  # fixed-order partial sums: bitwise reproducible
+    assert not torch.equal(split, single) or True  # (the tail rows are summed in another order; equality is allowed, not required)
+    ref = torch.relu(x.double() @ w.double().t() + b.double()).float()
+    assert_close(split, ref, rtol=1e-4, name="split-K linear")
+    assert_close(single, ref, rtol=1e-4, name="single-launch linear")
+    assert_close(half, ref, rtol=2.0 ** -10, atol=2.0 ** -10 * float(ref.abs().max()) * 0.01 + 1e-6, name="split-K linear, f16 out")
+    assert torch.equal(split[: 8192], single[: 8192])  # rows of the full rounds are untouched by the split
+
+
 # ------------------------------------------------------------------------------------------------------
 def test_box_predictor_tail(ops):
     gg = g(31)
