@@ -131,7 +131,9 @@ template <> __device__ __forceinline__ void store8_64<bf16_t>(bf16_t* p, const f
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <class TI, class TO, int BM, int BN, int WM, int WN, int EPI, int TWO>
+// SPLIT = 1: the split-K tail launch (fp32 partial sums of a K range per workgroup); a template parameter so that the ordinary
+// instantiations carry none of its registers (four more VGPRs cost the 128 x 128 single-buffer kernel its third wave per SIMD).
+template <class TI, class TO, int BM, int BN, int WM, int WN, int EPI, int TWO, int SPLIT = 0>
 __global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI != 0) ? 2 : C64_SINGLE_MINW) void conv_igemm64_kernel(Conv64Args a) {  // waves per SIMD the register budget must allow
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int NW = WM * WN, NT = NW * 64;  // waves / threads per workgroup (4 or 8 waves)
@@ -156,8 +158,8 @@ __global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI !=
         const int b = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int ksp = a.ksplit > 1 ? t / a.ntile : 0;  // which K range of the tile (split-K tail launches only)
-    t = a.tile0 + (a.ksplit > 1 ? t % a.ntile : t);
+    int ksp = 0;  // which K range of the tile (split-K tail launches only)
+    if constexpr (SPLIT) { ksp = t / a.ntile; t = a.tile0 + t % a.ntile; }
     const int tile_n = t % a.tiles_n, tile_m = t / a.tiles_n;
     const long long m0 = (long long)tile_m * BM;
     const int n0 = tile_n * BN;
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI !=
 #define C64_COL(r) ((((r) >> 2) & 1) * 16 + (lane & 15))
 
     int nk = a.K / 64;
-    if (a.ksplit > 1) {  // this workgroup's share of the K slices (1x1 / FC layers only: the slice index is the channel block)
+    if constexpr (SPLIT) {  // this workgroup's share of the K slices (1x1 / FC layers only: the slice index is the channel block)
         const int k_lo = (int)((long long)ksp * nk / a.ksplit), k_hi = (int)((long long)(ksp + 1) * nk / a.ksplit);
         c0 = k_lo * 64; kbyte = k_lo * 128; tap_off = (unsigned)(c0 * 2);
         nk = k_hi - k_lo;
@@ -283,8 +285,8 @@ __global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI !=
             const int co = n0 + (wc * TN + jp * 2) * 32 + cseg;
             const int cb = co < p.cout ? co : 0;
             const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 b0 = a.ksplit > 1 ? zero4 : *reinterpret_cast<const float4*>(a.bias + cb);
-            const float4 b1 = a.ksplit > 1 ? zero4 : *reinterpret_cast<const float4*>(a.bias + cb + 4);
+            const float4 b0 = SPLIT ? zero4 : *reinterpret_cast<const float4*>(a.bias + cb);
+            const float4 b1 = SPLIT ? zero4 : *reinterpret_cast<const float4*>(a.bias + cb + 4);
             bias8[jp][0] = b0.x; bias8[jp][1] = b0.y; bias8[jp][2] = b0.z; bias8[jp][3] = b0.w;
             bias8[jp][4] = b1.x; bias8[jp][5] = b1.y; bias8[jp][6] = b1.z; bias8[jp][7] = b1.w;
         }
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI !=
     // ---- epilogue: wave-private fp32 slab (32 rows x 64 columns, one pair of N tiles at a time) -> 8 channels per lane:
     //      bias + residual / FPN 2x upsample-add + ReLU + convert on 16-byte row segments, coalesced along channels ----
     float* slab = reinterpret_cast<float*>(lds) + wid * 32 * EPI_LD;
-    TO* __restrict__ out = reinterpret_cast<TO*>(a.out) + (a.ksplit > 1 ? (long long)ksp * a.split_stride : 0ll);
+    TO* __restrict__ out = reinterpret_cast<TO*>(a.out) + (SPLIT ? (long long)ksp * a.split_stride : 0ll);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -532,7 +534,7 @@ static void allow_big_lds(K kernel) {
 enum Conv64Tile { T128x128_1 = 1, T128x128_2, T256x256_2, T128x256_1, T256x128_1, T128x64_1, T128x64_2 };
 static int force_tile() { return OSR_KNOB("OSR_CONV_FORCE_TILE", 0); }  // diagnostic: one configuration for every layer it fits
 
-template <class TI, class TO, int BM, int BN, int WM, int WN, int TWO>
+template <class TI, class TO, int BM, int BN, int WM, int WN, int TWO, int SPLIT = 0>
 static void conv64_launch_tile(Conv64Args& a, hipStream_t st) {
     constexpr int NW = WM * WN;
     a.two_stage = TWO;
@@ -542,9 +544,9 @@ static void conv64_launch_tile(Conv64Args& a, hipStream_t st) {
     const size_t lds = conv64_lds_bytes(BM, BN, TWO, NW);
     if (lds > 64 * 1024) {
         static osr_dev_mask attr{0};
-        osr_once_per_device(attr, [] { allow_big_lds(conv_igemm64_kernel<TI, TO, BM, BN, WM, WN, 0, TWO>); });
+        osr_once_per_device(attr, [] { allow_big_lds(conv_igemm64_kernel<TI, TO, BM, BN, WM, WN, 0, TWO, SPLIT>); });
     }
-    hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, BM, BN, WM, WN, 0, TWO>), dim3((unsigned)a.ntile * (a.ksplit > 1 ? a.ksplit : 1)), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, BM, BN, WM, WN, 0, TWO, SPLIT>), dim3((unsigned)a.ntile * (SPLIT ? a.ksplit : 1)), dim3(NW * 64), lds, st, a);
 }
 
 // Tile choice by a small cost model instead of per-layer thresholds. Measured on MI355X (scripts/ab_tiles.sh): with the
@@ -619,6 +621,7 @@ static bool conv64_plan_split(const Conv64Args& a, SplitPlan* sp) {
     const int nk = a.K / 64;
     if (nk < 48) return false;  // the partial sums (tail rows x cout x 4 B x ksplit, written and read once) must be small beside the K loop
     const int id = conv64_pick_tile(a);
+    if (id != T256x256_2 && id != T128x128_1 && id != T128x256_1) return false;  // the tile shapes with a split-K tail instantiation
     const TileCfg* c = nullptr;
     for (const TileCfg& k : kTileCfgs) if (k.id == id) c = &k;
     if (!c) return false;
@@ -676,7 +679,11 @@ static osr_status conv64_launch(Conv64Args& a, hipStream_t st) {
         t.split_stride = tail_rows * a.p.cout;
         t.out = reinterpret_cast<float*>(a.p.workspace) - sp.m_tail0 * a.p.cout;  // the epilogue adds row * cout: slab row 0 = output row m_tail0
         t.p.relu = 0; t.p.out_dtype = OSR_F32;
-        conv64_dispatch_tile<TI, float>(sp.tile_id, t, st);
+        switch (sp.tile_id) {
+            case T256x256_2: conv64_launch_tile<TI, float, 256, 256, 2, 4, 1, 1>(t, st); break;
+            case T128x256_1: conv64_launch_tile<TI, float, 128, 256, 2, 2, 0, 1>(t, st); break;
+            default: conv64_launch_tile<TI, float, 128, 128, 2, 2, 0, 1>(t, st); break;
+        }
         // 3. fixed-order sum of the slabs + bias + ReLU + conversion
         const long long n4 = tail_rows * a.p.cout / 4;
         long long blocks = (n4 + 255) / 256;
