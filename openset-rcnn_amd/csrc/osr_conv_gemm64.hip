@@ -783,6 +783,23 @@ int osr_conv64_describe(const osr_conv_params* p, int has_workspace, char* buf, 
     return snprintf(buf, n, "%dx%d/%d rows [0,%lld) + %dx%d/%d rows [%lld,%lld)", c1.bm, c1.bn, c1.two + 1, rows_main, c2.bm, c2.bn, c2.two + 1, rows_main, a.M);
 }
 
+// Host-side description of how osr_conv2d_fwd covers this layer (tests).
+int osr_conv64_describe(const osr_conv_params* p, int has_workspace, char* buf, int n) {
+    Conv64Args a;
+    a.p = *p; a.mask = nullptr;
+    a.M = (long long)p->n * p->ho * p->wo;
+    a.K = p->kh * p->kw * p->cin;
+    a.stem = (p->pad_mode == 1 && p->cin == 32) ? 1 : 0;
+    auto nm = [](int id) { for (const TileCfg& k : kTileCfgs) if (k.id == id) return k; return kTileCfgs[0]; };
+    SplitPlan sp;
+    if (has_workspace && conv64_plan_split(a, &sp)) {
+        const TileCfg c = nm(sp.tile_id);
+        return snprintf(buf, n, "%dx%d/%d rows [0,%lld) + split-K x%d tail rows [%lld,%lld) + reduce", c.bm, c.bn, c.two + 1, sp.m_tail0, sp.ksplit, sp.m_tail0, a.M);
+    }
+    const TileCfg c1 = nm(conv64_pick_tile(a));
+    return snprintf(buf, n, "%dx%d/%d rows [0,%lld)", c1.bm, c1.bn, c1.two + 1, a.M);
+}
+
 // Bytes of workspace with which osr_conv2d_fwd cuts this layer's partial last dispatch round along K (0: not applicable).
 long long osr_conv64_split_workspace_bytes(const osr_conv_params* p) {
     Conv64Args a;

@@ -439,6 +439,9 @@ def test_linear_split_k_tail_round(ops, osr):
     p.in_dtype = p.out_dtype = L.OSR_F16
     import ctypes
     assert L.load().osr_conv2d_fwd_workspace_bytes(ctypes.byref(p)) > 0, "this shape must qualify for the split (otherwise the test tests nothing)"
+    buf = ctypes.create_string_buffer(256)
+    L.load().osr_conv2d_fwd_describe(ctypes.byref(p), 1, buf, 256)
+    assert "split-K" in buf.value.decode() and "reduce" in buf.value.decode(), buf.value
     try:
         ops.SPLIT_K_TAIL = False
         single = ops.linear(x, w, b, relu=True, out_dtype=torch.float32)
