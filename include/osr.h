@@ -93,10 +93,6 @@ int64_t osr_conv2d_fwd_workspace_bytes(const osr_conv_params* p);
  * (has_workspace != 0). Writes a short text ("256x256/2 rows [0,65536) + split-K x5 tail rows [65536,68368) + reduce") and
  * returns its length; host-side only (diagnostics, tests). */
 int32_t osr_conv2d_fwd_describe(const osr_conv_params* p, int32_t has_workspace, char* buf, int32_t buf_bytes);
-/* How osr_conv2d_fwd covers this layer: one launch, two launches with different tile shapes over disjoint row ranges (a mostly
- * empty last dispatch round goes to a smaller tile), or full rounds + split-K tail + reduction (has_workspace != 0). Writes a
- * short text ("128x128/1 rows [0,49152) + 128x64/1 rows [49152,67200)") and returns its length; host-side only (diagnostics). */
-int32_t osr_conv2d_fwd_describe(const osr_conv_params* p, int32_t has_workspace, char* buf, int32_t buf_bytes);
 
 osr_status osr_conv2d_fwd(const osr_conv_params* p, const void* in, const void* weight, const float* bias,
                           const void* residual, void* out, void* stream);

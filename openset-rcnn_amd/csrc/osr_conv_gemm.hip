@@ -265,7 +265,6 @@ osr_status osr_conv_f32_run(const osr_conv_params* p, const void* in, const void
 int osr_conv64_eligible(const osr_conv_params* p, long long in_bytes, long long w_bytes);
 long long osr_conv64_split_workspace_bytes(const osr_conv_params* p);
 int osr_conv64_describe(const osr_conv_params* p, int has_workspace, char* buf, int n);
-int osr_conv64_describe(const osr_conv_params* p, int has_workspace, char* buf, int n);
 osr_status osr_conv64_run(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* residual, const void* mask,
                           void* out, long long in_bytes, long long w_bytes, hipStream_t st);
 
@@ -351,13 +350,6 @@ static osr_status conv2d_fwd_impl(const osr_conv_params* p, const void* in, cons
 extern "C" int64_t osr_conv2d_fwd_workspace_bytes(const osr_conv_params* p) {
     if (!p || (p->in_dtype != OSR_F16 && p->in_dtype != OSR_BF16) || p->n < 1 || p->ho < 1 || p->wo < 1 || p->cin < 64 || p->cout < 8 || p->cout % 8 != 0) return 0;
     return osr_conv64_split_workspace_bytes(p);
-}
-
-extern "C" int32_t osr_conv2d_fwd_describe(const osr_conv_params* p, int32_t has_workspace, char* buf, int32_t buf_bytes) {
-    if (!p || !buf || buf_bytes < 1) return OSR_ERR_INVALID_ARG;
-    if ((p->in_dtype != OSR_F16 && p->in_dtype != OSR_BF16) || p->cin % 64 != 0 || p->n < 1 || p->ho < 1 || p->wo < 1 || p->cout < 8)
-        return snprintf(buf, buf_bytes, "not on the BK=64 kernel");
-    return osr_conv64_describe(p, has_workspace, buf, buf_bytes);
 }
 
 extern "C" int32_t osr_conv2d_fwd_describe(const osr_conv_params* p, int32_t has_workspace, char* buf, int32_t buf_bytes) {

@@ -94,7 +94,6 @@ struct Conv64Args {
     // slices, which write raw fp32 partial sums (no bias / ReLU) into slab s = out + s * split_stride floats.
     int tile0, ntile, ksplit;
     long long split_stride;
-    int tile_m0;           // first M tile of this launch (a layer may be covered by two launches with different tile shapes over disjoint row ranges)
 #ifdef C64_STAMPS
     unsigned long long* dbg;
 #endif
@@ -161,7 +160,7 @@ __global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI !=
     }
     int ksp = 0;  // which K range of the tile (split-K tail launches only)
     if constexpr (SPLIT) { ksp = t / a.ntile; t = a.tile0 + t % a.ntile; }
-    const int tile_n = t % a.tiles_n, tile_m = t / a.tiles_n + a.tile_m0;
+    const int tile_n = t % a.tiles_n, tile_m = t / a.tiles_n;
     const long long m0 = (long long)tile_m * BM;
     const int n0 = tile_n * BN;
 
@@ -541,7 +540,7 @@ static void conv64_launch_tile(Conv64Args& a, hipStream_t st) {
     a.two_stage = TWO;
     a.tiles_m = (int)((a.M + BM - 1) / BM);
     a.tiles_n = (a.p.cout + BN - 1) / BN;
-    if (a.ntile <= 0) { a.tile0 = 0; a.ntile = (a.tiles_m - a.tile_m0) * a.tiles_n; a.ksplit = 1; }  // every tile from M tile tile_m0 on
+    if (a.ntile <= 0) { a.tile0 = 0; a.ntile = a.tiles_m * a.tiles_n; a.ksplit = 1; }  // the whole grid in one launch
     const size_t lds = conv64_lds_bytes(BM, BN, TWO, NW);
     if (lds > 64 * 1024) {
         static osr_dev_mask attr{0};
@@ -640,38 +639,6 @@ static bool conv64_plan_split(const Conv64Args& a, SplitPlan* sp) {
     return true;
 }
 
-// Two tile shapes over disjoint row ranges: when the chosen shape leaves a mostly empty last round (res4 / FPN p4 at batch 16:
-// 1050 tiles of 128 x 128 on 768 slots), the rows of the full rounds keep it and the remaining rows go to a second launch with a
-// smaller tile, whose partial round is short. No partial sums: both launches write their own output rows.
-static void conv64_plan_rows(const Conv64Args& a, int* id1_out, int* id2_out, long long* rows_main_out) {
-    const int id1 = conv64_pick_tile(a);
-    int id2 = 0;
-    long long rows_main = 0;
-    const TileCfg* c1 = nullptr;
-    for (const TileCfg& k : kTileCfgs) if (k.id == id1) c1 = &k;
-    const int nk = a.K / 64;
-    const bool res = a.p.res_mode != 0;
-    const long long tiles_n1 = (a.p.cout + c1->bn - 1) / c1->bn, tiles1 = (a.M + c1->bm - 1) / c1->bm * tiles_n1, slots1 = 256ll * c1->occ;
-    const long long full1 = tiles1 / slots1, rem1 = tiles1 % slots1;
-    if (force_tile() == 0 && full1 >= 1 && rem1 != 0 && rem1 * 10 < slots1 * 8) {
-        const double single = (double)full1 * conv64_tile_us(*c1, nk, c1->occ, res) + conv64_tile_us(*c1, nk, (int)((rem1 + 255) / 256), res);
-        const long long mt_main = full1 * slots1 / tiles_n1;  // whole rows of M tiles inside the full rounds
-        double best = single * 0.93;  // (a second launch costs a kernel boundary: ask for a clear win)
-        for (const TileCfg& c2 : kTileCfgs) {
-            if (c2.bm * c2.bn >= c1->bm * c1->bn || c2.bm > c1->bm || (res && !c2.pre_res) || (c2.two && nk < 2)) continue;
-            if (c2.bn == 256 && a.p.cout % 256 != 0) continue;
-            const long long rows = a.M - mt_main * c1->bm;
-            if (rows <= 0) continue;
-            const long long tiles2 = (rows + c2.bm - 1) / c2.bm * ((a.p.cout + c2.bn - 1) / c2.bn), slots2 = 256ll * c2.occ;
-            const long long full2 = tiles2 / slots2, rem2 = tiles2 % slots2;
-            double us = (double)(mt_main * tiles_n1 / slots1) * conv64_tile_us(*c1, nk, c1->occ, res) + 1.5 + (double)full2 * conv64_tile_us(c2, nk, c2.occ, res);
-            if (rem2) us += conv64_tile_us(c2, nk, (int)((rem2 + 255) / 256), res);
-            if (us < best) { best = us; id2 = c2.id; rows_main = mt_main * c1->bm; }
-        }
-    }
-    *id1_out = id1; *id2_out = id2; *rows_main_out = rows_main;
-}
-
 template <class TO>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, long long split_stride, long long n4, int cout,
                                                             const float* __restrict__ bias, int relu, TO* __restrict__ out) {
@@ -695,7 +662,7 @@ template <class TI, class TO> static void conv64_dispatch_tile(int id, Conv64Arg
 template <class TI, class TO>
 static osr_status conv64_launch(Conv64Args& a, hipStream_t st) {
     a.tail_lds_off = 0;
-    a.tile0 = 0; a.ntile = 0; a.ksplit = 1; a.split_stride = 0; a.tile_m0 = 0;
+    a.tile0 = 0; a.ntile = 0; a.ksplit = 1; a.split_stride = 0;
     SplitPlan sp;
     if (a.p.workspace && conv64_plan_split(a, &sp) && a.p.workspace_bytes >= sp.ws_bytes && (((uintptr_t)a.p.workspace) & 15) == 0) {
         const TileCfg* c = nullptr;
@@ -727,22 +694,7 @@ static osr_status conv64_launch(Conv64Args& a, hipStream_t st) {
         if (e != hipSuccess) { osr_set_error("osr_conv2d_fwd(bk64, split-K tail): launch failed: %s", hipGetErrorString(e)); return OSR_ERR_LAUNCH; }
         return OSR_OK;
     }
-    int id1 = 0, id2 = 0;
-    long long rows_main = 0;
-    conv64_plan_rows(a, &id1, &id2, &rows_main);
-    if (id2 != 0) {
-        const TileCfg *c1 = nullptr, *c2 = nullptr;
-        for (const TileCfg& k : kTileCfgs) { if (k.id == id1) c1 = &k; if (k.id == id2) c2 = &k; }
-        Conv64Args m = a;
-        m.tile_m0 = 0; m.tile0 = 0; m.ksplit = 1;
-        m.ntile = (int)(rows_main / c1->bm) * ((a.p.cout + c1->bn - 1) / c1->bn);
-        conv64_dispatch_tile<TI, TO>(id1, m, st);
-        Conv64Args t = a;
-        t.tile_m0 = (int)(rows_main / c2->bm); t.ntile = 0;  // (ntile 0: conv64_launch_tile takes every tile from tile_m0 on)
-        conv64_dispatch_tile<TI, TO>(id2, t, st);
-    } else {
-        conv64_dispatch_tile<TI, TO>(id1, a, st);
-    }
+    conv64_dispatch_tile<TI, TO>(conv64_pick_tile(a), a, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { osr_set_error("osr_conv2d_fwd(bk64): launch failed: %s", hipGetErrorString(e)); return OSR_ERR_LAUNCH; }
     return OSR_OK;
@@ -759,28 +711,6 @@ static void conv64_dispatch_tile(int id, Conv64Args& a, hipStream_t st) {
         case T128x64_1: conv64_launch_tile<TI, TO, 128, 64, 4, 1, 0>(a, st); break;
         default: conv64_launch_tile<TI, TO, 128, 64, 4, 1, 1>(a, st); break;
     }
-}
-
-// Host-side description of how osr_conv2d_fwd would cover this layer (tests): "<tile> rows [a,b)" per launch.
-int osr_conv64_describe(const osr_conv_params* p, int has_workspace, char* buf, int n) {
-    Conv64Args a;
-    a.p = *p; a.mask = nullptr;
-    a.M = (long long)p->n * p->ho * p->wo;
-    a.K = p->kh * p->kw * p->cin;
-    a.stem = (p->pad_mode == 1 && p->cin == 32) ? 1 : 0;
-    a.tile_m0 = 0;
-    auto nm = [](int id) { for (const TileCfg& k : kTileCfgs) if (k.id == id) return k; return kTileCfgs[0]; };
-    SplitPlan sp;
-    if (has_workspace && conv64_plan_split(a, &sp)) {
-        const TileCfg c = nm(sp.tile_id);
-        return snprintf(buf, n, "%dx%d/%d rows [0,%lld) + split-K x%d tail rows [%lld,%lld) + reduce", c.bm, c.bn, c.two + 1, sp.m_tail0, sp.ksplit, sp.m_tail0, a.M);
-    }
-    int id1, id2; long long rows_main;
-    conv64_plan_rows(a, &id1, &id2, &rows_main);
-    const TileCfg c1 = nm(id1);
-    if (id2 == 0) return snprintf(buf, n, "%dx%d/%d rows [0,%lld)", c1.bm, c1.bn, c1.two + 1, a.M);
-    const TileCfg c2 = nm(id2);
-    return snprintf(buf, n, "%dx%d/%d rows [0,%lld) + %dx%d/%d rows [%lld,%lld)", c1.bm, c1.bn, c1.two + 1, rows_main, c2.bm, c2.bn, c2.two + 1, rows_main, a.M);
 }
 
 // Host-side description of how osr_conv2d_fwd covers this layer (tests).
@@ -807,7 +737,6 @@ long long osr_conv64_split_workspace_bytes(const osr_conv_params* p) {
     a.M = (long long)p->n * p->ho * p->wo;
     a.K = p->kh * p->kw * p->cin;
     a.stem = (p->pad_mode == 1 && p->cin == 32) ? 1 : 0;
-    a.tile_m0 = 0;
     SplitPlan sp;
     if (p->cin % 64 != 0 || a.M >= (1ll << 31) - 1024) return 0;
     return conv64_plan_split(a, &sp) ? sp.ws_bytes : 0;
@@ -816,7 +745,7 @@ long long osr_conv64_split_workspace_bytes(const osr_conv_params* p) {
 template <class TI>
 static osr_status cfrpn_fused_launch(Conv64Args& a, hipStream_t st) {
     a.tiles_n = 1;
-    a.tile0 = 0; a.ksplit = 1; a.split_stride = 0; a.tile_m0 = 0;
+    a.tile0 = 0; a.ksplit = 1; a.split_stride = 0;
     if ((a.M + 255) / 256 >= rpn_big_min_tiles() && a.K / 64 >= 8) {
         a.two_stage = 1;
         a.tiles_m = (int)((a.M + 255) / 256);

@@ -65,7 +65,6 @@ PROTOTYPES = {
     "osr_conv2d_fwd": (I32, [C.POINTER(ConvParams), P, P, P, P, P, P]),
     "osr_conv2d_fwd_workspace_bytes": (I64, [C.POINTER(ConvParams)]),
     "osr_conv2d_fwd_describe": (I32, [C.POINTER(ConvParams), I32, P, I32]),
-    "osr_conv2d_fwd_describe": (I32, [C.POINTER(ConvParams), I32, P, I32]),
     "osr_conv2d_fwd_masked": (I32, [C.POINTER(ConvParams), P, P, P, P, P, P, P]),
     "osr_maxpool3x3s2": (I32, [P, I32, I32, I32, I32, P, I32, P]),
     "osr_subsample2": (I32, [P, I32, I32, I32, I32, P, I32, P]),

@@ -386,41 +386,6 @@ def test_roi_align_linear_ramp_is_exact(ops):
             assert out[ph, pw].item() == pytest.approx(0.5 * cx - 0.25 * cy + 3.0, rel=1e-5)
 
 
-def test_conv2d_two_tile_shapes_over_row_ranges(ops, osr):
-    """A grid that leaves a mostly empty last dispatch round (res4 / FPN p4 at batch 16: 1050 tiles of 128 x 128 on 768 slots) is
-    covered by two launches with different tile shapes over disjoint row ranges (osr_conv2d_fwd_describe says so); the result is
-    the single-shape result, checked against the fp32 reference -- 3x3 without residual, 1x1 with the FPN upsample-add."""
-    import ctypes
-    L = osr._lib
-    gg = g(57)
-    n, h, w = 16, 50, 84
-    for cin, cout, k, res_mode in ((256, 256, 3, 0), (1024, 256, 1, 2)):
-        p = L.ConvParams()
-        p.n, p.hi, p.wi, p.cin, p.ho, p.wo, p.cout = n, h, w, cin, h, w, cout
-        p.kh = p.kw = k
-        p.stride_h = p.stride_w = 1
-        p.pad_h = p.pad_w = k // 2
-        p.in_stride_n, p.in_stride_h, p.in_stride_w = h * w * cin, w * cin, cin
-        p.out_stride_n, p.out_stride_h, p.out_stride_w = h * w * cout, w * cout, cout
-        p.in_dtype = p.out_dtype = L.OSR_F16
-        p.res_mode = res_mode
-        buf = ctypes.create_string_buffer(256)
-        L.load().osr_conv2d_fwd_describe(ctypes.byref(p), 0, buf, 256)
-        plan = buf.value.decode()
-        assert " + " in plan and "rows [0,49152)" in plan, plan  # two row ranges, the first one = the full rounds
-        x = torch.randn(n, cin, h, w, generator=gg).half()
-        wt = (torch.randn(cout, cin, k, k, generator=gg) / math.sqrt(cin * k * k)).half()
-        b = torch.randn(cout, generator=gg)
-        res = torch.randn(n, cout, (h + 1) // 2, (w + 1) // 2, generator=gg).half() if res_mode == 2 else None
-        out = ops.conv2d(nhwc(x).to(DEV), wt.permute(0, 2, 3, 1).contiguous().to(DEV), b.to(DEV), pad=k // 2, relu=True,
-                         residual=None if res is None else nhwc(res).to(DEV), res_mode=res_mode, out_dtype=torch.float32)
-        ref = F.conv2d(x.float().to(DEV), wt.float().to(DEV), b.to(DEV), padding=k // 2)  # fp32 reference of the tensor library on the same box
-        if res is not None:
-            ref = ref + F.interpolate(res.float().to(DEV), scale_factor=2.0, mode="nearest")[:, :, :h, :w]
-        ref = F.relu(ref)
-        assert_close(out.permute(0, 3, 1, 2), ref, rtol=2e-4, name=f"two-range conv {cin}->{cout} k{k}")
-
-
 def test_linear_split_k_tail_round(ops, osr):
     """Deep-K FC layers whose tile grid leaves a mostly empty last dispatch round are cut along K for that round (three launches:
     full rounds, ksplit partial-sum launches of the tail tiles, fixed-order reduction + epilogue). Same result as the single launch
