@@ -90,6 +90,42 @@ def cpu_baseline(params, batch: int, one_thread: bool):
                 points=points)
 
 
+def measure_traffic(timeout_s: int = 150):
+    """HBM-side traffic of the two kernel groups, measured in this run: two child passes of this very script under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (counters only, separate passes, as MI355X_MICROARCH.md prescribes; FETCH_SIZE
+    doubled for gfx950), eager single stream so that every launch is one dispatch. Returns (conv family GB per step, roi_align GB per
+    step, source text) or None when rocprofv3 is unavailable or a pass fails (the committed profile is quoted instead)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        import pmc_summary as PS
+        steps, warm = 2, 1
+        passes = steps + warm + 2 + 0.25  # + the un-timed and the bracketed attribution pass + the 4-image calibration pass
+        out = {}
+        with tempfile.TemporaryDirectory(prefix="osr_pmc_", dir="/tmp") as tmp:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = os.path.join(tmp, counter)
+                cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "run", "--", sys.executable,
+                       os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--no-train-step", "--no-pmc",
+                       "--streams", "1", "--no-graph"]
+                env = dict(os.environ, TMPDIR="/tmp")
+                r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, env=env, cwd="/tmp")
+                if r.returncode != 0:
+                    return None
+                out[counter] = PS.counter_sum(d, passes)
+        conv = lambda c, f: sum(v[0] for k, v in out[c].items() if k.startswith("conv_igemm") or k.startswith("splitk_reduce")) * 1024 * f / 1e9  # noqa: E731
+        roi = lambda c, f: sum(v[0] for k, v in out[c].items() if k.startswith("roi_align")) * 1024 * f / 1e9  # noqa: E731
+        return (round(conv("FETCH_SIZE", 2) + conv("WRITE_SIZE", 1), 2), round(roi("FETCH_SIZE", 2) + roi("WRITE_SIZE", 1), 2),
+                "measured in this run: two child passes of `bench.py --steps 2 --warmup 1 --streams 1 --no-graph` under rocprofv3 --pmc FETCH_SIZE "
+                "(x2, gfx950) / --pmc WRITE_SIZE, separate passes")
+    except Exception:  # noqa: BLE001  (profiler missing pieces, time-out, parse error: fall back to the committed profile)
+        return None
+
+
 def synthetic_gt(n: int, h: int, w: int, per_image: int = 8, seed: int = 0):
     """BASELINE.md section 3 / SURVEY.md 8d: 8 boxes per image, sizes uniform in 32-512 px, classes uniform in [0, 20), seed 0."""
     g = torch.Generator().manual_seed(seed)
@@ -159,6 +195,7 @@ def main():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true", help="skip the config-3 train-step leg")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure HBM traffic with rocprofv3 child passes (quote the committed profile)")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--streams", type=int, default=2, help="micro-batch streams inside one GPU (1 = single stream)")
@@ -278,6 +315,10 @@ def main():
                 hbm_traffic = round(ra.get("fetch_GB_per_step_x2corrected", 0.0) + ra.get("write_GB_per_step", 0.0), 2)
             traffic_source = f"profiles/{tag}_kernel_times_and_traffic.json (scripts/profile_round.sh: --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
             break
+    if world == 1 and rank == 0 and not args.no_pmc:
+        live = measure_traffic()
+        if live is not None:
+            traffic, hbm_traffic, traffic_source = live
     algo_bytes = sum(nb for _, _, _, _, nb in prof)
     roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic,
                     traffic_unit="GB of HBM traffic per step of the same kernel family (all its launches)", traffic_source=traffic_source,
@@ -301,7 +342,8 @@ def main():
     hbm_gbs = hbm_bytes / hbm_ms / 1e6 if hbm_ms > 0 else 0.0
     roofline_hbm = dict(bound="hbm", group="RoIAlign + proposal selection + NMS (SURVEY.md 8d)", achieved=round(hbm_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(hbm_gbs / HBM_PEAK_GBS, 4), algorithmic_GB_per_step=round(hbm_bytes / 1e9, 3), kernel_ms_per_step=round(hbm_ms, 3),
-                        traffic=hbm_traffic, traffic_unit="GB of HBM traffic per step of roi_align_kernel (FETCH_SIZE x2 + WRITE_SIZE)", kernels=kernels)
+                        traffic=hbm_traffic, traffic_unit="GB of HBM traffic per step of roi_align_kernel (FETCH_SIZE x2 + WRITE_SIZE)",
+                        traffic_source=traffic_source, kernels=kernels)
     if args.layers and rank == 0:
         for name, f, e0, e1, nb in prof:
             ms_ = e0.elapsed_time(e1)
