@@ -241,13 +241,13 @@ def main():
     params = random_params(0)
     cal = OpensetRCNNEngine(params, dtype=tdt, device=dev)
     keep = {}
-    cal.forward_device(images[:4], image_hw[:4], 800, 1344, keep)
+    # (the calibration images are the same on every rank -- seed 1234, rank 0's stream -- so that every rank derives the same
+    # bias without a collective: identical weights by construction)
+    cal_images = torch.randint(0, 256, (4, 3, 800, 1333), generator=torch.Generator().manual_seed(1234), dtype=torch.uint8).to(dev)
+    cal.forward_device(cal_images, image_hw[:4], 800, 1344, keep)
     cnt = keep["cnt1"].cpu()
     emb = torch.cat([keep["emb"].view(4, -1, keep["emb"].shape[-1])[i, :int(cnt[i])] for i in range(4)]).cpu()
-    if dist is not None:  # every rank uses rank 0's calibration: identical weights
-        blob = [emb if rank == 0 else None]
-        dist.broadcast_object_list(blob, src=0)
-        emb = blob[0]
+    del cal_images
     params = with_known_unknown_mix(params, emb)
     del cal, keep
     eng = OpensetRCNNEngine(params, dtype=tdt, device=dev)

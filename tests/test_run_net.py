@@ -196,3 +196,23 @@ def test_graspnet_configuration_trains_and_evaluates_on_a_coco_layout_toy_set(os
     inf = os.path.join(out, "inference", "graspnet_test_1", "Final")
     assert os.path.isdir(inf) and any(f.endswith(".json") for f in os.listdir(inf))
     assert run_net.main(common + ["--resume_test"] + opts) == 0
+
+
+@pytest.mark.gpu
+def test_two_rank_training_rehearsal_over_gloo(osr, toy_voc_root, tmp_path):
+    """The N > 1 training path end to end with two processes on this one GPU (gloo instead of RCCL, which needs one GPU per rank):
+    torchrun launch, sharded train loader, the bucketed gradient all-reduce issued from inside the HIP backward (async_op on the
+    device buffer), the loss reduce of train.py:139, rank-0 checkpoints, sharded evaluation. Both ranks must finish and agree."""
+    import subprocess
+    out = str(tmp_path / "out2")
+    env = dict(os.environ, DETECTRON2_DATASETS=toy_voc_root, OSR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+           os.path.join(ROOT, "run_net.py"), "--config-file", os.path.join(ROOT, "configs", "voc_coco.yaml"), "--opendet-benchmark", "--test-batch", "2",
+           "OUTPUT_DIR", out, "SEED", "3", "DATASETS.TRAIN", "('voc_2007_train',)", "DATASETS.TEST", "('voc_2007_test',)", "SOLVER.IMS_PER_BATCH", "2",
+           "SOLVER.BASE_LR", "0.00005", "SOLVER.WARMUP_ITERS", "0", "SOLVER.CHECKPOINT_PERIOD", "0", "SOLVER.MAX_ITER", "3", "INPUT.MIN_SIZE_TRAIN", "(96,)",
+           "INPUT.MAX_SIZE_TRAIN", "128", "INPUT.MIN_SIZE_TEST", "96", "INPUT.MAX_SIZE_TEST", "128"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    blob = torch.load(os.path.join(out, "model_final.pth"), map_location="cpu", weights_only=False)
+    assert blob["iteration"] == 2 and all(torch.isfinite(v).all() for v in blob["model"].values() if v.is_floating_point())
+    assert os.path.isdir(os.path.join(out, "inference", "voc_2007_test", "Final"))
