@@ -167,3 +167,28 @@ def test_fast_mode_detection_agreement_is_reported(world):
     _, dets_bf = _run(world, torch.bfloat16)
     _report("fast mode, bf16 storage", dets_bf, ref)
     assert frac >= 0.5 and lfrac >= frac, (frac, lfrac)
+
+
+def test_parity_mode_at_benchmark_resolution(osr):
+    """One 3x800x1333 image (the benchmark's input size: 89 523 anchors, 4273 proposals) through the parity mode against the fp32
+    oracle: the same agreement bar as at 256x384, so the result does not hinge on small feature maps."""
+    from openset_rcnn_amd.host.engine import OpensetRCNNEngine
+    from openset_rcnn_amd.host.weights import random_params, with_known_unknown_mix
+    g = torch.Generator().manual_seed(77)
+    image = torch.randint(0, 256, (1, 3, 800, 1333), generator=g, dtype=torch.uint8)
+    base = random_params(0)
+    keep = {}
+    eng = OpensetRCNNEngine(base, dtype=torch.float32, device=DEV)
+    eng.forward(image.to(DEV), [(800, 1333)], keep=keep)
+    params = with_known_unknown_mix(base, keep["emb"][: int(keep["cnt1"][0])])
+    del eng, keep
+    with torch.no_grad():
+        ref = O.detector_inference([image[0]], params, params, roi_align_fn=CO.roi_align)
+    eng = OpensetRCNNEngine(params, dtype=torch.float32, device=DEV)
+    out = eng.forward(image.to(DEV), [(800, 1333)])
+    torch.cuda.synchronize()
+    d = eng.to_instances(out, 1)[0]
+    m, c, ng, nr = agreement((d["pred_boxes"], d["scores"], d["pred_classes"]), ref[0])
+    print(f"\n[parity mode, 800x1333] {m}/{nr} oracle detections matched ({c} with the same class), engine returned {ng}; "
+          f"known {int((ref[0][2] != 80).sum())} / unknown {int((ref[0][2] == 80).sum())}")
+    assert nr > 50 and m >= 0.95 * max(nr, ng) and c == m
