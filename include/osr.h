@@ -116,6 +116,13 @@ osr_status osr_subsample2(const void* in, int32_t n, int32_t hi, int32_t wi, int
  * prototype_learning_network.py:204-205; cls_score, softmax_classifier.py:306). lda/ldo in elements. */
 osr_status osr_gemm_f32(const float* a, int64_t lda, const float* w, const float* bias, float* out, int64_t ldo,
                         int32_t m, int32_t n, int32_t k, int32_t relu, void* stream);
+/* fp32 out[m,n] = sum_k a[k,m] * b[k,n] on the exact-f32 MFMA: dW = dy^T x of the same layers in the training step (the
+ * autograd backward of F.linear at prototype_learning_network.py:204-205, softmax_classifier.py:306), operands as they lie
+ * (row = sample). The sample axis is split over workgroups when `workspace` holds osr_gemm_f32_tn_workspace_bytes(m,n,k);
+ * the partial sums are added in split order. */
+int64_t osr_gemm_f32_tn_workspace_bytes(int32_t m, int32_t n, int32_t k);
+osr_status osr_gemm_f32_tn(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int32_t m,
+                           int32_t n, int32_t k, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * CF-RPN head tail: ClsFreeRPNHead.forward after the 3x3 conv+ReLU (classification_free_rpn.py:159-161):
@@ -194,6 +201,21 @@ typedef struct osr_pyramid {
 osr_status osr_roi_align_fwd(const osr_pyramid* feats, int32_t feat_dtype, int32_t n, const float* boxes,
                              const int32_t* batch_idx, int64_t m, int32_t pooled, int32_t canonical_level,
                              int32_t canonical_size, int32_t min_level, void* out, int32_t out_dtype, void* stream);
+
+/* The same with an explicit processing order: `order` is a permutation of 0..m-1 (or NULL = list order); workgroup i pools RoI
+ * order[i] into ITS OWN row out[order[i]], so the result is bit-identical for every order. osr_roi_locality_order fills
+ * `order` so that RoIs that are neighbours in the image are neighbours in time on one XCD (bucket sort by image, pyramid level
+ * and 32x32-pixel tile of the box centre; the level rule is the one of osr_roi_align_fwd): the proposals of an image overlap
+ * each other several times over, and in score order every overlap is a re-read from HBM.
+ * workspace: osr_roi_locality_order_workspace_bytes(n, m) bytes. */
+osr_status osr_roi_align_fwd_ordered(const osr_pyramid* feats, int32_t feat_dtype, int32_t n, const float* boxes,
+                                     const int32_t* batch_idx, int64_t m, int32_t pooled, int32_t canonical_level,
+                                     int32_t canonical_size, int32_t min_level, const int32_t* order, void* out,
+                                     int32_t out_dtype, void* stream);
+int64_t osr_roi_locality_order_workspace_bytes(int32_t n, int64_t m);
+osr_status osr_roi_locality_order(const osr_pyramid* feats, int32_t n, const float* boxes, const int32_t* batch_idx, int64_t m,
+                                  int32_t canonical_level, int32_t canonical_size, int32_t min_level, int32_t* order,
+                                  void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Box predictor tail: OpensetFastRCNNOutputLayers.forward + predict_boxes + predict_ious

@@ -442,3 +442,124 @@ extern "C" osr_status osr_gemm_f32(const float* a, int64_t lda, const float* w, 
     OSR_CHECK_LAUNCH("osr_gemm_f32");
     return OSR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// out[m][n] = sum_k a[k][m] * b[k][n]: the weight-gradient product dW = dy^T x of an fp32 linear layer, both operands read as
+// they lie (row = sample), so no transposed copies. Same 64x64x16 tile and k-major LDS as gemm_f32_kernel (the staging is a
+// straight copy here). The sample axis is split over blockIdx.z: each split writes its partial tile to the workspace and
+// gemm_f32_tn_reduce adds the splits in index order (a fixed order: results do not depend on scheduling).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_f32_tn_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ B, long long ldb,
+                                                          float* __restrict__ out, long long ldo, long long split_stride, int M, int N, int K,
+                                                          int kchunk) {
+    __shared__ __attribute__((aligned(16))) float sA[2][16][G32_LD];
+    __shared__ __attribute__((aligned(16))) float sB[2][16][G32_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int k_lo = blockIdx.z * kchunk, k_hi = min(K, k_lo + kchunk);
+    const int lk = tid >> 4, l4 = (tid & 15) * 4;
+    const bool avec = (lda & 3) == 0 && m0 + 64 <= M && (((uintptr_t)A) & 15) == 0;
+    const bool bvec = (ldb & 3) == 0 && n0 + 64 <= N && (((uintptr_t)B) & 15) == 0;
+    auto fetch = [&](const float* P, long long ld, int c0, int C, bool vec, int k) -> float4 {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < k_hi) {
+            const float* p = P + (long long)k * ld + c0 + l4;
+            if (vec) v = *reinterpret_cast<const float4*>(p);
+            else {
+                if (c0 + l4 + 0 < C) v.x = p[0];
+                if (c0 + l4 + 1 < C) v.y = p[1];
+                if (c0 + l4 + 2 < C) v.z = p[2];
+                if (c0 + l4 + 3 < C) v.w = p[3];
+            }
+        }
+        return v;
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float4 ra = fetch(A, lda, m0, M, avec, k_lo + lk), rb = fetch(B, ldb, n0, N, bvec, k_lo + lk);
+    *reinterpret_cast<float4*>(&sA[0][lk][l4]) = ra;
+    *reinterpret_cast<float4*>(&sB[0][lk][l4]) = rb;
+    __syncthreads();
+    const int nk = (k_hi - k_lo + 15) / 16;
+    for (int ks = 0; ks < nk; ++ks) {
+        const bool more = ks + 1 < nk;
+        if (more) {
+            ra = fetch(A, lda, m0, M, avec, k_lo + (ks + 1) * 16 + lk);
+            rb = fetch(B, ldb, n0, N, bvec, k_lo + (ks + 1) * 16 + lk);
+        }
+        const int buf = ks & 1;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const float fa = sA[buf][kk * 2 + (lane >> 5)][wr * 32 + (lane & 31)];
+            const float fb = sB[buf][kk * 2 + (lane >> 5)][wc * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc, 0, 0, 0);
+        }
+        if (more) {
+            *reinterpret_cast<float4*>(&sA[buf ^ 1][lk][l4]) = ra;
+            *reinterpret_cast<float4*>(&sB[buf ^ 1][lk][l4]) = rb;
+        }
+        __syncthreads();
+    }
+    out += (long long)blockIdx.z * split_stride;
+    const int col = n0 + wc * 32 + (lane & 31);
+    if (col < N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < M) out[(long long)row * ldo + col] = acc[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_tn_reduce(const float* __restrict__ ws, long long split_stride, int splits, float* __restrict__ out,
+                                                          long long ldo, int M, int N) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)M * N) return;
+    float s = ws[i];
+    for (int k = 1; k < splits; ++k) s += ws[k * split_stride + i];
+    out[(i / N) * ldo + i % N] = s;
+}
+
+static int gemm_tn_splits(int m, int n, int k) {
+    const long long tiles = (long long)((m + 63) / 64) * ((n + 63) / 64);
+    long long s = (768 + tiles - 1) / tiles;                 // ~3 workgroups per CU
+    s = std::min<long long>(s, std::max(1, k / 128));        // at least 128 samples per split
+    return (int)std::max<long long>(1, std::min<long long>(s, 64));
+}
+
+extern "C" int64_t osr_gemm_f32_tn_workspace_bytes(int32_t m, int32_t n, int32_t k) {
+    if (m <= 0 || n <= 0 || k <= 0) return 0;
+    const int s = gemm_tn_splits(m, n, k);
+    return s > 1 ? (int64_t)s * m * n * 4 : 0;
+}
+
+extern "C" osr_status osr_gemm_f32_tn(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int32_t m, int32_t n,
+                                      int32_t k, void* workspace, int64_t workspace_bytes, void* stream) {
+    OSR_REQUIRE(a && b && out, OSR_ERR_INVALID_ARG, "osr_gemm_f32_tn: null pointer");
+    OSR_REQUIRE(m >= 1 && n >= 1 && k >= 0, OSR_ERR_INVALID_ARG, "osr_gemm_f32_tn: bad shape");
+    OSR_REQUIRE(lda >= m && ldb >= n && ldo >= n, OSR_ERR_INVALID_ARG, "osr_gemm_f32_tn: bad leading dimensions");
+    int splits = gemm_tn_splits(m, n, std::max(k, 1));
+    const int64_t per = (int64_t)m * n * 4;
+    if (!workspace || workspace_bytes < 2 * per) splits = 1;
+    else splits = (int)std::min<int64_t>(splits, workspace_bytes / per);
+    int kchunk = ((k + splits - 1) / splits + 15) / 16 * 16;
+    if (kchunk < 16) kchunk = 16;
+    splits = std::max(1, (k + kchunk - 1) / kchunk);
+    dim3 grid((n + 63) / 64, (m + 63) / 64, splits);
+    OSR_REQUIRE(grid.y <= 65535, OSR_ERR_UNSUPPORTED, "osr_gemm_f32_tn: m too large");
+    if (splits == 1) {
+        hipLaunchKernelGGL(gemm_f32_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, (long long)lda, b, (long long)ldb, out, (long long)ldo, 0LL, m, n,
+                           k, kchunk);
+        OSR_CHECK_LAUNCH("osr_gemm_f32_tn");
+        return OSR_OK;
+    }
+    hipLaunchKernelGGL(gemm_f32_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, (long long)lda, b, (long long)ldb, (float*)workspace, (long long)n,
+                       (long long)m * n, m, n, k, kchunk);
+    OSR_CHECK_LAUNCH("osr_gemm_f32_tn");
+    const long long tot = (long long)m * n;
+    hipLaunchKernelGGL(gemm_f32_tn_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, tot, splits, out,
+                       (long long)ldo, m, n);
+    OSR_CHECK_LAUNCH("osr_gemm_f32_tn_reduce");
+    return OSR_OK;
+}

@@ -211,6 +211,24 @@ def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], rel
     return out
 
 
+def gemm_f32_tn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[m, n] = sum_k a[k, m] * b[k, n] (= a^T b) in exact fp32: the weight gradient dy^T x of an fp32 linear layer."""
+    lib = _lib.load()
+    _need(a, torch.float32, "a"); _need(b, torch.float32, "b")
+    k, m = a.shape
+    assert b.shape[0] == k
+    n = b.shape[1]
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    else:
+        _need(out, torch.float32, "out")
+        assert tuple(out.shape) == (m, n)
+    nb = int(lib.osr_gemm_f32_tn_workspace_bytes(m, n, k))
+    ws = torch.empty((nb,), dtype=torch.uint8, device=a.device) if nb else None
+    check(lib.osr_gemm_f32_tn(_p(a), m, _p(b), n, _p(out), n, m, n, k, _p(ws), nb, _stream()), "osr_gemm_f32_tn")
+    return out
+
+
 def cfrpn_head_tail(t: torch.Tensor, w_delta, b_delta, w_ctr, b_ctr) -> Tuple[torch.Tensor, torch.Tensor]:
     lib = _lib.load()
     _need(t, name="t")
@@ -331,22 +349,54 @@ def fastrcnn_candidates(logits, deltas, prop_boxes, prop_count, image_hw, num_cl
     return o
 
 
-def roi_align(feats: List[torch.Tensor], scales: Sequence[float], boxes: torch.Tensor, batch_idx: torch.Tensor,
-              pooled: int = 7, out_dtype: Optional[torch.dtype] = None, canonical_level: int = 4, canonical_size: int = 224,
-              min_level: int = 2) -> torch.Tensor:
-    """feats: NHWC per level; boxes (m,4) fp32; batch_idx (m) int32. Returns (m, pooled, pooled, c)."""
-    lib = _lib.load()
-    _need(boxes, torch.float32, "boxes"); _need(batch_idx, torch.int32, "batch_idx")
+def _pyramid(feats, scales) -> "Pyramid":
     py = Pyramid()
     py.num_levels, py.c = len(feats), feats[0].shape[3]
     for i, (f, s) in enumerate(zip(feats, scales)):
         _need(f, feats[0].dtype, f"feats[{i}]")
         py.h[i], py.w[i], py.scale[i], py.data[i] = f.shape[1], f.shape[2], float(s), f.data_ptr()
+    return py
+
+
+# RoIAlign pools the RoIs in locality order (osr_roi_locality_order) unless told otherwise: same output bits, ~8x fewer re-reads
+# from HBM than the score order the proposal lists arrive in.
+ROI_LOCALITY_ORDER = True
+
+
+def roi_locality_order(feats: List[torch.Tensor], scales: Sequence[float], boxes: torch.Tensor, batch_idx: torch.Tensor,
+                       canonical_level: int = 4, canonical_size: int = 224, min_level: int = 2) -> torch.Tensor:
+    """A permutation of the RoI list (int32, (m,)) that puts RoIs of one image / level / 32-pixel tile next to each other."""
+    lib = _lib.load()
+    _need(boxes, torch.float32, "boxes"); _need(batch_idx, torch.int32, "batch_idx")
+    py = _pyramid(feats, scales)
+    m, n = boxes.shape[0], feats[0].shape[0]
+    order = torch.empty((m,), dtype=torch.int32, device=boxes.device)
+    nb = int(lib.osr_roi_locality_order_workspace_bytes(n, m))
+    ws = torch.empty((nb,), dtype=torch.uint8, device=boxes.device)
+    check(lib.osr_roi_locality_order(C.byref(py), n, _p(boxes), _p(batch_idx), m, canonical_level, canonical_size, min_level, _p(order), _p(ws), nb,
+                                     _stream()), "osr_roi_locality_order")
+    return order
+
+
+def roi_align(feats: List[torch.Tensor], scales: Sequence[float], boxes: torch.Tensor, batch_idx: torch.Tensor,
+              pooled: int = 7, out_dtype: Optional[torch.dtype] = None, canonical_level: int = 4, canonical_size: int = 224,
+              min_level: int = 2, order: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """feats: NHWC per level; boxes (m,4) fp32; batch_idx (m) int32. Returns (m, pooled, pooled, c). order: processing order
+    (None: osr_roi_locality_order when ROI_LOCALITY_ORDER, else list order); the result does not depend on it."""
+    lib = _lib.load()
+    _need(boxes, torch.float32, "boxes"); _need(batch_idx, torch.int32, "batch_idx")
+    py = _pyramid(feats, scales)
     m = boxes.shape[0]
+    if order is None and ROI_LOCALITY_ORDER and m > 0:
+        order = roi_locality_order(feats, scales, boxes, batch_idx, canonical_level, canonical_size, min_level)
+    if order is not None:
+        _need(order, torch.int32, "order")
+        assert order.numel() == m
     out_dtype = out_dtype or feats[0].dtype
     out = torch.empty((m, pooled, pooled, py.c), dtype=out_dtype, device=boxes.device)
-    check(lib.osr_roi_align_fwd(C.byref(py), _DT[feats[0].dtype], feats[0].shape[0], _p(boxes), _p(batch_idx), m, pooled,
-                                canonical_level, canonical_size, min_level, _p(out), _DT[out_dtype], _stream()), "osr_roi_align_fwd")
+    check(lib.osr_roi_align_fwd_ordered(C.byref(py), _DT[feats[0].dtype], feats[0].shape[0], _p(boxes), _p(batch_idx), m, pooled,
+                                        canonical_level, canonical_size, min_level, _p(order), _p(out), _DT[out_dtype], _stream()),
+          "osr_roi_align_fwd")
     return out
 
 

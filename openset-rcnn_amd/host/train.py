@@ -191,8 +191,7 @@ class OpensetRCNNTrainer:
         g = self.grad
         dyp = dy if dy_pad is None else torch.nn.functional.pad(dy, (0, dy_pad - dy.shape[1]))
         dx = ops.gemm_f32(dyp, wt, None)                                                    # (m, k_in)
-        dw = ops.gemm_f32(dy.t().contiguous(), x.t().contiguous(), None)                    # (n_out, k_in)
-        g[name + ".w"].copy_(dw)
+        ops.gemm_f32_tn(dy, x, out=g[name + ".w"])                                          # dW = dy^T x, (n_out, k_in)
         ops.bias_grad(dy, g[name + ".b"])
         self._done(name + ".w", name + ".b")
         return dx

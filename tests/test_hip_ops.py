@@ -666,3 +666,38 @@ def test_detector_postprocess(ops):
         assert torch.equal(ob[i, :m], b[keep]) and torch.equal(os_[i, :m], scores[i, :c][keep]) and torch.equal(oc[i, :m], classes[i, :c][keep])
         assert bool((oc[i, m:] == -1).all())
     assert int(on[0]) < 100 and int(on[1]) < 37
+
+
+def test_roi_locality_order_is_a_permutation_and_changes_nothing(ops):
+    """osr_roi_locality_order / osr_roi_align_fwd_ordered: the order is a permutation of the list that groups RoIs by image, then
+    pyramid level ([d2] assign_boxes_to_levels as osrcnn_roi_heads.py:108-113 configures it), then 32-pixel tile; padding rows
+    (batch index -1) go last; pooling in that order, in list order and in reversed order gives bit-identical rows."""
+    g = torch.Generator().manual_seed(5)
+    n, per = 3, 700
+    shapes = [(64, 96), (32, 48), (16, 24), (8, 12)]
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+    feats = [torch.randn(n, h, w, 256, generator=g).half().to(DEV) for h, w in shapes]
+    ctr = torch.rand(n * per, 2, generator=g) * torch.tensor([384.0, 256.0])
+    size = torch.exp(torch.rand(n * per, 2, generator=g) * 4.5 + 1.5)           # 4 .. 400 px: every level
+    boxes = torch.cat((ctr - size / 2, ctr + size / 2), dim=1).clamp(min=0).contiguous().to(DEV)
+    bi = torch.arange(n, dtype=torch.int32).repeat_interleave(per)
+    bi[torch.rand(n * per, generator=g) < 0.1] = -1
+    bi = bi[torch.randperm(n * per, generator=g)].contiguous().to(DEV)           # images interleaved in the list
+    order = ops.roi_locality_order(feats, scales, boxes, bi)
+    m = n * per
+    assert order.dtype == torch.int32 and torch.equal(torch.sort(order.long()).values.cpu(), torch.arange(m))
+    ob = bi[order.long()].cpu()
+    valid = ob >= 0
+    assert bool((ob[valid][1:] >= ob[valid][:-1]).all()), "images are contiguous and ascending"
+    assert not bool(valid[int(valid.sum()):].any()), "padding rows last"
+    area = ((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])).cpu()
+    lvl = torch.floor(4 + torch.log2(torch.sqrt(area) / 224 + 1e-8)).clamp(2, 5)[order.long().cpu()]
+    key = ob[valid].double() * 10 + lvl[valid].double()
+    assert bool((key[1:] >= key[:-1]).all()), "levels ascend inside an image"
+    ident = torch.arange(m, dtype=torch.int32, device=DEV)
+    a = ops.roi_align(feats, scales, boxes, bi, 7, torch.float16, order=ident)
+    b = ops.roi_align(feats, scales, boxes, bi, 7, torch.float16, order=order)
+    c = ops.roi_align(feats, scales, boxes, bi, 7, torch.float16, order=ident.flip(0).contiguous())
+    d = ops.roi_align(feats, scales, boxes, bi, 7, torch.float16)
+    assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
+    assert float(a[(bi < 0)].abs().sum()) == 0.0

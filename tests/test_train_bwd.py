@@ -234,3 +234,24 @@ def test_pack_dgrad_weight_kernel_and_overflow_flag(ops):
     x[99999] = 0.0
     x[12345] = float("-inf")
     assert int(ops.check_finite_(x, flag)) == 0
+
+
+def test_gemm_f32_tn_is_dy_transposed_times_x(ops):
+    """osr_gemm_f32_tn (dW = dy^T x of the fp32 heads, autograd of F.linear at prototype_learning_network.py:204-205) against a
+    float64 product: the head shapes of the training step (5-, 21-, 256-, 1024-wide dy over 8192 samples: split over samples and
+    reduced), ragged shapes that take the scalar-load path, a single split, writing into a preallocated view; tolerance 1e-5 of
+    the result scale (fp32 accumulation over up to 8192 samples)."""
+    gg = g(91)
+    for k, m, n in ((8192, 21, 1024), (8192, 5, 1024), (8192, 256, 1024), (8192, 1024, 256), (1000, 67, 130), (48, 64, 64), (7, 3, 5), (130, 200, 64)):
+        a = torch.randn(k, m, generator=gg)
+        b = torch.randn(k, n, generator=gg)
+        want = a.double().t() @ b.double()
+        got = ops.gemm_f32_tn(a.to(DEV), b.to(DEV)).cpu().double()
+        assert got.shape == want.shape
+        assert (got - want).abs().max() <= 1e-5 * want.abs().max(), (k, m, n)
+    flat = torch.zeros(21 * 1024 + 8, device=DEV)
+    a, b = torch.randn(8192, 21, generator=gg), torch.randn(8192, 1024, generator=gg)
+    view = flat[8:].view(21, 1024)
+    assert ops.gemm_f32_tn(a.to(DEV), b.to(DEV), out=view) is view
+    assert torch.equal(view, ops.gemm_f32_tn(a.to(DEV), b.to(DEV)))           # fixed reduction order: bit-identical reruns
+    assert float(flat[:8].abs().sum()) == 0.0

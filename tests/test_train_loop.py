@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda:0"
 LOSS_KEYS = {"loss_rpn_loc", "loss_rpn_ctr", "loss_box_reg", "loss_iou", "loss_dml", "loss_cls"}
-# parameters whose gradients do not pass through RoIAlign's atomic scatter: bitwise reproducible from run to run
+# parameters whose gradients do not pass through RoIAlign's atomic scatter: reproducible from run to run (bitwise in the first
+# iteration)
 DETERMINISTIC = ("roi_heads.box_head.fc1.weight", "roi_heads.box_head.fc2.weight", "roi_heads.box_predictor.bbox_pred.weight",
                  "roi_heads.dml.encoder.weight", "roi_heads.dml.decoder.weight", "roi_heads.dml.representatives",
                  "roi_heads.softmaxcls.cls_score.weight", "proposal_generator.rpn_head.conv.weight",
@@ -96,8 +97,11 @@ def test_reference_loop_body_runs_verbatim_and_matches_trainer_step(osr):
     assert all(torch.isfinite(v) for v in want2.values())
     model.eval()  # leaving training mode writes the masters back into the module
     got, exp = model.state_dict(), tr.export_state_dict()
+    # (after ONE iteration these are bit-identical; the second iteration's forward reads backbone / FPN weights whose first update
+    # carried the scatter's summation-order noise, so from then on "identical" means to fp32 rounding)
     for k in DETERMINISTIC:
-        assert torch.equal(got[k].cpu(), exp[k]), k
+        d = (got[k].cpu() - exp[k]).abs().max()
+        assert float(d) <= 1e-6 * max(float(exp[k].abs().max()), 1e-3), (k, float(d))
     for k, v in exp.items():  # everything downstream of RoIAlign's atomic scatter: equal up to its fp32 summation order
         assert torch.allclose(got[k].cpu(), v, rtol=1e-3, atol=1e-6), k
     assert not torch.equal(got["backbone.fpn_output2.weight"].cpu(), ref_model.state_dict()["backbone.fpn_output2.weight"].cpu())  # it did train
