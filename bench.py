@@ -303,7 +303,7 @@ def main():
     # one collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x2 per the gfx950 guide) on this
     # very command by scripts/profile_round.sh and committed under profiles/ (newest round first); null when absent.
     traffic, traffic_source, hbm_traffic = None, None, None
-    for tag in ("r02_b", "r02_a", "r01_j"):
+    for tag in ("r02_d", "r02_b", "r02_a", "r01_j"):
         tfile = os.path.join(ROOT, "profiles", f"{tag}_kernel_times_and_traffic.json")
         if os.path.exists(tfile):
             with open(tfile) as fh:

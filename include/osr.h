@@ -203,19 +203,21 @@ osr_status osr_roi_align_fwd(const osr_pyramid* feats, int32_t feat_dtype, int32
                              int32_t canonical_size, int32_t min_level, void* out, int32_t out_dtype, void* stream);
 
 /* The same with an explicit processing order: `order` is a permutation of 0..m-1 (or NULL = list order); workgroup i pools RoI
- * order[i] into ITS OWN row out[order[i]], so the result is bit-identical for every order. osr_roi_locality_order fills
- * `order` so that RoIs that are neighbours in the image are neighbours in time on one XCD (bucket sort by image, pyramid level
- * and 32x32-pixel tile of the box centre; the level rule is the one of osr_roi_align_fwd): the proposals of an image overlap
- * each other several times over, and in score order every overlap is a re-read from HBM.
+ * order[i] into ITS OWN row out[order[i]], so the result is bit-identical for every order. `order_nvalid` (device pointer, may
+ * be NULL): the number of leading entries of `order` that are real RoIs, the rest being padding rows (batch index -1): the
+ * kernel then gives every XCD the same share of the real work. osr_roi_locality_order fills both so that RoIs that are
+ * neighbours in the image are neighbours in time on one XCD (bucket sort by image, pyramid level and 32x32-pixel tile of the box
+ * centre; the level rule is the one of osr_roi_align_fwd; padding rows last): the proposals of an image overlap each other
+ * several times over, and in score order every overlap is a re-read from HBM.
  * workspace: osr_roi_locality_order_workspace_bytes(n, m) bytes. */
 osr_status osr_roi_align_fwd_ordered(const osr_pyramid* feats, int32_t feat_dtype, int32_t n, const float* boxes,
                                      const int32_t* batch_idx, int64_t m, int32_t pooled, int32_t canonical_level,
-                                     int32_t canonical_size, int32_t min_level, const int32_t* order, void* out,
-                                     int32_t out_dtype, void* stream);
+                                     int32_t canonical_size, int32_t min_level, const int32_t* order,
+                                     const int32_t* order_nvalid, void* out, int32_t out_dtype, void* stream);
 int64_t osr_roi_locality_order_workspace_bytes(int32_t n, int64_t m);
 osr_status osr_roi_locality_order(const osr_pyramid* feats, int32_t n, const float* boxes, const int32_t* batch_idx, int64_t m,
                                   int32_t canonical_level, int32_t canonical_size, int32_t min_level, int32_t* order,
-                                  void* workspace, int64_t workspace_bytes, void* stream);
+                                  int32_t* nvalid, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Box predictor tail: OpensetFastRCNNOutputLayers.forward + predict_boxes + predict_ious

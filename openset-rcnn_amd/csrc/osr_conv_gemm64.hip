@@ -134,7 +134,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 // SPLIT = 1: the split-K tail launch (fp32 partial sums of a K range per workgroup); a template parameter so that the ordinary
 // instantiations carry none of its registers (four more VGPRs cost the 128 x 128 single-buffer kernel its third wave per SIMD).
 template <class TI, class TO, int BM, int BN, int WM, int WN, int EPI, int TWO, int SPLIT = 0>
-__global__ __launch_bounds__(WM * WN * 64, (TWO || BM * BN > 128 * 128 || EPI != 0) ? 2 : C64_SINGLE_MINW) void conv_igemm64_kernel(Conv64Args a) {  // waves per SIMD the register budget must allow
+__global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4) ? 1 : (TWO || BM * BN > 128 * 128 || EPI != 0) ? 2 : C64_SINGLE_MINW) void conv_igemm64_kernel(Conv64Args a) {  // waves per SIMD the register budget must allow
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int NW = WM * WN, NT = NW * 64;  // waves / threads per workgroup (4 or 8 waves)
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
@@ -705,7 +705,11 @@ static void conv64_dispatch_tile(int id, Conv64Args& a, hipStream_t st) {
     switch (id) {
         case T128x128_1: conv64_launch_tile<TI, TO, 128, 128, 2, 2, 0>(a, st); break;
         case T128x128_2: conv64_launch_tile<TI, TO, 128, 128, 2, 2, 1>(a, st); break;
+#ifdef C64_BIG_W4
+        case T256x256_2: conv64_launch_tile<TI, TO, 256, 256, 2, 2, 1>(a, st); break;
+#else
         case T256x256_2: conv64_launch_tile<TI, TO, 256, 256, 2, 4, 1>(a, st); break;
+#endif
         case T128x256_1: conv64_launch_tile<TI, TO, 128, 256, 2, 2, 0>(a, st); break;
         case T256x128_1: conv64_launch_tile<TI, TO, 256, 128, 2, 2, 0>(a, st); break;
         case T128x64_1: conv64_launch_tile<TI, TO, 128, 64, 4, 1, 0>(a, st); break;

@@ -47,6 +47,7 @@ struct RoiAlignArgs {
     int pooled, canonical_level, canonical_size, min_level;
     void* out;
     const int* order;  // processing order of the RoIs (a permutation of 0..m-1) or null: the result does not depend on it
+    const int* order_nvalid;  // (with order) how many leading entries of it are real RoIs, the rest padding rows; null: unknown
 };
 
 template <class T> struct Vec4;
@@ -200,9 +201,6 @@ struct RaWaveLds {
 #define RA_ANY(x) __any(x)
 #endif
 #define RA_THREADS (RA_WPB * RA_WPR * 64)
-#ifndef RA_CHUNK
-#define RA_CHUNK 32  // workgroups per chunk of the XCD deal
-#endif
 typedef float ra_f2 __attribute__((ext_vector_type(2)));
 typedef unsigned int ra_u2 __attribute__((ext_vector_type(2)));
 
@@ -453,15 +451,24 @@ __global__ __launch_bounds__(RA_THREADS, RA_MINW) void roi_align_kernel(RoiAlign
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     // table builders of one RoI: the whole workgroup (RA_WPR > 1) or the RoI's wave; sub = this wave's share of the bin rows
     const int grp = RA_WPR > 1 ? 0 : wid, sub = RA_WPR > 1 ? wid : 0, gtid = RA_WPR > 1 ? tid : lane;
-    // XCD-aware order: workgroup b runs on XCD b % 8. The list is dealt to the XCDs in chunks of RA_CHUNK workgroups, so RoIs
-    // that are neighbours in the list (a.order: in the image) share an L2 while every XCD gets the same mix of cheap rows
-    // (padding, small boxes) and expensive ones; the last partial round of chunks keeps the plain order.
+    // XCD-aware order: workgroup b runs on XCD b % 8, and each XCD walks one CONTIGUOUS share of the list, so RoIs that are
+    // neighbours in the list (a.order: in the image) are neighbours in time on one L2. When the list says where its padding rows
+    // start (a.order_nvalid), every XCD gets an eighth of the real RoIs followed by its part of the padding, i.e. the same amount
+    // of work: with the padding (a fifth of the bench's list, all at the end of the locality order) in the plain eighths the
+    // last XCDs idle.
     long long r;
     {
-        const int nwg = gridDim.x, bq = blockIdx.x, full = nwg / (8 * RA_CHUNK) * (8 * RA_CHUNK);
-        const int xcd = bq & 7, idx = bq >> 3;
-        const int t = bq < full ? ((idx / RA_CHUNK) * 8 + xcd) * RA_CHUNK + idx % RA_CHUNK : bq;
-        r = (long long)t * RA_WPB + grp;
+        const int nwg = gridDim.x, bq = blockIdx.x, q = nwg >> 3, rr = nwg & 7, xcd = bq & 7, idx = bq >> 3;
+        const int slot0 = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) * RA_WPB;  // first list slot of this XCD
+        const int pos = idx * RA_WPB + grp;                                                       // this RoI's slot inside the XCD's share
+        r = (long long)slot0 + pos;
+        if (a.order_nvalid) {  // this XCD's slots [slot0, slot0 + cap) take the same fraction of the real RoIs as of all slots
+            const long long cap = (long long)(xcd < rr ? q + 1 : q) * RA_WPB, total = (long long)nwg * RA_WPB;
+            const long long V = min(max(*a.order_nvalid, 0), (int)a.m);
+            const long long v0 = V * slot0 / total, v1 = V * (slot0 + cap) / total;  // v1 - v0 <= cap because V <= total
+            const long long nv = v1 - v0, p0 = slot0 - v0;                           // padding rows taken by the XCDs before this one
+            r = pos < nv ? v0 + pos : V + p0 + (pos - nv);
+        }
     }
     if (r >= a.m) return;
     if (a.order) r = a.order[r];
@@ -687,8 +694,8 @@ static osr_status launch_out(const RoiAlignArgs& a, int out_dtype, hipStream_t s
 
 extern "C" osr_status osr_roi_align_fwd_ordered(const osr_pyramid* f, int32_t feat_dtype, int32_t n, const float* boxes,
                                                 const int32_t* batch_idx, int64_t m, int32_t pooled, int32_t canonical_level,
-                                                int32_t canonical_size, int32_t min_level, const int32_t* order, void* out,
-                                                int32_t out_dtype, void* stream) {
+                                                int32_t canonical_size, int32_t min_level, const int32_t* order,
+                                                const int32_t* order_nvalid, void* out, int32_t out_dtype, void* stream) {
     OSR_REQUIRE(f && boxes && batch_idx && out, OSR_ERR_INVALID_ARG, "osr_roi_align_fwd: null pointer");
     OSR_REQUIRE(f->num_levels >= 1 && f->num_levels <= 4, OSR_ERR_INVALID_ARG, "osr_roi_align_fwd: 1..4 levels, got %d", f->num_levels);
     OSR_REQUIRE(pooled >= 1 && pooled <= 7, OSR_ERR_UNSUPPORTED, "osr_roi_align_fwd: pooled size 1..7, got %d", pooled);
@@ -705,7 +712,7 @@ extern "C" osr_status osr_roi_align_fwd_ordered(const osr_pyramid* f, int32_t fe
     }
     a.num_levels = f->num_levels; a.c = f->c; a.boxes = boxes; a.batch_idx = batch_idx; a.m = m;
     a.pooled = pooled; a.canonical_level = canonical_level; a.canonical_size = canonical_size; a.min_level = min_level;
-    a.out = out; a.order = order;
+    a.out = out; a.order = order; a.order_nvalid = order ? order_nvalid : nullptr;
     hipStream_t st = (hipStream_t)stream;
     switch (feat_dtype) {
         case OSR_F32: return launch_out<float>(a, out_dtype, st);
@@ -718,8 +725,8 @@ extern "C" osr_status osr_roi_align_fwd(const osr_pyramid* f, int32_t feat_dtype
                                         const int32_t* batch_idx, int64_t m, int32_t pooled, int32_t canonical_level,
                                         int32_t canonical_size, int32_t min_level, void* out, int32_t out_dtype,
                                         void* stream) {
-    return osr_roi_align_fwd_ordered(f, feat_dtype, n, boxes, batch_idx, m, pooled, canonical_level, canonical_size, min_level, nullptr, out,
-                                     out_dtype, stream);
+    return osr_roi_align_fwd_ordered(f, feat_dtype, n, boxes, batch_idx, m, pooled, canonical_level, canonical_size, min_level, nullptr, nullptr,
+                                     out, out_dtype, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -772,7 +779,8 @@ __global__ __launch_bounds__(256) void roi_order_count(RoiOrderArgs a) {
     } else if (k >= 0) atomicAdd(&a.counts[k], 1);
 }
 
-__global__ __launch_bounds__(1024) void roi_order_scan(int* counts, int nb) {  // exclusive scan in place, one workgroup
+__global__ __launch_bounds__(1024) void roi_order_scan(int* counts, int nb, int* nvalid) {  // exclusive scan in place, one workgroup; the
+                                                                                            // padding bucket (the last) starts at *nvalid
     __shared__ int part[1024];
     const int tid = threadIdx.x, per = (nb + 1023) / 1024, lo = tid * per, hi = min(lo + per, nb);
     int s = 0;
@@ -786,7 +794,12 @@ __global__ __launch_bounds__(1024) void roi_order_scan(int* counts, int nb) {  /
         __syncthreads();
     }
     int run = part[tid] - s;
-    for (int i = lo; i < hi; ++i) { const int c = counts[i]; counts[i] = run; run += c; }
+    for (int i = lo; i < hi; ++i) {
+        const int c = counts[i];
+        counts[i] = run;
+        if (i == nb - 1) *nvalid = run;
+        run += c;
+    }
 }
 
 __global__ __launch_bounds__(256) void roi_order_scatter(RoiOrderArgs a) {
@@ -813,14 +826,18 @@ extern "C" int64_t osr_roi_locality_order_workspace_bytes(int32_t n, int64_t m) 
 
 extern "C" osr_status osr_roi_locality_order(const osr_pyramid* f, int32_t n, const float* boxes, const int32_t* batch_idx, int64_t m,
                                              int32_t canonical_level, int32_t canonical_size, int32_t min_level, int32_t* order,
-                                             void* workspace, int64_t workspace_bytes, void* stream) {
-    OSR_REQUIRE(f && boxes && batch_idx && order && workspace, OSR_ERR_INVALID_ARG, "osr_roi_locality_order: null pointer");
+                                             int32_t* nvalid, void* workspace, int64_t workspace_bytes, void* stream) {
+    OSR_REQUIRE(f && boxes && batch_idx && order && nvalid && workspace, OSR_ERR_INVALID_ARG, "osr_roi_locality_order: null pointer");
     OSR_REQUIRE(f->num_levels >= 1 && f->num_levels <= 4, OSR_ERR_INVALID_ARG, "osr_roi_locality_order: 1..4 levels, got %d", f->num_levels);
     OSR_REQUIRE(n >= 1 && m >= 0 && m < (1ll << 31) && canonical_size > 0, OSR_ERR_INVALID_ARG, "osr_roi_locality_order: bad n/m/canonical_size");
     OSR_REQUIRE((((uintptr_t)boxes) & 15) == 0, OSR_ERR_INVALID_ARG, "osr_roi_locality_order: boxes must be 16-byte aligned");
     OSR_REQUIRE(workspace_bytes >= osr_roi_locality_order_workspace_bytes(n, m), OSR_ERR_WORKSPACE, "osr_roi_locality_order: workspace needs %lld bytes",
                 (long long)osr_roi_locality_order_workspace_bytes(n, m));
-    if (m == 0) return OSR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (m == 0) {
+        OSR_REQUIRE(hipMemsetAsync(nvalid, 0, 4, st) == hipSuccess, OSR_ERR_LAUNCH, "osr_roi_locality_order: memset failed");
+        return OSR_OK;
+    }
     RoiOrderArgs a;
     for (int l = 0; l < 4; ++l) {
         const int s = l < f->num_levels ? l : 0;
@@ -830,13 +847,12 @@ extern "C" osr_status osr_roi_locality_order(const osr_pyramid* f, int32_t n, co
     a.num_levels = f->num_levels; a.n = n; a.boxes = boxes; a.batch_idx = batch_idx; a.m = m;
     a.canonical_level = canonical_level; a.canonical_size = canonical_size; a.min_level = min_level;
     a.counts = (int*)workspace; a.bucket = a.counts + (size_t)n * RA_BUCKETS + 2; a.order = order;
-    hipStream_t st = (hipStream_t)stream;
     const int nb = n * RA_BUCKETS + 1;
     OSR_REQUIRE(hipMemsetAsync(a.counts, 0, (size_t)(nb + 1) * 4, st) == hipSuccess, OSR_ERR_LAUNCH, "osr_roi_locality_order: memset failed");
     const unsigned grid = (unsigned)((m + 255) / 256);
     hipLaunchKernelGGL(roi_order_count, dim3(grid), dim3(256), 0, st, a);
     OSR_CHECK_LAUNCH("osr_roi_locality_order(count)");
-    hipLaunchKernelGGL(roi_order_scan, dim3(1), dim3(1024), 0, st, a.counts, nb);
+    hipLaunchKernelGGL(roi_order_scan, dim3(1), dim3(1024), 0, st, a.counts, nb, nvalid);
     OSR_CHECK_LAUNCH("osr_roi_locality_order(scan)");
     hipLaunchKernelGGL(roi_order_scatter, dim3(grid), dim3(256), 0, st, a);
     OSR_CHECK_LAUNCH("osr_roi_locality_order(scatter)");

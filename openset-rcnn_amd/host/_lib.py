@@ -79,9 +79,9 @@ PROTOTYPES = {
     "osr_rpn_select_ex": (I32, [C.POINTER(RpnLevels), P, P, P, I32, P, I32, F32, I32, P, P, P, P, P, P, P, P, P, I64, P]),
     "osr_fastrcnn_candidates": (I32, [P, P, I32, I32, P, P, I32, I32, P, P, F32, P, P, P, P, P, P]),
     "osr_roi_align_fwd": (I32, [C.POINTER(Pyramid), I32, I32, P, P, I64, I32, I32, I32, I32, P, I32, P]),
-    "osr_roi_align_fwd_ordered": (I32, [C.POINTER(Pyramid), I32, I32, P, P, I64, I32, I32, I32, I32, P, P, I32, P]),
+    "osr_roi_align_fwd_ordered": (I32, [C.POINTER(Pyramid), I32, I32, P, P, I64, I32, I32, I32, I32, P, P, P, I32, P]),
     "osr_roi_locality_order_workspace_bytes": (I64, [I32, I64]),
-    "osr_roi_locality_order": (I32, [C.POINTER(Pyramid), I32, P, P, I64, I32, I32, I32, P, P, I64, P]),
+    "osr_roi_locality_order": (I32, [C.POINTER(Pyramid), I32, P, P, I64, I32, I32, I32, P, P, P, I64, P]),
     "osr_box_predictor_tail": (I32, [P, I64, I32, P, P, P, P, P, P, C.POINTER(C.c_float), I32, F32, P, P, P, P, P, P]),
     "osr_nms_topk_workspace_bytes": (I64, [I32, I64]),
     "osr_nms_topk": (I32, [P, P, P, P, I32, I64, P, F32, I32, P, P, P, I64, P]),

@@ -365,37 +365,42 @@ ROI_LOCALITY_ORDER = True
 
 def roi_locality_order(feats: List[torch.Tensor], scales: Sequence[float], boxes: torch.Tensor, batch_idx: torch.Tensor,
                        canonical_level: int = 4, canonical_size: int = 224, min_level: int = 2) -> torch.Tensor:
-    """A permutation of the RoI list (int32, (m,)) that puts RoIs of one image / level / 32-pixel tile next to each other."""
+    """(m + 1,) int32: a permutation of the RoI list that puts RoIs of one image / level / 32-pixel tile next to each other, padding
+    rows (batch index -1) last, followed by one more entry: the number of non-padding rows."""
     lib = _lib.load()
     _need(boxes, torch.float32, "boxes"); _need(batch_idx, torch.int32, "batch_idx")
     py = _pyramid(feats, scales)
     m, n = boxes.shape[0], feats[0].shape[0]
-    order = torch.empty((m,), dtype=torch.int32, device=boxes.device)
+    order = torch.empty((m + 1,), dtype=torch.int32, device=boxes.device)
     nb = int(lib.osr_roi_locality_order_workspace_bytes(n, m))
-    ws = torch.empty((nb,), dtype=torch.uint8, device=boxes.device)
-    check(lib.osr_roi_locality_order(C.byref(py), n, _p(boxes), _p(batch_idx), m, canonical_level, canonical_size, min_level, _p(order), _p(ws), nb,
-                                     _stream()), "osr_roi_locality_order")
+    ws = torch.empty((max(nb, 4),), dtype=torch.uint8, device=boxes.device)
+    check(lib.osr_roi_locality_order(C.byref(py), n, _p(boxes), _p(batch_idx), m, canonical_level, canonical_size, min_level, _p(order),
+                                     C.c_void_p(order.data_ptr() + 4 * m), _p(ws), nb, _stream()), "osr_roi_locality_order")
     return order
 
 
 def roi_align(feats: List[torch.Tensor], scales: Sequence[float], boxes: torch.Tensor, batch_idx: torch.Tensor,
               pooled: int = 7, out_dtype: Optional[torch.dtype] = None, canonical_level: int = 4, canonical_size: int = 224,
               min_level: int = 2, order: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """feats: NHWC per level; boxes (m,4) fp32; batch_idx (m) int32. Returns (m, pooled, pooled, c). order: processing order
-    (None: osr_roi_locality_order when ROI_LOCALITY_ORDER, else list order); the result does not depend on it."""
+    """feats: NHWC per level; boxes (m,4) fp32; batch_idx (m) int32. Returns (m, pooled, pooled, c). order: processing order, (m,)
+    int32 or (m + 1,) as roi_locality_order returns it (None: that order when ROI_LOCALITY_ORDER, else list order); the result
+    does not depend on it."""
     lib = _lib.load()
     _need(boxes, torch.float32, "boxes"); _need(batch_idx, torch.int32, "batch_idx")
     py = _pyramid(feats, scales)
     m = boxes.shape[0]
     if order is None and ROI_LOCALITY_ORDER and m > 0:
         order = roi_locality_order(feats, scales, boxes, batch_idx, canonical_level, canonical_size, min_level)
+    nvalid = None
     if order is not None:
         _need(order, torch.int32, "order")
-        assert order.numel() == m
+        assert order.numel() in (m, m + 1)
+        if order.numel() == m + 1:
+            nvalid = C.c_void_p(order.data_ptr() + 4 * m)
     out_dtype = out_dtype or feats[0].dtype
     out = torch.empty((m, pooled, pooled, py.c), dtype=out_dtype, device=boxes.device)
     check(lib.osr_roi_align_fwd_ordered(C.byref(py), _DT[feats[0].dtype], feats[0].shape[0], _p(boxes), _p(batch_idx), m, pooled,
-                                        canonical_level, canonical_size, min_level, _p(order), _p(out), _DT[out_dtype], _stream()),
+                                        canonical_level, canonical_size, min_level, _p(order), nvalid, _p(out), _DT[out_dtype], _stream()),
           "osr_roi_align_fwd")
     return out
 

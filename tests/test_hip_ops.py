@@ -683,8 +683,10 @@ def test_roi_locality_order_is_a_permutation_and_changes_nothing(ops):
     bi = torch.arange(n, dtype=torch.int32).repeat_interleave(per)
     bi[torch.rand(n * per, generator=g) < 0.1] = -1
     bi = bi[torch.randperm(n * per, generator=g)].contiguous().to(DEV)           # images interleaved in the list
-    order = ops.roi_locality_order(feats, scales, boxes, bi)
+    full = ops.roi_locality_order(feats, scales, boxes, bi)
     m = n * per
+    order = full[:m]
+    assert full.shape == (m + 1,) and int(full[m]) == int((bi >= 0).sum())
     assert order.dtype == torch.int32 and torch.equal(torch.sort(order.long()).values.cpu(), torch.arange(m))
     ob = bi[order.long()].cpu()
     valid = ob >= 0
@@ -696,7 +698,9 @@ def test_roi_locality_order_is_a_permutation_and_changes_nothing(ops):
     assert bool((key[1:] >= key[:-1]).all()), "levels ascend inside an image"
     ident = torch.arange(m, dtype=torch.int32, device=DEV)
     a = ops.roi_align(feats, scales, boxes, bi, 7, torch.float16, order=ident)
-    b = ops.roi_align(feats, scales, boxes, bi, 7, torch.float16, order=order)
+    b = ops.roi_align(feats, scales, boxes, bi, 7, torch.float16, order=full)
+    b2 = ops.roi_align(feats, scales, boxes, bi, 7, torch.float16, order=order.contiguous())
+    assert torch.equal(b, b2)
     c = ops.roi_align(feats, scales, boxes, bi, 7, torch.float16, order=ident.flip(0).contiguous())
     d = ops.roi_align(feats, scales, boxes, bi, 7, torch.float16)
     assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
