@@ -380,13 +380,22 @@ class OpensetRCNNEngine:
         return self.id_map[cls].contiguous(), self.cfg["num_known"]  # a gather: cls == -1 reads the last slot (-1)
 
     # ---- training step, forward half ----------------------------------------------------------------------
-    def rpn_losses_forward(self, sel: dict, n: int, gt_boxes: torch.Tensor, gt_count: torch.Tensor, keys: Dict[str, torch.Tensor],
-                           keep: Optional[dict] = None):
-        """ClsFreeRPN.label_and_sample_anchors + .losses (classification_free_rpn.py:320-491) on the head outputs `sel` carries
-        (level-major pred_deltas / pred_ctr). Returns (6 floats: loss_rpn_loc, loss_rpn_ctr, 4 anchor counts; state dict that the
-        backward needs: labels, obj_labels, matched_boxes, ctr_target)."""
-        check_supported_losses(self.cfg)
-        c, lv = self.cfg, sel["levels"]
+    def pyramid_shapes(self, hp: int, wp: int):
+        """(h, w) of p2..p6 for a padded hp x wp batch: stem 7x7/2 pad 3, max pool 3x3/2 pad 1, stride-2 1x1 convs, p6 = p5 subsampled."""
+        down = lambda v: (v - 1) // 2 + 1  # noqa: E731
+        h, w = (hp + 6 - 7) // 2 + 1, (wp + 6 - 7) // 2 + 1
+        shapes = []
+        for _ in range(5):
+            h, w = down(h), down(w)
+            shapes.append((h, w))
+        return shapes
+
+    def rpn_targets_forward(self, lv, n: int, gt_boxes: torch.Tensor, gt_count: torch.Tensor, keys: Dict[str, torch.Tensor],
+                            keep: Optional[dict] = None) -> dict:
+        """ClsFreeRPN.label_and_sample_anchors (classification_free_rpn.py:320-402): anchor labels, sampling and regression /
+        centerness targets. A function of the ground truth, the anchor grid and the sampling keys only -- not of the network's
+        outputs -- so the trainer runs it on a side stream beside the backbone."""
+        c = self.cfg
         midx, miou, lab, olab = ops.rpn_match_anchors(lv, self.cell_anchors, n, gt_boxes, gt_count, c["rpn_iou_thresholds"],
                                                       c["rpn_iou_thresholds_objectness"])
         if keep is not None:
@@ -394,9 +403,20 @@ class OpensetRCNNEngine:
         ops.subsample_labels_(lab, keys["rpn_reg"], c["rpn_batch_size"], c["rpn_positive_fraction"])
         ops.subsample_labels_(olab, keys["rpn_obj"], c["rpn_batch_size"], c["rpn_positive_fraction_objectness"])
         mboxes, ctr_t = ops.rpn_anchor_targets(lv, self.cell_anchors, n, gt_boxes, gt_count, midx, olab)
-        rpn = ops.rpn_losses_fwd(lv, self.cell_anchors, n, sel["pred_deltas"], sel["pred_ctr"], lab, olab, mboxes, ctr_t,
-                                 c["rpn_loc_weight"], c["rpn_ctr_weight"], c["rpn_batch_size"])
-        return rpn, dict(labels=lab, obj_labels=olab, matched_boxes=mboxes, ctr_target=ctr_t)
+        return dict(labels=lab, obj_labels=olab, matched_boxes=mboxes, ctr_target=ctr_t)
+
+    def rpn_losses_forward(self, sel: dict, n: int, gt_boxes: torch.Tensor, gt_count: torch.Tensor, keys: Dict[str, torch.Tensor],
+                           keep: Optional[dict] = None, targets: Optional[dict] = None):
+        """ClsFreeRPN.label_and_sample_anchors + .losses (classification_free_rpn.py:320-491) on the head outputs `sel` carries
+        (level-major pred_deltas / pred_ctr). Returns (6 floats: loss_rpn_loc, loss_rpn_ctr, 4 anchor counts; state dict that the
+        backward needs: labels, obj_labels, matched_boxes, ctr_target). targets: the result of rpn_targets_forward when the
+        caller has already computed it."""
+        check_supported_losses(self.cfg)
+        c, lv = self.cfg, sel["levels"]
+        tg = targets if targets is not None else self.rpn_targets_forward(lv, n, gt_boxes, gt_count, keys, keep)
+        rpn = ops.rpn_losses_fwd(lv, self.cell_anchors, n, sel["pred_deltas"], sel["pred_ctr"], tg["labels"], tg["obj_labels"], tg["matched_boxes"],
+                                 tg["ctr_target"], c["rpn_loc_weight"], c["rpn_ctr_weight"], c["rpn_batch_size"])
+        return rpn, dict(tg)
 
     def roi_losses_forward(self, feats: Dict[str, torch.Tensor], prop_boxes, prop_scores, prop_counts, gt_boxes, gt_classes, gt_count,
                            keys_roi: torch.Tensor):

@@ -103,6 +103,8 @@ class OpensetRCNNTrainer:
         self.overflow_steps = 0
         self._overlap = False
         self.grads_ready = False
+        self._side: Optional[torch.cuda.Stream] = None  # stream of the ground-truth-only part of the forward (anchor targets)
+        self.overlap_targets = True
         self._refresh_derived()
 
     def _add_conv(self, name: str, params, bias: bool):
@@ -144,6 +146,18 @@ class OpensetRCNNTrainer:
         e, c = self.eng, self.eng.cfg
         n = images.shape[0]
         s: dict = {}
+        # anchor labels / sampling / targets depend on the ground truth only: a few small-grid launches (one workgroup per image)
+        # that would otherwise sit in the stream between the RPN head and its loss; they run beside the backbone on a side stream
+        cur = torch.cuda.current_stream(self.device)
+        shapes = e.pyramid_shapes(hp, wp)
+        lv = e._levels(shapes, n)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        if self.overlap_targets:
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                rpn_targets = e.rpn_targets_forward(lv, n, gt_boxes, gt_count, keys)
+                targets_ready = self._side.record_event()
         xpad = ops.preprocess(images, hp, wp, c["pixel_mean"], c["pixel_std"], self.dtype)
         x = ops.stem_conv(xpad, e.w["backbone.bottom_up.stem.conv1.w"], e.w["backbone.bottom_up.stem.conv1.b"], hp, wp, relu=True)
         x = ops.maxpool3x3s2(x)
@@ -176,7 +190,15 @@ class OpensetRCNNTrainer:
         keep: dict = {}
         sel = e._rpn(out, image_hw, keep, topk=c["pre_nms_topk_train"])
         s["rpn_t"], s["rpn_shapes"], s["sel"] = keep["rpn_t"], keep["rpn_shapes"], sel
-        rpn, rpn_state = e.rpn_losses_forward(sel, n, gt_boxes, gt_count, keys)
+        assert list(keep["rpn_shapes"]) == list(shapes), "pyramid_shapes disagrees with the backbone"
+        if self.overlap_targets:
+            cur.wait_event(targets_ready)
+            if not torch.cuda.is_current_stream_capturing():
+                for t in rpn_targets.values():
+                    t.record_stream(cur)
+        else:
+            rpn_targets = None
+        rpn, rpn_state = e.rpn_losses_forward(sel, n, gt_boxes, gt_count, keys, targets=rpn_targets)
         s.update(rpn_state)
         # RoI heads on the sampled proposals
         roi, roi_state = e.roi_losses_forward(out, sel["boxes"], sel["scores"], sel["counts"], gt_boxes, gt_classes, gt_count, keys["roi"])

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--gt", type=int, default=8, help="ground-truth boxes per image")
     ap.add_argument("--graph", action="store_true", help="capture one iteration into a hipGraph and replay it (single GPU)")
+    ap.add_argument("--no-overlap-targets", action="store_true", help="anchor targets in the main stream (A/B of the side stream)")
     ap.add_argument("--phases", action="store_true", help="also time forward / backward / update separately (extra syncs)")
     args = ap.parse_args()
     rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -43,6 +44,7 @@ def main():
     from openset_rcnn_amd.host.weights import random_params
     dev = f"cuda:{local_rank}"
     tr = OpensetRCNNTrainer(random_params(0), dtype=torch.float16, device=dev, lr=1e-5, loss_scale=1024.0)
+    tr.overlap_targets = not args.no_overlap_targets
     g = torch.Generator().manual_seed(99 + rank)
     n, h, w = args.batch, 800, 1333
     images = torch.randint(0, 256, (n, 3, h, w), generator=g, dtype=torch.uint8).to(dev)
