@@ -362,6 +362,22 @@ osr_status osr_rpn_losses_fwd(const osr_rpn_levels* levels, const float* cell_an
                               const int8_t* labels_obj, const float* matched_boxes, const float* ctr_target,
                               float loc_weight, float ctr_weight, int32_t batch_size_per_image, float* out6,
                               void* workspace, int64_t workspace_bytes, void* stream);
+/* The loss functions the reference selects by name (box_regression_w_iou.py:13-85: BBOX_REG_LOSS_TYPE "smooth_l1" | "iou" |
+ * "giou" | "diou" | "ciou" with SMOOTH_L1_BETA; classification_free_rpn.py:475-481 and osrcnn_fast_rcnn.py:368: smooth L1 with
+ * its own beta for the centerness / IoU regression). NULL options = what both Openset yaml files select: "iou" for the CF-RPN
+ * boxes, "smooth_l1" for the RoI boxes, every beta 0 (= L1). */
+enum { OSR_BOX_LOSS_IOU = 0, OSR_BOX_LOSS_SMOOTH_L1 = 1, OSR_BOX_LOSS_GIOU = 2, OSR_BOX_LOSS_DIOU = 3, OSR_BOX_LOSS_CIOU = 4 };
+typedef struct osr_loss_options {
+    int32_t box_loss_type;     /* OSR_BOX_LOSS_* */
+    float box_smooth_l1_beta;  /* used by OSR_BOX_LOSS_SMOOTH_L1 */
+    float aux_smooth_l1_beta;  /* centerness loss (CF-RPN) / IoU regression loss (RoI head) */
+} osr_loss_options;
+osr_status osr_rpn_losses_fwd_ex(const osr_rpn_levels* levels, const float* cell_anchors, int32_t n,
+                                 const float* pred_deltas, const float* pred_ctr, const int8_t* labels_reg,
+                                 const int8_t* labels_obj, const float* matched_boxes, const float* ctr_target,
+                                 float loc_weight, float ctr_weight, int32_t batch_size_per_image,
+                                 const osr_loss_options* options, float* out6, void* workspace, int64_t workspace_bytes,
+                                 void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * OpensetROIHeads.label_and_sample_proposals (osrcnn_roi_heads.py:177-216): append the GT boxes to the
@@ -396,6 +412,12 @@ osr_status osr_roi_box_losses_fwd(const float* pred_deltas, int32_t delta_stride
                                   const float* gt_boxes, const int64_t* gt_classes, const float* gt_iou, int64_t m,
                                   int32_t num_classes, const float reg_weights[4], float box_weight, float iou_weight,
                                   float* out3, void* workspace, int64_t workspace_bytes, void* stream);
+osr_status osr_roi_box_losses_fwd_ex(const float* pred_deltas, int32_t delta_stride, const float* pred_iou,
+                                     int32_t iou_stride, int32_t iou_is_logit, const float* proposal_boxes,
+                                     const float* gt_boxes, const int64_t* gt_classes, const float* gt_iou, int64_t m,
+                                     int32_t num_classes, const float reg_weights[4], float box_weight, float iou_weight,
+                                     const osr_loss_options* options, float* out3, void* workspace,
+                                     int64_t workspace_bytes, void* stream);
 
 /* PLN.loss, COS distance, one prototype per class (prototype_learning_network.py:133-187): rows with a known
  * class and IoU > iou_thr contribute relu(d_own - alpha) + relu(beta - min d_other); the prototypes contribute
@@ -440,6 +462,11 @@ osr_status osr_rpn_losses_bwd(const osr_rpn_levels* levels, const float* cell_an
                               const int8_t* labels_obj, const float* matched_boxes, const float* ctr_target,
                               float loc_weight, float ctr_weight, int32_t batch_size_per_image, float loss_scale,
                               float* d_out5, void* stream);
+osr_status osr_rpn_losses_bwd_ex(const osr_rpn_levels* levels, const float* cell_anchors, int32_t n,
+                                 const float* pred_deltas, const float* pred_ctr, const int8_t* labels_reg,
+                                 const int8_t* labels_obj, const float* matched_boxes, const float* ctr_target,
+                                 float loc_weight, float ctr_weight, int32_t batch_size_per_image, float loss_scale,
+                                 const osr_loss_options* options, float* d_out5, void* stream);
 
 /* ClsFreeRPNHead tail backward (classification_free_rpn.py:159-161): t (rows,256) is the hidden state after the 3x3 conv's
  * ReLU; outputs dt (rows,256, same dtype, already masked by t > 0), dw_tail (5,256), db_tail (5). */
@@ -453,6 +480,11 @@ osr_status osr_roi_box_losses_bwd(const float* pred5, const float* proposal_boxe
                                   const int64_t* gt_classes, const float* gt_iou, int64_t m, int32_t num_classes,
                                   const float reg_weights[4], float box_weight, float iou_weight, float loss_scale,
                                   float* d_pred5, void* workspace, int64_t workspace_bytes, void* stream);
+osr_status osr_roi_box_losses_bwd_ex(const float* pred5, const float* proposal_boxes, const float* gt_boxes,
+                                     const int64_t* gt_classes, const float* gt_iou, int64_t m, int32_t num_classes,
+                                     const float reg_weights[4], float box_weight, float iou_weight, float loss_scale,
+                                     const osr_loss_options* options, float* d_pred5, void* workspace,
+                                     int64_t workspace_bytes, void* stream);
 
 /* Gradient of osr_softmax_ce_loss_fwd w.r.t. the logits (m, num_known+1). workspace 16 bytes. */
 osr_status osr_softmax_ce_loss_bwd(const float* logits, int64_t m, int32_t num_known, const int64_t* gt_classes,

@@ -6,6 +6,7 @@
 // the gradient goes to the strictly selected one (ties are measure-zero for real data; torch splits them evenly).
 // Reductions over rows are two-stage and fixed-order: results are bitwise reproducible.
 #include "osr_common.h"
+#include "osr_box_loss.h"
 
 struct TbLevels {
     int num_levels, num_anchors;
@@ -46,7 +47,8 @@ __device__ __forceinline__ float4 tb_anchor(const TbLevels& lv, const float* __r
 __global__ __launch_bounds__(256) void rpn_losses_bwd_kernel(TbLevels lv, const float* __restrict__ cell, int n, const float* __restrict__ pred_deltas,
                                                              const float* __restrict__ pred_ctr, const signed char* __restrict__ labels_reg,
                                                              const signed char* __restrict__ labels_obj, const float* __restrict__ matched_boxes,
-                                                             const float* __restrict__ ctr_target, float s_loc, float s_ctr, float* __restrict__ out5) {
+                                                             const float* __restrict__ ctr_target, float s_loc, float s_ctr, int box_type, float box_beta,
+                                                             float ctr_beta, float* __restrict__ out5) {
     const long long total = (long long)n * lv.R;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int img = (int)(i / lv.R), r = (int)(i - (long long)img * lv.R);
@@ -58,36 +60,38 @@ __global__ __launch_bounds__(256) void rpn_losses_bwd_kernel(TbLevels lv, const 
         if (lr == 1) {
             const float4 d = *reinterpret_cast<const float4*>(pred_deltas + pi * 4);
             const float cx = 0.5f * (a.x + a.z), cy = 0.5f * (a.y + a.w), aw = a.z - a.x, ah = a.w - a.y;
-            const float x1 = cx - fmaxf(d.x, 0.f) * aw, y1 = cy - fmaxf(d.y, 0.f) * ah, x2 = cx + fmaxf(d.z, 0.f) * aw, y2 = cy + fmaxf(d.w, 0.f) * ah;
             const float4 gt = *reinterpret_cast<const float4*>(matched_boxes + i * 4);
-            const float w = fminf(x2, gt.z) - fmaxf(x1, gt.x), h = fminf(y2, gt.w) - fmaxf(y1, gt.y);
-            if (w > 0.f && h > 0.f) {
-                const float I = w * h, a1 = (x2 - x1) * (y2 - y1), a2 = (gt.z - gt.x) * (gt.w - gt.y), U = a1 + a2 - I;
-                const float iou = I / U;
-                if (iou > 1e-6f) {  // below the clamp the loss is constant
-                    // dI and da1 w.r.t. (x1, y1, x2, y2); dIoU = (dI*(U + I) - I*da1) / U^2 ; dL/dIoU = -s_loc
-                    const float dI[4] = {x1 > gt.x ? -h : 0.f, y1 > gt.y ? -w : 0.f, x2 < gt.z ? h : 0.f, y2 < gt.w ? w : 0.f};
-                    const float da[4] = {-(y2 - y1), -(x2 - x1), (y2 - y1), (x2 - x1)};
-                    const float db[4] = {d.x > 0.f ? -aw : 0.f, d.y > 0.f ? -ah : 0.f, d.z > 0.f ? aw : 0.f, d.w > 0.f ? ah : 0.f};  // d box / d delta
+            if (box_type == OSR_LOSS_SMOOTH_L1) {
+                g[0] = s_loc * osr_smooth_l1_grad(d.x - (cx - gt.x) / aw, box_beta);
+                g[1] = s_loc * osr_smooth_l1_grad(d.y - (cy - gt.y) / ah, box_beta);
+                g[2] = s_loc * osr_smooth_l1_grad(d.z - (gt.z - cx) / aw, box_beta);
+                g[3] = s_loc * osr_smooth_l1_grad(d.w - (gt.w - cy) / ah, box_beta);
+            } else {
+                const float4 pb = make_float4(cx - fmaxf(d.x, 0.f) * aw, cy - fmaxf(d.y, 0.f) * ah, cx + fmaxf(d.z, 0.f) * aw, cy + fmaxf(d.w, 0.f) * ah);
+                float dp[4];
+                (void)osr_box_loss<true>(box_type, pb, gt, dp);
+                const float db[4] = {d.x > 0.f ? -aw : 0.f, d.y > 0.f ? -ah : 0.f, d.z > 0.f ? aw : 0.f, d.w > 0.f ? ah : 0.f};  // d box / d delta (through the ReLU)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) g[q] = -s_loc * ((dI[q] * (U + I) - I * da[q]) / (U * U)) * db[q];
-                }
+                for (int q = 0; q < 4; ++q) g[q] = s_loc * dp[q] * db[q];
             }
         }
         if (lo != -1) {
-            const float c = pred_ctr[pi], df = c - ctr_target[i];
-            const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
-            g[4] = s_ctr * sg * c * (1.f - c);  // through the sigmoid
+            const float c = pred_ctr[pi];
+            g[4] = s_ctr * osr_smooth_l1_grad(c - ctr_target[i], ctr_beta) * c * (1.f - c);  // through the sigmoid
         }
 #pragma unroll
         for (int q = 0; q < 5; ++q) out5[pi * 5 + q] = g[q];
     }
 }
 
-extern "C" osr_status osr_rpn_losses_bwd(const osr_rpn_levels* lvl, const float* cell_anchors, int32_t n, const float* pred_deltas,
+extern "C" osr_status osr_rpn_losses_bwd_ex(const osr_rpn_levels* lvl, const float* cell_anchors, int32_t n, const float* pred_deltas,
                                          const float* pred_ctr, const int8_t* labels_reg, const int8_t* labels_obj, const float* matched_boxes,
                                          const float* ctr_target, float loc_weight, float ctr_weight, int32_t batch_size_per_image, float loss_scale,
-                                         float* d_out5, void* stream) {
+                                            const osr_loss_options* opt, float* d_out5, void* stream) {
+    const int box_type = opt ? opt->box_loss_type : OSR_LOSS_IOU;
+    const float box_beta = opt ? opt->box_smooth_l1_beta : 0.f, ctr_beta = opt ? opt->aux_smooth_l1_beta : 0.f;
+    OSR_REQUIRE(box_type >= OSR_LOSS_IOU && box_type <= OSR_LOSS_CIOU && box_beta >= 0.f && ctr_beta >= 0.f, OSR_ERR_INVALID_ARG,
+                "osr_rpn_losses_bwd: bad loss options (type %d)", box_type);
     TbLevels lv;
     OSR_REQUIRE(tb_fill(lvl, &lv), OSR_ERR_INVALID_ARG, "osr_rpn_losses_bwd: bad level table");
     OSR_REQUIRE(cell_anchors && pred_deltas && pred_ctr && labels_reg && labels_obj && matched_boxes && ctr_target && d_out5, OSR_ERR_INVALID_ARG,
@@ -97,9 +101,17 @@ extern "C" osr_status osr_rpn_losses_bwd(const osr_rpn_levels* lvl, const float*
     const float norm = (float)batch_size_per_image * (float)n;
     hipLaunchKernelGGL(rpn_losses_bwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, lv, cell_anchors, n, pred_deltas, pred_ctr,
                        (const signed char*)labels_reg, (const signed char*)labels_obj, matched_boxes, ctr_target, loss_scale * loc_weight / norm,
-                       loss_scale * ctr_weight / norm, d_out5);
+                       loss_scale * ctr_weight / norm, box_type, box_beta, ctr_beta, d_out5);
     OSR_CHECK_LAUNCH("osr_rpn_losses_bwd");
     return OSR_OK;
+}
+
+extern "C" osr_status osr_rpn_losses_bwd(const osr_rpn_levels* lvl, const float* cell_anchors, int32_t n, const float* pred_deltas,
+                                         const float* pred_ctr, const int8_t* labels_reg, const int8_t* labels_obj, const float* matched_boxes,
+                                         const float* ctr_target, float loc_weight, float ctr_weight, int32_t batch_size_per_image, float loss_scale,
+                                         float* d_out5, void* stream) {
+    return osr_rpn_losses_bwd_ex(lvl, cell_anchors, n, pred_deltas, pred_ctr, labels_reg, labels_obj, matched_boxes, ctr_target, loc_weight, ctr_weight,
+                                 batch_size_per_image, loss_scale, nullptr, d_out5, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -225,7 +237,8 @@ __global__ void count_rows_kernel(const long long* __restrict__ cls, long long m
 __global__ __launch_bounds__(256) void roi_box_losses_bwd_kernel(const float* __restrict__ pred, int pstride, const float* __restrict__ prop,
                                                                  const float* __restrict__ gtb, const long long* __restrict__ cls,
                                                                  const float* __restrict__ gt_iou, long long m, int num_classes, float wx, float wy, float ww,
-                                                                 float wh, float s_box, float s_iou, const float* __restrict__ rows, float* __restrict__ d_pred) {
+                                                                 float wh, float s_box, float s_iou, int box_type, float box_beta, float iou_beta,
+                                                                 const float* __restrict__ rows, float* __restrict__ d_pred) {
     const float r = fmaxf(rows[0], 1.0f);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
         float g[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -235,23 +248,38 @@ __global__ __launch_bounds__(256) void roi_box_losses_bwd_kernel(const float* __
             const float* d = pred + i * pstride;
             const float sw = s.z - s.x, sh = s.w - s.y, scx = s.x + 0.5f * sw, scy = s.y + 0.5f * sh;
             const float tw = t.z - t.x, th = t.w - t.y, tcx = t.x + 0.5f * tw, tcy = t.y + 0.5f * th;
-            const float tg[4] = {wx * (tcx - scx) / sw, wy * (tcy - scy) / sh, ww * logf(tw / sw), wh * logf(th / sh)};
+            if (box_type == OSR_LOSS_SMOOTH_L1) {
+                const float tg[4] = {wx * (tcx - scx) / sw, wy * (tcy - scy) / sh, ww * logf(tw / sw), wh * logf(th / sh)};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float df = d[q] - tg[q];
-                g[q] = (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * s_box / r;
+                for (int q = 0; q < 4; ++q) g[q] = osr_smooth_l1_grad(d[q] - tg[q], box_beta) * s_box / r;
+            } else {  // through [d2] Box2BoxTransform.apply_deltas: centre = d/w * size + centre, size = exp(min(d/w, clamp)) * size
+                const float kClamp = 4.135166556742356f;
+                const float ew = d[2] / ww, eh = d[3] / wh;
+                const float pw = expf(fminf(ew, kClamp)) * sw, ph = expf(fminf(eh, kClamp)) * sh;
+                const float pcx = d[0] / wx * sw + scx, pcy = d[1] / wy * sh + scy;
+                float dp[4];
+                (void)osr_box_loss<true>(box_type, make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph), t, dp);
+                g[0] = (dp[0] + dp[2]) * sw / wx * s_box / r;
+                g[1] = (dp[1] + dp[3]) * sh / wy * s_box / r;
+                g[2] = ew < kClamp ? 0.5f * (dp[2] - dp[0]) * pw / ww * s_box / r : 0.f;
+                g[3] = eh < kClamp ? 0.5f * (dp[3] - dp[1]) * ph / wh * s_box / r : 0.f;
             }
-            const float sg = 1.0f / (1.0f + expf(-d[4])), df = sg - gt_iou[i];
-            g[4] = (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * sg * (1.f - sg) * s_iou / r;
+            const float sg = 1.0f / (1.0f + expf(-d[4]));
+            g[4] = osr_smooth_l1_grad(sg - gt_iou[i], iou_beta) * sg * (1.f - sg) * s_iou / r;
         }
 #pragma unroll
         for (int q = 0; q < 5; ++q) d_pred[i * 5 + q] = g[q];
     }
 }
 
-extern "C" osr_status osr_roi_box_losses_bwd(const float* pred5, const float* proposal_boxes, const float* gt_boxes, const int64_t* gt_classes,
+extern "C" osr_status osr_roi_box_losses_bwd_ex(const float* pred5, const float* proposal_boxes, const float* gt_boxes, const int64_t* gt_classes,
                                              const float* gt_iou, int64_t m, int32_t num_classes, const float reg_weights[4], float box_weight,
-                                             float iou_weight, float loss_scale, float* d_pred5, void* workspace, int64_t workspace_bytes, void* stream) {
+                                             float iou_weight, float loss_scale, const osr_loss_options* opt, float* d_pred5, void* workspace,
+                                                int64_t workspace_bytes, void* stream) {
+    const int box_type = opt ? opt->box_loss_type : OSR_LOSS_SMOOTH_L1;
+    const float box_beta = opt ? opt->box_smooth_l1_beta : 0.f, iou_beta = opt ? opt->aux_smooth_l1_beta : 0.f;
+    OSR_REQUIRE(box_type >= OSR_LOSS_IOU && box_type <= OSR_LOSS_CIOU && box_beta >= 0.f && iou_beta >= 0.f, OSR_ERR_INVALID_ARG,
+                "osr_roi_box_losses_bwd: bad loss options (type %d)", box_type);
     OSR_REQUIRE(pred5 && proposal_boxes && gt_boxes && gt_classes && gt_iou && reg_weights && d_pred5 && workspace, OSR_ERR_INVALID_ARG,
                 "osr_roi_box_losses_bwd: null pointer");
     OSR_REQUIRE(m >= 1 && workspace_bytes >= 16, OSR_ERR_INVALID_ARG, "osr_roi_box_losses_bwd: bad m / workspace (16 bytes)");
@@ -260,9 +288,16 @@ extern "C" osr_status osr_roi_box_losses_bwd(const float* pred5, const float* pr
     OSR_CHECK_LAUNCH("osr_roi_box_losses_bwd(count)");
     hipLaunchKernelGGL(roi_box_losses_bwd_kernel, dim3(256), dim3(256), 0, st, pred5, 5, proposal_boxes, gt_boxes, (const long long*)gt_classes, gt_iou, (long long)m,
                        num_classes, reg_weights[0], reg_weights[1], reg_weights[2], reg_weights[3], loss_scale * box_weight, loss_scale * iou_weight,
-                       (const float*)workspace, d_pred5);
+                       box_type, box_beta, iou_beta, (const float*)workspace, d_pred5);
     OSR_CHECK_LAUNCH("osr_roi_box_losses_bwd");
     return OSR_OK;
+}
+
+extern "C" osr_status osr_roi_box_losses_bwd(const float* pred5, const float* proposal_boxes, const float* gt_boxes, const int64_t* gt_classes,
+                                             const float* gt_iou, int64_t m, int32_t num_classes, const float reg_weights[4], float box_weight,
+                                             float iou_weight, float loss_scale, float* d_pred5, void* workspace, int64_t workspace_bytes, void* stream) {
+    return osr_roi_box_losses_bwd_ex(pred5, proposal_boxes, gt_boxes, gt_classes, gt_iou, m, num_classes, reg_weights, box_weight, iou_weight, loss_scale,
+                                     nullptr, d_pred5, workspace, workspace_bytes, stream);
 }
 
 // softmax cross entropy: d logits = (softmax - onehot) * weight / count over the rows with a valid target

@@ -11,6 +11,9 @@
 // Every reduction is two-stage (per-workgroup partials in fixed order, then one workgroup), so losses are bitwise
 // reproducible run to run. Compile with -ffp-contract=off (labels / sampled index lists must be bit-exact).
 #include "osr_common.h"
+#include "osr_box_loss.h"
+static_assert(OSR_LOSS_IOU == OSR_BOX_LOSS_IOU && OSR_LOSS_SMOOTH_L1 == OSR_BOX_LOSS_SMOOTH_L1 && OSR_LOSS_GIOU == OSR_BOX_LOSS_GIOU &&
+                  OSR_LOSS_DIOU == OSR_BOX_LOSS_DIOU && OSR_LOSS_CIOU == OSR_BOX_LOSS_CIOU, "osr_box_loss.h and include/osr.h number the losses alike");
 
 struct TrLevels {
     int num_levels, num_anchors;
@@ -362,7 +365,8 @@ __global__ void tr_final_reduce(const float* __restrict__ partial, int nblocks, 
 __global__ __launch_bounds__(256) void rpn_losses_kernel(TrLevels lv, const float* __restrict__ cell, int n, const float* __restrict__ pred_deltas,
                                                          const float* __restrict__ pred_ctr, const signed char* __restrict__ labels_reg,
                                                          const signed char* __restrict__ labels_obj, const float* __restrict__ matched_boxes,
-                                                         const float* __restrict__ ctr_target, float* __restrict__ partial) {
+                                                         const float* __restrict__ ctr_target, int box_type, float box_beta, float ctr_beta,
+                                                         float* __restrict__ partial) {
     float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // loc, ctr, num_pos, num_neg, obj_pos, obj_neg
     const long long total = (long long)n * lv.R;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -376,20 +380,32 @@ __global__ __launch_bounds__(256) void rpn_losses_kernel(TrLevels lv, const floa
         if (lr == 1) {
             const float4 d = *reinterpret_cast<const float4*>(pred_deltas + pi * 4);
             const float cx = 0.5f * (a.x + a.z), cy = 0.5f * (a.y + a.w), aw = a.z - a.x, ah = a.w - a.y;
-            const float4 pb = make_float4(cx - fmaxf(d.x, 0.f) * aw, cy - fmaxf(d.y, 0.f) * ah, cx + fmaxf(d.z, 0.f) * aw, cy + fmaxf(d.w, 0.f) * ah);
             const float4 g = *reinterpret_cast<const float4*>(matched_boxes + i * 4);
-            // diag(pairwise_iou(pred, gt)).clamp(min=1e-6): pred plays the "b1" role (box_regression_w_iou.py:56)
-            v[0] += 1.0f - fmaxf(tr_iou(pb, g), 1e-6f);
+            if (box_type == OSR_LOSS_SMOOTH_L1) {
+                // the raw deltas against Box2BoxTransformLinear.get_deltas(anchor, gt) (box_regression_w_iou.py:40-48)
+                v[0] += osr_smooth_l1(d.x - (cx - g.x) / aw, box_beta) + osr_smooth_l1(d.y - (cy - g.y) / ah, box_beta) +
+                        osr_smooth_l1(d.z - (g.z - cx) / aw, box_beta) + osr_smooth_l1(d.w - (g.w - cy) / ah, box_beta);
+            } else {
+                // the decoded box (apply_deltas: ReLU of the deltas) against the matched box; "iou": diag(pairwise_iou(pred, gt)).clamp(min=1e-6),
+                // pred in the "b1" role (box_regression_w_iou.py:49-61); giou / diou / ciou: :62-82
+                const float4 pb = make_float4(cx - fmaxf(d.x, 0.f) * aw, cy - fmaxf(d.y, 0.f) * ah, cx + fmaxf(d.z, 0.f) * aw, cy + fmaxf(d.w, 0.f) * ah);
+                float unused[4];
+                v[0] += osr_box_loss<false>(box_type, pb, g, unused);
+            }
         }
-        if (lo != -1) v[1] += fabsf(pred_ctr[pi] - ctr_target[i]);
+        if (lo != -1) v[1] += osr_smooth_l1(pred_ctr[pi] - ctr_target[i], ctr_beta);
     }
     tr_block_reduce_store<6>(v, partial);
 }
 
-extern "C" osr_status osr_rpn_losses_fwd(const osr_rpn_levels* lvl, const float* cell_anchors, int32_t n, const float* pred_deltas,
+extern "C" osr_status osr_rpn_losses_fwd_ex(const osr_rpn_levels* lvl, const float* cell_anchors, int32_t n, const float* pred_deltas,
                                          const float* pred_ctr, const int8_t* labels_reg, const int8_t* labels_obj, const float* matched_boxes,
-                                         const float* ctr_target, float loc_weight, float ctr_weight, int32_t batch_size_per_image, float* out6,
-                                         void* workspace, int64_t workspace_bytes, void* stream) {
+                                         const float* ctr_target, float loc_weight, float ctr_weight, int32_t batch_size_per_image,
+                                            const osr_loss_options* opt, float* out6, void* workspace, int64_t workspace_bytes, void* stream) {
+    const int box_type = opt ? opt->box_loss_type : OSR_LOSS_IOU;
+    const float box_beta = opt ? opt->box_smooth_l1_beta : 0.f, ctr_beta = opt ? opt->aux_smooth_l1_beta : 0.f;
+    OSR_REQUIRE(box_type >= OSR_LOSS_IOU && box_type <= OSR_LOSS_CIOU && box_beta >= 0.f && ctr_beta >= 0.f, OSR_ERR_INVALID_ARG,
+                "osr_rpn_losses_fwd: bad loss options (type %d)", box_type);
     TrLevels lv;
     OSR_REQUIRE(tr_fill(lvl, &lv), OSR_ERR_INVALID_ARG, "osr_rpn_losses_fwd: bad level table");
     OSR_REQUIRE(cell_anchors && pred_deltas && pred_ctr && labels_reg && labels_obj && matched_boxes && ctr_target && out6 && workspace,
@@ -402,11 +418,19 @@ extern "C" osr_status osr_rpn_losses_fwd(const osr_rpn_levels* lvl, const float*
     const float norm = (float)batch_size_per_image * (float)n;
     const TrScale scale = {{1.0f / norm * loc_weight, 1.0f / norm * ctr_weight, 1.f, 1.f, 1.f, 1.f, 0.f, 0.f}};
     hipLaunchKernelGGL(rpn_losses_kernel, dim3(RED_BLOCKS), dim3(256), 0, st, lv, cell_anchors, n, pred_deltas, pred_ctr, (const signed char*)labels_reg,
-                       (const signed char*)labels_obj, matched_boxes, ctr_target, partial);
+                       (const signed char*)labels_obj, matched_boxes, ctr_target, box_type, box_beta, ctr_beta, partial);
     OSR_CHECK_LAUNCH("osr_rpn_losses_fwd");
     hipLaunchKernelGGL(tr_final_reduce, dim3(1), dim3(64), 0, st, partial, RED_BLOCKS, 6, scale, -1, out6);
     OSR_CHECK_LAUNCH("osr_rpn_losses_fwd(final)");
     return OSR_OK;
+}
+
+extern "C" osr_status osr_rpn_losses_fwd(const osr_rpn_levels* lvl, const float* cell_anchors, int32_t n, const float* pred_deltas,
+                                         const float* pred_ctr, const int8_t* labels_reg, const int8_t* labels_obj, const float* matched_boxes,
+                                         const float* ctr_target, float loc_weight, float ctr_weight, int32_t batch_size_per_image, float* out6,
+                                         void* workspace, int64_t workspace_bytes, void* stream) {
+    return osr_rpn_losses_fwd_ex(lvl, cell_anchors, n, pred_deltas, pred_ctr, labels_reg, labels_obj, matched_boxes, ctr_target, loc_weight, ctr_weight,
+                                 batch_size_per_image, nullptr, out6, workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -522,8 +546,8 @@ __global__ __launch_bounds__(256) void roi_box_losses_kernel(const float* __rest
                                                              int iou_stride, int iou_is_logit, const float* __restrict__ prop,
                                                              const float* __restrict__ gtb, const long long* __restrict__ cls,
                                                              const float* __restrict__ gt_iou, long long m, int num_classes, float wx, float wy, float ww,
-                                                             float wh, float* __restrict__ partial) {
-    float v[3] = {0.f, 0.f, 0.f};  // box L1, IoU L1, rows that count (class >= 0; padding rows carry -1)
+                                                             float wh, int box_type, float box_beta, float iou_beta, float* __restrict__ partial) {
+    float v[3] = {0.f, 0.f, 0.f};  // box loss, IoU loss, rows that count (class >= 0; padding rows carry -1)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
         const long long c = cls[i];
         if (c < 0) continue;
@@ -534,19 +558,33 @@ __global__ __launch_bounds__(256) void roi_box_losses_kernel(const float* __rest
         // [d2] Box2BoxTransform.get_deltas
         const float sw = s.z - s.x, sh = s.w - s.y, scx = s.x + 0.5f * sw, scy = s.y + 0.5f * sh;
         const float tw = t.z - t.x, th = t.w - t.y, tcx = t.x + 0.5f * tw, tcy = t.y + 0.5f * th;
-        const float dx = wx * (tcx - scx) / sw, dy = wy * (tcy - scy) / sh, dw = ww * logf(tw / sw), dh = wh * logf(th / sh);
-        v[0] += fabsf(d[0] - dx) + fabsf(d[1] - dy) + fabsf(d[2] - dw) + fabsf(d[3] - dh);
+        if (box_type == OSR_LOSS_SMOOTH_L1) {
+            const float dx = wx * (tcx - scx) / sw, dy = wy * (tcy - scy) / sh, dw = ww * logf(tw / sw), dh = wh * logf(th / sh);
+            v[0] += osr_smooth_l1(d[0] - dx, box_beta) + osr_smooth_l1(d[1] - dy, box_beta) + osr_smooth_l1(d[2] - dw, box_beta) +
+                    osr_smooth_l1(d[3] - dh, box_beta);
+        } else {  // [d2] Box2BoxTransform.apply_deltas, then the box loss (box_regression_w_iou.py:49-82)
+            const float kClamp = 4.135166556742356f;  // log(1000 / 16)
+            const float pw = expf(fminf(d[2] / ww, kClamp)) * sw, ph = expf(fminf(d[3] / wh, kClamp)) * sh;
+            const float pcx = d[0] / wx * sw + scx, pcy = d[1] / wy * sh + scy;
+            float unused[4];
+            v[0] += osr_box_loss<false>(box_type, make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph), t, unused);
+        }
         float pi = pred_iou[i * iou_stride];
         if (iou_is_logit) pi = 1.0f / (1.0f + expf(-pi));  // OpensetFastRCNNOutputLayers.forward: iou_pred(x).sigmoid()
-        v[1] += fabsf(pi - gt_iou[i]);
+        v[1] += osr_smooth_l1(pi - gt_iou[i], iou_beta);
     }
     tr_block_reduce_store<3>(v, partial);
 }
 
-extern "C" osr_status osr_roi_box_losses_fwd(const float* pred_deltas, int32_t delta_stride, const float* pred_iou, int32_t iou_stride,
+extern "C" osr_status osr_roi_box_losses_fwd_ex(const float* pred_deltas, int32_t delta_stride, const float* pred_iou, int32_t iou_stride,
                                              int32_t iou_is_logit, const float* proposal_boxes, const float* gt_boxes, const int64_t* gt_classes,
                                              const float* gt_iou, int64_t m, int32_t num_classes, const float reg_weights[4], float box_weight,
-                                             float iou_weight, float* out3, void* workspace, int64_t workspace_bytes, void* stream) {
+                                                float iou_weight, const osr_loss_options* opt, float* out3, void* workspace, int64_t workspace_bytes,
+                                                void* stream) {
+    const int box_type = opt ? opt->box_loss_type : OSR_LOSS_SMOOTH_L1;
+    const float box_beta = opt ? opt->box_smooth_l1_beta : 0.f, iou_beta = opt ? opt->aux_smooth_l1_beta : 0.f;
+    OSR_REQUIRE(box_type >= OSR_LOSS_IOU && box_type <= OSR_LOSS_CIOU && box_beta >= 0.f && iou_beta >= 0.f, OSR_ERR_INVALID_ARG,
+                "osr_roi_box_losses_fwd: bad loss options (type %d)", box_type);
     OSR_REQUIRE(pred_deltas && pred_iou && proposal_boxes && gt_boxes && gt_classes && gt_iou && reg_weights && out3 && workspace, OSR_ERR_INVALID_ARG,
                 "osr_roi_box_losses_fwd: null pointer");
     OSR_REQUIRE(m >= 0 && delta_stride >= 4 && iou_stride >= 1, OSR_ERR_INVALID_ARG, "osr_roi_box_losses_fwd: bad m / strides");
@@ -557,11 +595,19 @@ extern "C" osr_status osr_roi_box_losses_fwd(const float* pred_deltas, int32_t d
     const TrScale scale = {{box_weight, iou_weight, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
     hipLaunchKernelGGL(roi_box_losses_kernel, dim3(RED_BLOCKS), dim3(256), 0, st, pred_deltas, delta_stride, pred_iou, iou_stride, iou_is_logit, proposal_boxes,
                        gt_boxes, (const long long*)gt_classes, gt_iou, (long long)m, num_classes, reg_weights[0], reg_weights[1], reg_weights[2],
-                       reg_weights[3], partial);
+                       reg_weights[3], box_type, box_beta, iou_beta, partial);
     OSR_CHECK_LAUNCH("osr_roi_box_losses_fwd");
     hipLaunchKernelGGL(tr_final_reduce, dim3(1), dim3(64), 0, st, partial, RED_BLOCKS, 3, scale, 2, out3);
     OSR_CHECK_LAUNCH("osr_roi_box_losses_fwd(final)");
     return OSR_OK;
+}
+
+extern "C" osr_status osr_roi_box_losses_fwd(const float* pred_deltas, int32_t delta_stride, const float* pred_iou, int32_t iou_stride,
+                                             int32_t iou_is_logit, const float* proposal_boxes, const float* gt_boxes, const int64_t* gt_classes,
+                                             const float* gt_iou, int64_t m, int32_t num_classes, const float reg_weights[4], float box_weight,
+                                             float iou_weight, float* out3, void* workspace, int64_t workspace_bytes, void* stream) {
+    return osr_roi_box_losses_fwd_ex(pred_deltas, delta_stride, pred_iou, iou_stride, iou_is_logit, proposal_boxes, gt_boxes, gt_classes, gt_iou, m,
+                                     num_classes, reg_weights, box_weight, iou_weight, nullptr, out3, workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------

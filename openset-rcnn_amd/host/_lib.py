@@ -37,6 +37,13 @@ class ConvParams(C.Structure):
     ]
 
 
+class LossOptions(C.Structure):
+    _fields_ = [("box_loss_type", C.c_int32), ("box_smooth_l1_beta", C.c_float), ("aux_smooth_l1_beta", C.c_float)]
+
+
+BOX_LOSS_TYPES = {"iou": 0, "smooth_l1": 1, "giou": 2, "diou": 3, "ciou": 4}
+
+
 class RpnLevels(C.Structure):
     _fields_ = [
         ("num_levels", C.c_int32), ("num_anchors", C.c_int32),
@@ -96,9 +103,11 @@ PROTOTYPES = {
     "osr_subsample_labels": (I32, [P, P, I32, I64, I32, F32, P, P, P]),
     "osr_rpn_anchor_targets": (I32, [P, P, I32, P, P, I32, P, P, P, P, P]),
     "osr_rpn_losses_fwd": (I32, [P, P, I32, P, P, P, P, P, P, F32, F32, I32, P, P, I64, P]),
+    "osr_rpn_losses_fwd_ex": (I32, [P, P, I32, P, P, P, P, P, P, F32, F32, I32, P, P, P, I64, P]),
     "osr_roi_match_sample_workspace_bytes": (I64, [I32, I64, I32]),
     "osr_roi_match_and_sample": (I32, [P, P, P, I64, P, P, P, I32, I32, P, I32, I32, F32, F32, P, P, P, P, P, P, P, P, P, I64, P]),
     "osr_roi_box_losses_fwd": (I32, [P, I32, P, I32, I32, P, P, P, P, I64, I32, P, F32, F32, P, P, I64, P]),
+    "osr_roi_box_losses_fwd_ex": (I32, [P, I32, P, I32, I32, P, P, P, P, I64, I32, P, F32, F32, P, P, P, I64, P]),
     "osr_pln_loss_fwd": (I32, [P, I64, I32, P, I32, P, P, F32, F32, F32, F32, P, P, I64, P]),
     "osr_softmax_ce_loss_fwd": (I32, [P, I64, I32, P, I32, F32, P, P, I64, P]),
     # training step, backward half
@@ -106,9 +115,11 @@ PROTOTYPES = {
     "osr_conv2d_wgrad": (I32, [P, P, P, P, I32, P, I64, P]),
     "osr_bias_grad": (I32, [P, I32, I64, I32, P, I32, P, I64, P]),
     "osr_rpn_losses_bwd": (I32, [P, P, I32, P, P, P, P, P, P, F32, F32, I32, F32, P, P]),
+    "osr_rpn_losses_bwd_ex": (I32, [P, P, I32, P, P, P, P, P, P, F32, F32, I32, F32, P, P, P]),
     "osr_cfrpn_tail_bwd_workspace_bytes": (I64, []),
     "osr_cfrpn_tail_bwd": (I32, [P, I32, I64, P, P, P, P, P, I32, P, I64, P]),
     "osr_roi_box_losses_bwd": (I32, [P, P, P, P, P, I64, I32, P, F32, F32, F32, P, P, I64, P]),
+    "osr_roi_box_losses_bwd_ex": (I32, [P, P, P, P, P, I64, I32, P, F32, F32, F32, P, P, P, I64, P]),
     "osr_softmax_ce_loss_bwd": (I32, [P, I64, I32, P, I32, F32, F32, P, P, I64, P]),
     "osr_pln_loss_bwd_workspace_bytes": (I64, [I64]),
     "osr_pln_loss_bwd": (I32, [P, I64, I32, P, I32, P, P, F32, F32, F32, F32, F32, P, P, I32, P, I64, P]),

@@ -37,20 +37,33 @@ DEFAULT_CFG = dict(
 )
 
 
+DEFAULT_LOSS_TYPES = dict(rpn_box=("iou", 0.0), rpn_ctr=("smooth_l1", 0.0), roi_box=("smooth_l1", 0.0), roi_iou=("smooth_l1", 0.0))
+BOX_LOSS_NAMES = ("smooth_l1", "iou", "giou", "diou", "ciou")
+
+
+def loss_types_of(cfg: dict) -> dict:
+    """(type, smooth-L1 beta) of the four regression losses: cfg['loss_types'] (modeling.engine_cfg_from fills it from MODEL.RPN.* /
+    MODEL.ROI_BOX_HEAD.*) over the defaults both Openset yaml files select."""
+    lt = dict(DEFAULT_LOSS_TYPES)
+    lt.update(cfg.get("loss_types") or {})
+    return lt
+
+
 def check_supported_losses(cfg: dict) -> None:
-    """What the loss kernels implement -- exactly what both Openset yaml files select: the "iou" box loss of the CF-RPN
-    (box_regression_w_iou.py:49-61) and smooth_l1 with beta 0 (= L1) for centerness, RoI box deltas and IoU. Any other
-    MODEL.RPN.BBOX_REG_LOSS_TYPE / *_LOSS_TYPE / *_SMOOTH_L1_BETA is refused here instead of silently training another loss."""
-    lt = cfg.get("loss_types")
-    if not lt:
-        return
-    if lt["rpn_box"][0] != "iou":
-        raise NotImplementedError(f"MODEL.RPN.BBOX_REG_LOSS_TYPE '{lt['rpn_box'][0]}': the HIP CF-RPN loss implements \"iou\" "
-                                  "(box_regression_w_iou.py:49-61), as both Openset yaml files select")
-    for key, name in (("rpn_ctr", "MODEL.RPN.CTR_REG_LOSS_TYPE"), ("roi_box", "MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE"), ("roi_iou", "MODEL.ROI_BOX_HEAD.IOU_REG_LOSS_TYPE")):
-        typ, beta = lt[key]
-        if typ != "smooth_l1" or beta != 0.0:
-            raise NotImplementedError(f"{name} '{typ}' with beta {beta}: the HIP losses implement smooth_l1 with beta 0 (= L1), the yaml default")
+    """What the loss kernels implement: every box regression loss box_regression_w_iou.py:13-85 names ("smooth_l1" with its beta,
+    "iou", "giou", "diou", "ciou") for the CF-RPN and the RoI box head, and smooth L1 with any beta for the centerness and IoU
+    regressions (the only type classification_free_rpn.py:475-481 / osrcnn_fast_rcnn.py:368 implement). Anything else is refused
+    here instead of silently training another loss."""
+    lt = loss_types_of(cfg)
+    for key, name in (("rpn_box", "MODEL.RPN.BBOX_REG_LOSS_TYPE"), ("roi_box", "MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE")):
+        if lt[key][0] not in BOX_LOSS_NAMES:
+            raise NotImplementedError(f"{name} '{lt[key][0]}': one of {BOX_LOSS_NAMES}")
+    for key, name in (("rpn_ctr", "MODEL.RPN.CTR_REG_LOSS_TYPE"), ("roi_iou", "MODEL.ROI_BOX_HEAD.IOU_REG_LOSS_TYPE")):
+        if lt[key][0] != "smooth_l1":
+            raise NotImplementedError(f"{name} '{lt[key][0]}': the reference implements \"smooth_l1\" only")
+    for key in lt:
+        if lt[key][1] < 0.0:
+            raise ValueError(f"loss_types['{key}']: negative smooth-L1 beta")
 
 
 class OpensetRCNNEngine:
@@ -414,8 +427,10 @@ class OpensetRCNNEngine:
         check_supported_losses(self.cfg)
         c, lv = self.cfg, sel["levels"]
         tg = targets if targets is not None else self.rpn_targets_forward(lv, n, gt_boxes, gt_count, keys, keep)
+        lt = loss_types_of(c)
         rpn = ops.rpn_losses_fwd(lv, self.cell_anchors, n, sel["pred_deltas"], sel["pred_ctr"], tg["labels"], tg["obj_labels"], tg["matched_boxes"],
-                                 tg["ctr_target"], c["rpn_loc_weight"], c["rpn_ctr_weight"], c["rpn_batch_size"])
+                                 tg["ctr_target"], c["rpn_loc_weight"], c["rpn_ctr_weight"], c["rpn_batch_size"], box_loss=lt["rpn_box"],
+                                 ctr_beta=lt["rpn_ctr"][1])
         return rpn, dict(tg)
 
     def roi_losses_forward(self, feats: Dict[str, torch.Tensor], prop_boxes, prop_scores, prop_counts, gt_boxes, gt_classes, gt_count,
@@ -435,8 +450,10 @@ class OpensetRCNNEngine:
         box_feats = self._linear(h1, self.fc2_w, self.fc2_b, True, torch.float32, name="roi_heads.box_head.fc2")
         pred = ops.gemm_f32(box_feats, self.pred_w, self.pred_b)  # (m,5): 4 deltas + IoU logit
         cls, ious = smp["gt_classes"].view(-1), smp["ious"].view(-1)
+        lt = loss_types_of(c)
         box = ops.roi_box_losses_fwd(pred[:, :4], pred[:, 4], boxes, smp["gt_boxes"].view(-1, 4), cls, ious, c["num_classes"],
-                                     c["bbox_reg_weights"], c["box_reg_weight"], c["iou_reg_weight"], iou_is_logit=True)
+                                     c["bbox_reg_weights"], c["box_reg_weight"], c["iou_reg_weight"], iou_is_logit=True, box_loss=lt["roi_box"],
+                                     iou_beta=lt["roi_iou"][1])
         cls_k, nck = self.known_class_targets(cls)
         emb = ops.gemm_f32(box_feats, self.enc_w, self.enc_b)
         rec = ops.gemm_f32(emb, self.dec_w, self.dec_b)

@@ -573,18 +573,29 @@ def rpn_anchor_targets(lv: RpnLevels, cell_anchors, n: int, gt_boxes, gt_count, 
     return mb, ct
 
 
+def _loss_options(box, aux_beta):
+    """box = (type name, smooth-L1 beta) as the yaml names it; aux_beta: beta of the centerness / IoU smooth-L1 loss."""
+    o = _lib.LossOptions()
+    if box[0] not in _lib.BOX_LOSS_TYPES:
+        raise OsrError(f"box regression loss type '{box[0]}': one of {sorted(_lib.BOX_LOSS_TYPES)}")
+    o.box_loss_type, o.box_smooth_l1_beta, o.aux_smooth_l1_beta = _lib.BOX_LOSS_TYPES[box[0]], float(box[1]), float(aux_beta)
+    return o
+
+
 def rpn_losses_fwd(lv: RpnLevels, cell_anchors, n: int, pred_deltas, pred_ctr, labels_reg, labels_obj, matched_boxes, ctr_target,
-                   loc_weight=0.5, ctr_weight=0.5, batch_size_per_image=256) -> torch.Tensor:
-    """pred_*: level-major (as the RPN head writes them). Returns 6 floats: loss_rpn_loc, loss_rpn_ctr, 4 anchor counts."""
+                   loc_weight=0.5, ctr_weight=0.5, batch_size_per_image=256, box_loss=("iou", 0.0), ctr_beta=0.0) -> torch.Tensor:
+    """pred_*: level-major (as the RPN head writes them). Returns 6 floats: loss_rpn_loc, loss_rpn_ctr, 4 anchor counts.
+    box_loss: (MODEL.RPN.BBOX_REG_LOSS_TYPE, MODEL.RPN.SMOOTH_L1_BETA); ctr_beta: MODEL.RPN.CTR_SMOOTH_L1_BETA."""
     lib = _lib.load()
     _need(pred_deltas, torch.float32, "pred_deltas"); _need(pred_ctr, torch.float32, "pred_ctr")
     _need(matched_boxes, torch.float32, "matched_boxes"); _need(ctr_target, torch.float32, "ctr_target")
     dev = pred_ctr.device
     out = torch.empty((6,), dtype=torch.float32, device=dev)
     ws = torch.empty((256 * 6 * 4,), dtype=torch.uint8, device=dev)
-    check(lib.osr_rpn_losses_fwd(C.byref(lv), _p(cell_anchors), n, _p(pred_deltas), _p(pred_ctr), _p(labels_reg), _p(labels_obj),
-                                 _p(matched_boxes), _p(ctr_target), loc_weight, ctr_weight, batch_size_per_image, _p(out), _p(ws),
-                                 ws.numel(), _stream()), "osr_rpn_losses_fwd")
+    opt = _loss_options(box_loss, ctr_beta)
+    check(lib.osr_rpn_losses_fwd_ex(C.byref(lv), _p(cell_anchors), n, _p(pred_deltas), _p(pred_ctr), _p(labels_reg), _p(labels_obj),
+                                    _p(matched_boxes), _p(ctr_target), loc_weight, ctr_weight, batch_size_per_image, C.byref(opt), _p(out), _p(ws),
+                                    ws.numel(), _stream()), "osr_rpn_losses_fwd")
     return out
 
 
@@ -624,9 +635,11 @@ def _loss_ws(dev, nv: int):
 
 
 def roi_box_losses_fwd(pred_deltas, pred_iou, proposal_boxes, gt_boxes, gt_classes, gt_iou, num_classes: int,
-                       reg_weights=(10.0, 10.0, 5.0, 5.0), box_weight=0.5, iou_weight=0.5, iou_is_logit: bool = False) -> torch.Tensor:
+                       reg_weights=(10.0, 10.0, 5.0, 5.0), box_weight=0.5, iou_weight=0.5, iou_is_logit: bool = False,
+                       box_loss=("smooth_l1", 0.0), iou_beta=0.0) -> torch.Tensor:
     """pred_deltas (m,>=4) / pred_iou (m) may be column views of one row-major predictor output (stride(1) == 1).
-    Returns 3 floats: loss_box_reg, loss_iou, rows counted (class >= 0)."""
+    Returns 3 floats: loss_box_reg, loss_iou, rows counted (class >= 0). box_loss: (MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE,
+    SMOOTH_L1_BETA); iou_beta: IOU_SMOOTH_L1_BETA."""
     lib = _lib.load()
     for t, nm in ((proposal_boxes, "proposal_boxes"), (gt_boxes, "gt_boxes"), (gt_iou, "gt_iou")):
         _need(t, torch.float32, nm)
@@ -638,9 +651,10 @@ def roi_box_losses_fwd(pred_deltas, pred_iou, proposal_boxes, gt_boxes, gt_class
     out = torch.empty((3,), dtype=torch.float32, device=dev)
     ws = _loss_ws(dev, 3)
     rw = (C.c_float * 4)(*reg_weights)
-    check(lib.osr_roi_box_losses_fwd(_p(pred_deltas), pred_deltas.stride(0), _p(pred_iou), pred_iou.stride(0), int(iou_is_logit), _p(proposal_boxes),
-                                     _p(gt_boxes), _p(gt_classes), _p(gt_iou), m, num_classes, rw, box_weight, iou_weight, _p(out), _p(ws),
-                                     ws.numel(), _stream()), "osr_roi_box_losses_fwd")
+    opt = _loss_options(box_loss, iou_beta)
+    check(lib.osr_roi_box_losses_fwd_ex(_p(pred_deltas), pred_deltas.stride(0), _p(pred_iou), pred_iou.stride(0), int(iou_is_logit), _p(proposal_boxes),
+                                        _p(gt_boxes), _p(gt_classes), _p(gt_iou), m, num_classes, rw, box_weight, iou_weight, C.byref(opt), _p(out), _p(ws),
+                                        ws.numel(), _stream()), "osr_roi_box_losses_fwd")
     return out
 
 
@@ -785,13 +799,14 @@ def bias_grad(dy: torch.Tensor, db: Optional[torch.Tensor] = None, accumulate: b
 # training step, backward half: losses, per-row stages, elementwise, optimiser
 # ----------------------------------------------------------------------------------------------------------
 def rpn_losses_bwd(lv: RpnLevels, cell_anchors, n: int, pred_deltas, pred_ctr, labels_reg, labels_obj, matched_boxes, ctr_target,
-                   loc_weight=0.5, ctr_weight=0.5, batch_size_per_image=256, loss_scale=1.0) -> torch.Tensor:
+                   loc_weight=0.5, ctr_weight=0.5, batch_size_per_image=256, loss_scale=1.0, box_loss=("iou", 0.0), ctr_beta=0.0) -> torch.Tensor:
     """-> d_out5 (rows, 5) fp32, level-major: gradient w.r.t. the head's {4 deltas, centerness logit}."""
     lib = _lib.load()
     out = torch.empty((pred_ctr.numel(), 5), dtype=torch.float32, device=pred_ctr.device)
-    check(lib.osr_rpn_losses_bwd(C.byref(lv), _p(cell_anchors), n, _p(pred_deltas), _p(pred_ctr), _p(labels_reg), _p(labels_obj),
-                                 _p(matched_boxes), _p(ctr_target), loc_weight, ctr_weight, batch_size_per_image, loss_scale, _p(out), _stream()),
-          "osr_rpn_losses_bwd")
+    opt = _loss_options(box_loss, ctr_beta)
+    check(lib.osr_rpn_losses_bwd_ex(C.byref(lv), _p(cell_anchors), n, _p(pred_deltas), _p(pred_ctr), _p(labels_reg), _p(labels_obj),
+                                    _p(matched_boxes), _p(ctr_target), loc_weight, ctr_weight, batch_size_per_image, loss_scale, C.byref(opt), _p(out),
+                                    _stream()), "osr_rpn_losses_bwd")
     return out
 
 
@@ -811,15 +826,16 @@ def cfrpn_tail_bwd(t: torch.Tensor, w_tail: torch.Tensor, d_out5: torch.Tensor):
 
 
 def roi_box_losses_bwd(pred5, proposal_boxes, gt_boxes, gt_classes, gt_iou, num_classes: int, reg_weights=(10.0, 10.0, 5.0, 5.0),
-                       box_weight=0.5, iou_weight=0.5, loss_scale=1.0) -> torch.Tensor:
+                       box_weight=0.5, iou_weight=0.5, loss_scale=1.0, box_loss=("smooth_l1", 0.0), iou_beta=0.0) -> torch.Tensor:
     lib = _lib.load()
     _need(pred5, torch.float32, "pred5")
     m = gt_classes.numel()
     out = torch.empty((m, 5), dtype=torch.float32, device=pred5.device)
     ws = torch.empty((16,), dtype=torch.uint8, device=pred5.device)
     rw = (C.c_float * 4)(*reg_weights)
-    check(lib.osr_roi_box_losses_bwd(_p(pred5), _p(proposal_boxes), _p(gt_boxes), _p(gt_classes), _p(gt_iou), m, num_classes, rw, box_weight,
-                                     iou_weight, loss_scale, _p(out), _p(ws), 16, _stream()), "osr_roi_box_losses_bwd")
+    opt = _loss_options(box_loss, iou_beta)
+    check(lib.osr_roi_box_losses_bwd_ex(_p(pred5), _p(proposal_boxes), _p(gt_boxes), _p(gt_classes), _p(gt_iou), m, num_classes, rw, box_weight,
+                                        iou_weight, loss_scale, C.byref(opt), _p(out), _p(ws), 16, _stream()), "osr_roi_box_losses_bwd")
     return out
 
 

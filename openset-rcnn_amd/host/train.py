@@ -19,7 +19,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import ops, parallel
-from .engine import OpensetRCNNEngine
+from .engine import OpensetRCNNEngine, loss_types_of
 from .weights import R50_BLOCKS, pack_conv_weight, pack_fc1_weight
 
 
@@ -233,8 +233,10 @@ class OpensetRCNNTrainer:
         self.buckets.reset()
         dt = self.dtype
         # --- RoI-head losses -> predictor / PLN / classifier (fp32 heads) ---
+        lt = loss_types_of(c)
         d_pred = ops.roi_box_losses_bwd(s["pred"], s["boxes"], s["smp"]["gt_boxes"].view(-1, 4), s["cls"], s["ious"], c["num_classes"],
-                                        c["bbox_reg_weights"], c["box_reg_weight"], c["iou_reg_weight"], S)
+                                        c["bbox_reg_weights"], c["box_reg_weight"], c["iou_reg_weight"], S, box_loss=lt["roi_box"],
+                                        iou_beta=lt["roi_iou"][1])
         d_logits = ops.softmax_ce_loss_bwd(s["logits"], s["cls_k"], s["nck"], c["cls_loss_weight"], S)
         d_emb_pln, d_protos = ops.pln_loss_bwd(s["emb"], self.master["protos"], s["cls_k"], s["ious"], c["pln_iou_threshold"], c["pln_alpha"],
                                                c["pln_beta"], c["pln_loss_weight"], S)
@@ -267,7 +269,8 @@ class OpensetRCNNTrainer:
         # --- CF-RPN: losses -> tail -> 3x3 conv (weights shared by the five levels) ---
         sel = s["sel"]
         d5 = ops.rpn_losses_bwd(sel["levels"], e.cell_anchors, n, sel["pred_deltas"], sel["pred_ctr"], s["labels"], s["obj_labels"], s["matched_boxes"],
-                                s["ctr_target"], c["rpn_loc_weight"], c["rpn_ctr_weight"], c["rpn_batch_size"], S)
+                                s["ctr_target"], c["rpn_loc_weight"], c["rpn_ctr_weight"], c["rpn_batch_size"], S, box_loss=loss_types_of(c)["rpn_box"],
+                                ctr_beta=loss_types_of(c)["rpn_ctr"][1])
         dt_all, dw_tail, db_tail = ops.cfrpn_tail_bwd(s["rpn_t"], e.rpn_wtail, d5)
         g["rpn_tail.w"].copy_(dw_tail)
         g["rpn_tail.b"].copy_(db_tail)

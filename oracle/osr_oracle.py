@@ -871,17 +871,61 @@ def rpn_label_and_sample(anchors: torch.Tensor, gt_boxes: torch.Tensor, keys_reg
                 matched_boxes=mboxes, ctr_target=ctr)
 
 
+def smooth_l1(x: torch.Tensor, beta: float) -> torch.Tensor:
+    """fvcore.nn.smooth_l1_loss elementwise (third-party, not vendored in /root/reference; its published definition):
+    beta < 1e-5 -> |x|, else 0.5 x^2 / beta below beta and |x| - 0.5 beta above."""
+    ax = x.abs()
+    if beta < 1e-5:
+        return ax
+    return torch.where(ax < beta, 0.5 * x * x / beta, ax - 0.5 * beta)
+
+
+def box_pair_losses(pred: torch.Tensor, gt: torch.Tensor, kind: str) -> torch.Tensor:
+    """Per-pair loss of decoded boxes against their targets as box_regression_w_iou.py:49-82 selects it:
+    "iou": 1 - diag(pairwise_iou(pred, gt)).clamp(min=1e-6) (:49-61); "giou": fvcore.nn.giou_loss; "diou" / "ciou":
+    detectron2.layers.diou_loss / ciou_loss (third-party, absent from /root/reference; published definitions, eps = 1e-7;
+    alpha of CIoU is computed without gradient, as there)."""
+    if kind == "iou":
+        return 1 - elementwise_iou(pred, gt).clamp(min=1e-6)
+    eps = 1e-7
+    x1, y1, x2, y2 = pred.unbind(-1)
+    x1g, y1g, x2g, y2g = gt.unbind(-1)
+    xk1, yk1, xk2, yk2 = torch.max(x1, x1g), torch.max(y1, y1g), torch.min(x2, x2g), torch.min(y2, y2g)
+    hit = (yk2 > yk1) & (xk2 > xk1)
+    inter = torch.where(hit, (xk2 - xk1) * (yk2 - yk1), torch.zeros_like(x1))
+    union = (x2 - x1) * (y2 - y1) + (x2g - x1g) * (y2g - y1g) - inter
+    iou = inter / (union + eps)
+    xc1, yc1, xc2, yc2 = torch.min(x1, x1g), torch.min(y1, y1g), torch.max(x2, x2g), torch.max(y2, y2g)
+    if kind == "giou":
+        area_c = (xc2 - xc1) * (yc2 - yc1)
+        return 1 - (iou - (area_c - union) / (area_c + eps))
+    diag = (xc2 - xc1) ** 2 + (yc2 - yc1) ** 2 + eps
+    dist = ((x2 + x1) / 2 - (x2g + x1g) / 2) ** 2 + ((y2 + y1) / 2 - (y2g + y1g) / 2) ** 2
+    if kind == "diou":
+        return 1 - iou + dist / diag
+    if kind == "ciou":
+        v = (4 / math.pi ** 2) * (torch.atan((x2g - x1g) / (y2g - y1g)) - torch.atan((x2 - x1) / (y2 - y1))) ** 2
+        with torch.no_grad():
+            alpha = v / (1 - iou + v + eps)
+        return 1 - iou + dist / diag + alpha * v
+    raise ValueError(f"Invalid dense box regression loss type '{kind}'")
+
+
 def rpn_losses(anchors: torch.Tensor, pred_deltas: torch.Tensor, pred_ctr: torch.Tensor, labels: torch.Tensor, obj_labels: torch.Tensor,
-               matched_boxes: torch.Tensor, ctr_target: torch.Tensor, batch_size=256, w_loc=0.5, w_ctr=0.5):
-    """ClsFreeRPN.losses with BBOX_REG_LOSS_TYPE "iou" (classification_free_rpn.py:446-490; box_regression_w_iou.py:49-61).
-    All inputs stacked over images: pred_deltas (N,R,4), pred_ctr (N,R), labels (N,R) ..."""
+               matched_boxes: torch.Tensor, ctr_target: torch.Tensor, batch_size=256, w_loc=0.5, w_ctr=0.5, box_loss=("iou", 0.0), ctr_beta=0.0):
+    """ClsFreeRPN.losses (classification_free_rpn.py:446-490) with BBOX_REG_LOSS_TYPE box_loss[0] (box_regression_w_iou.py:13-85;
+    both yaml files: "iou", :49-61) and the smooth-L1 centerness loss (:475-481). All inputs stacked over images: pred_deltas
+    (N,R,4), pred_ctr (N,R), labels (N,R) ..."""
     n = labels.shape[0]
     pos = labels == 1
-    pb = torch.stack([ltrb_apply_deltas(pred_deltas[i], anchors) for i in range(n)])
-    ious = elementwise_iou(pb[pos], matched_boxes[pos]).clamp(min=1e-6)
-    loss_loc = torch.sum(1 - ious)
+    if box_loss[0] == "smooth_l1":
+        tgt = torch.stack([ltrb_get_deltas(anchors, matched_boxes[i]) for i in range(n)])
+        loss_loc = smooth_l1(pred_deltas[pos] - tgt[pos], box_loss[1]).sum()
+    else:
+        pb = torch.stack([ltrb_apply_deltas(pred_deltas[i], anchors) for i in range(n)])
+        loss_loc = box_pair_losses(pb[pos], matched_boxes[pos], box_loss[0]).sum()
     om = obj_labels != -1
-    loss_ctr = torch.sum(torch.abs(pred_ctr[om] - ctr_target[om]))
+    loss_ctr = smooth_l1(pred_ctr[om] - ctr_target[om], ctr_beta).sum()
     norm = batch_size * n
     return dict(loss_rpn_loc=loss_loc / norm * w_loc, loss_rpn_ctr=loss_ctr / norm * w_ctr,
                 num_pos=int(pos.sum()), num_neg=int((labels == 0).sum()),
@@ -914,13 +958,17 @@ def roi_label_and_sample(prop_boxes: torch.Tensor, prop_logits: torch.Tensor, gt
                 num_fg=len(fg), num_bg=len(bg))
 
 
-def roi_box_losses(pred_deltas, pred_iou, proposal_boxes, gt_boxes, gt_classes, gt_iou, num_classes=81, w_box=0.5, w_iou=0.5):
-    """OpensetFastRCNNOutputLayers.losses (osrcnn_fast_rcnn.py:266-370): L1 on Box2BoxTransform deltas and L1 on the
+def roi_box_losses(pred_deltas, pred_iou, proposal_boxes, gt_boxes, gt_classes, gt_iou, num_classes=81, w_box=0.5, w_iou=0.5,
+                   box_loss=("smooth_l1", 0.0), iou_beta=0.0):
+    """OpensetFastRCNNOutputLayers.losses (osrcnn_fast_rcnn.py:266-370): the box regression loss box_loss[0] names
+    (box_regression_w_iou.py:13-85: smooth L1 on Box2BoxTransform deltas, or a box loss on the decoded boxes) and smooth L1 on the
     predicted IoU over foreground rows, both divided by the total number of rows."""
     fg = (gt_classes >= 0) & (gt_classes < num_classes)
-    tgt = b2b_get_deltas(proposal_boxes[fg], gt_boxes[fg])
-    lb = torch.abs(pred_deltas[fg] - tgt).sum()
-    li = torch.abs(pred_iou[fg] - gt_iou[fg]).sum()
+    if box_loss[0] == "smooth_l1":
+        lb = smooth_l1(pred_deltas[fg] - b2b_get_deltas(proposal_boxes[fg], gt_boxes[fg]), box_loss[1]).sum()
+    else:
+        lb = box_pair_losses(b2b_apply_deltas(pred_deltas[fg], proposal_boxes[fg]), gt_boxes[fg], box_loss[0]).sum()
+    li = smooth_l1(pred_iou[fg] - gt_iou[fg], iou_beta).sum()
     r = max(gt_classes.numel(), 1.0)
     return lb / r * w_box, li / r * w_iou
 

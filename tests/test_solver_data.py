@@ -37,13 +37,23 @@ def test_scheduler_mirror_follows_warmup_multistep(osr):
 
 
 def test_unsupported_loss_types_are_rejected_not_silently_replaced(osr):
-    from openset_rcnn_amd.host.engine import check_supported_losses
+    from openset_rcnn_amd.host.engine import check_supported_losses, loss_types_of
     from openset_rcnn_amd.host.modeling import engine_cfg_from
     assert engine_cfg_from(_cfg(osr))["rpn_loc_weight"] == 0.5
     check_supported_losses(engine_cfg_from(_cfg(osr)))  # the yaml's choice passes
-    for opt in (["MODEL.RPN.BBOX_REG_LOSS_TYPE", "giou"], ["MODEL.RPN.BBOX_REG_LOSS_TYPE", "smooth_l1"], ["MODEL.RPN.CTR_SMOOTH_L1_BETA", "0.1"],
-                ["MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE", "giou"], ["MODEL.ROI_BOX_HEAD.IOU_SMOOTH_L1_BETA", "1.0"]):
-        with pytest.raises(NotImplementedError):  # raised when a loss is first computed (engine.*_losses_forward), never at inference
+    # every loss the reference implements is accepted and reaches the kernels as (type, beta) ...
+    for opt, key, want in ((["MODEL.RPN.BBOX_REG_LOSS_TYPE", "giou"], "rpn_box", ("giou", 0.0)),
+                           (["MODEL.RPN.BBOX_REG_LOSS_TYPE", "smooth_l1", "MODEL.RPN.SMOOTH_L1_BETA", "0.11"], "rpn_box", ("smooth_l1", 0.11)),
+                           (["MODEL.RPN.CTR_SMOOTH_L1_BETA", "0.1"], "rpn_ctr", ("smooth_l1", 0.1)),
+                           (["MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE", "ciou"], "roi_box", ("ciou", 0.0)),
+                           (["MODEL.ROI_BOX_HEAD.IOU_SMOOTH_L1_BETA", "1.0"], "roi_iou", ("smooth_l1", 1.0))):
+        c = engine_cfg_from(_cfg(osr, opt))
+        check_supported_losses(c)
+        assert loss_types_of(c)[key] == want
+    # ... and a name it does not implement is refused when a loss is first computed (engine.*_losses_forward), never at inference
+    for opt in (["MODEL.RPN.BBOX_REG_LOSS_TYPE", "l2"], ["MODEL.RPN.CTR_REG_LOSS_TYPE", "giou"], ["MODEL.ROI_BOX_HEAD.IOU_REG_LOSS_TYPE", "l1"],
+                ["MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE", "huber"]):
+        with pytest.raises(NotImplementedError):
             check_supported_losses(engine_cfg_from(_cfg(osr, opt)))
     # RPN.LOSS_WEIGHT multiplies both CF-RPN losses (classification_free_rpn.py:273-276)
     assert engine_cfg_from(_cfg(osr, ["MODEL.RPN.LOSS_WEIGHT", "2.0"]))["rpn_ctr_weight"] == 1.0

@@ -255,3 +255,75 @@ def test_gemm_f32_tn_is_dy_transposed_times_x(ops):
     assert ops.gemm_f32_tn(a.to(DEV), b.to(DEV), out=view) is view
     assert torch.equal(view, ops.gemm_f32_tn(a.to(DEV), b.to(DEV)))           # fixed reduction order: bit-identical reruns
     assert float(flat[:8].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("box_loss,aux_beta", [(("iou", 0.0), 0.0), (("smooth_l1", 0.0), 0.3), (("smooth_l1", 0.11), 0.0), (("giou", 0.0), 0.05),
+                                               (("diou", 0.0), 0.0), (("ciou", 0.0), 0.2)])
+def test_every_box_regression_loss_of_the_reference(ops, box_loss, aux_beta):
+    """BBOX_REG_LOSS_TYPE "smooth_l1" | "iou" | "giou" | "diou" | "ciou" with SMOOTH_L1_BETA, and CTR_ / IOU_SMOOTH_L1_BETA
+    (box_regression_w_iou.py:13-85, classification_free_rpn.py:466-481, osrcnn_fast_rcnn.py:330-368) for the CF-RPN and the RoI box
+    head: loss values against the oracle (1e-5) and gradients against autograd over the oracle (1e-4)."""
+    import tests.test_train_fwd as TF
+    # ---- CF-RPN ----
+    shapes, strides, sizes = [(24, 40), (12, 20), (6, 10), (3, 5)], (4, 8, 16, 32), (32, 64, 128, 256)
+    c = TF._rpn_case(ops, 161, shapes, strides, sizes, 2, (96, 160), [5, 3])
+    lr, lo, mb, ct = TF._check_rpn_targets(ops, c)
+    n, gg = c["n"], g(162)
+    rows = [n * h * w for h, w in shapes]
+    o = torch.randn(sum(rows), 5, generator=gg) * 0.8 + torch.tensor([0.5, 0.5, 0.5, 0.5, 0.0])
+    if box_loss[0] == "ciou":  # (a box that the ReLU of apply_deltas collapses to zero width AND height has no aspect ratio: atan(0/0) is NaN in
+        o[:, :4] = o[:, :4].abs() + 0.05  # the reference's ciou_loss as well; keep the predicted boxes non-degenerate for this loss)
+
+    def image_major(x):
+        dl, cl, off = [], [], 0
+        for (h, w), r in zip(shapes, rows):
+            dl.append(x[off:off + r, :4].reshape(n, h * w, 4))
+            cl.append(torch.sigmoid(x[off:off + r, 4]).view(n, h * w))
+            off += r
+        return torch.cat(dl, 1), torch.cat(cl, 1)
+    o2 = o.clone().requires_grad_(True)
+    d_im, c_im = image_major(o2)
+    ref = O.rpn_losses(c["anchors"], d_im, c_im, lr.cpu(), lo.cpu(), mb.cpu(), ct.cpu(), box_loss=box_loss, ctr_beta=aux_beta)
+    (ref["loss_rpn_loc"] + ref["loss_rpn_ctr"]).backward()
+    deltas_lm, ctr_lm = o[:, :4].contiguous().to(DEV), torch.sigmoid(o[:, 4]).contiguous().to(DEV)
+    got = ops.rpn_losses_fwd(c["lv"], c["cell"], n, deltas_lm, ctr_lm, lr, lo, mb, ct, box_loss=box_loss, ctr_beta=aux_beta).cpu()
+    assert float(got[0]) == pytest.approx(float(ref["loss_rpn_loc"]), rel=1e-5, abs=1e-7)
+    assert float(got[1]) == pytest.approx(float(ref["loss_rpn_ctr"]), rel=1e-5, abs=1e-7)
+    d5 = ops.rpn_losses_bwd(c["lv"], c["cell"], n, deltas_lm, ctr_lm, lr, lo, mb, ct, loss_scale=16.0, box_loss=box_loss, ctr_beta=aux_beta)
+    assert rel(d5 / 16.0, o2.grad) < 1e-4
+    assert int((o2.grad[:, :4].abs().sum(1) > 0).sum()) > 10 and int((o2.grad[:, 4].abs() > 0).sum()) > 20
+    # ---- RoI box head ----
+    gg = g(171)
+    m, K, NC = 512, 20, 81
+    cls = torch.randint(0, K, (m,), generator=gg)
+    cls[torch.rand(m, generator=gg) < 0.5] = NC
+    cls[m - 20:] = -1
+    prop = torch.rand(m, 4, generator=gg) * 300
+    prop[:, 2:] = prop[:, :2] + 8 + torch.rand(m, 2, generator=gg) * 200
+    gtb = prop + torch.randn(m, 4, generator=gg) * 6
+    gtb[:, 2:] = torch.max(gtb[:, 2:], gtb[:, :2] + 2)
+    gi = torch.rand(m, generator=gg)
+    pred = torch.randn(m, 5, generator=gg)
+    pred[::7, 2] = 30.0  # beyond the scale clamp of Box2BoxTransform.apply_deltas: zero gradient there for the decoded-box losses
+    ok = cls >= 0
+    p = pred.clone().requires_grad_(True)
+    lb, li = O.roi_box_losses(p[ok][:, :4], torch.sigmoid(p[ok][:, 4]), prop[ok], gtb[ok], cls[ok], gi[ok], NC, box_loss=box_loss, iou_beta=aux_beta)
+    (lb + li).backward()
+    pd = pred.to(DEV)
+    out3 = ops.roi_box_losses_fwd(pd[:, :4], pd[:, 4], prop.to(DEV), gtb.to(DEV), cls.to(DEV), gi.to(DEV), NC, iou_is_logit=True, box_loss=box_loss,
+                                  iou_beta=aux_beta).cpu()
+    assert float(out3[0]) == pytest.approx(float(lb), rel=2e-5) and float(out3[1]) == pytest.approx(float(li), rel=2e-5)
+    dp = ops.roi_box_losses_bwd(pd, prop.to(DEV), gtb.to(DEV), cls.to(DEV), gi.to(DEV), NC, loss_scale=8.0, box_loss=box_loss, iou_beta=aux_beta)
+    assert rel(dp / 8.0, p.grad) < 1e-4
+
+
+def test_loss_type_is_validated(ops):
+    from openset_rcnn_amd.host.engine import check_supported_losses
+    from openset_rcnn_amd.host.ops import OsrError
+    check_supported_losses(dict(loss_types=dict(rpn_box=("ciou", 0.0), roi_box=("giou", 0.0), rpn_ctr=("smooth_l1", 0.2), roi_iou=("smooth_l1", 0.1))))
+    with pytest.raises(NotImplementedError):
+        check_supported_losses(dict(loss_types=dict(rpn_box=("l2", 0.0))))
+    with pytest.raises(NotImplementedError):
+        check_supported_losses(dict(loss_types=dict(roi_iou=("giou", 0.0))))
+    with pytest.raises(OsrError):
+        ops._loss_options(("huber", 0.0), 0.0)

@@ -172,3 +172,28 @@ def test_bf16_training_step(setup):
         hist.append(sum(float(v) for v in losses.values()))
     assert all(torch.isfinite(torch.tensor(hist))), hist
     assert hist[-1] < 0.9 * hist[0], hist
+
+
+def test_training_step_with_the_other_reference_losses(setup):
+    """The whole step with the losses the yaml files do not select (MODEL.RPN.BBOX_REG_LOSS_TYPE "giou" + CTR_SMOOTH_L1_BETA 0.1,
+    MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE "diou" + IOU_SMOOTH_L1_BETA 0.05; box_regression_w_iou.py:62-82): they reach the kernels
+    through the trainer's cfg, the six losses are finite, differ from the default's where they should, and SGD reduces their sum."""
+    from openset_rcnn_amd.host.train import OpensetRCNNTrainer
+    d = setup["dev"]
+    args = (d["images"], d["hw"], setup["h"], setup["w"], d["gt"], d["gcls"], d["gcnt"], d["keys"])
+    base = OpensetRCNNTrainer(setup["params"], dtype=torch.float16, device=DEV, lr=5e-5, loss_scale=512.0)
+    l0 = {k: float(v) for k, v in base.step(*args, update=False).items()}
+    cfg = dict(loss_types=dict(rpn_box=("giou", 0.0), rpn_ctr=("smooth_l1", 0.1), roi_box=("diou", 0.0), roi_iou=("smooth_l1", 0.05)))
+    tr = OpensetRCNNTrainer(setup["params"], cfg=cfg, dtype=torch.float16, device=DEV, lr=5e-5, loss_scale=512.0)
+    hist = []
+    for i in range(5):
+        losses = tr.step(*args)
+        if i == 0:
+            l1 = {k: float(v) for k, v in losses.items()}
+        hist.append(sum(float(v) for v in losses.values()))
+    assert all(torch.isfinite(torch.tensor(hist))), hist
+    assert l1["loss_cls"] == pytest.approx(l0["loss_cls"], rel=1e-6) and l1["loss_dml"] == pytest.approx(l0["loss_dml"], rel=1e-6)
+    assert l1["loss_rpn_loc"] > l0["loss_rpn_loc"]              # GIoU loss >= IoU loss pair by pair
+    assert l1["loss_rpn_ctr"] < l0["loss_rpn_ctr"]              # smooth L1 with beta > 0 <= L1
+    assert l1["loss_iou"] < l0["loss_iou"] and l1["loss_box_reg"] != pytest.approx(l0["loss_box_reg"], rel=1e-3)
+    assert hist[-1] < 0.95 * hist[0], hist
