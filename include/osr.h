@@ -267,6 +267,13 @@ osr_status osr_pln_tail(const float* emb, int64_t rows, int32_t d, const float* 
                         int32_t reps, float unk_thr, int64_t unknown_id, const int64_t* class_map,
                         const int32_t* rows_valid, int32_t seg_rows, int64_t* pred_class, float* min_dist,
                         void* stream);
+/* MODEL.PLN.DISTANCE_TYPE (prototype_learning_network.py:155-160, 213-218): the distance between the normalised embedding and
+ * the normalised prototypes. osr_pln_tail / osr_pln_loss_fwd / osr_pln_loss_bwd are the COS forms with one prototype per class. */
+enum { OSR_PLN_DIST_COS = 0, OSR_PLN_DIST_L1 = 1, OSR_PLN_DIST_L2 = 2 };
+osr_status osr_pln_tail_ex(const float* emb, int64_t rows, int32_t d, const float* protos_normed, int32_t num_known,
+                           int32_t reps, int32_t distance_type, float unk_thr, int64_t unknown_id,
+                           const int64_t* class_map, const int32_t* rows_valid, int32_t seg_rows, int64_t* pred_class,
+                           float* min_dist, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Softmax classifier candidates: SoftMaxClassifier.inference up to the NMS calls (softmax_classifier.py:300-307,
@@ -426,6 +433,13 @@ osr_status osr_roi_box_losses_fwd_ex(const float* pred_deltas, int32_t delta_str
 osr_status osr_pln_loss_fwd(const float* emb, int64_t m, int32_t d, const float* protos_normed, int32_t num_known,
                             const int64_t* gt_classes, const float* ious, float iou_thr, float alpha, float beta,
                             float loss_weight, float* out1, void* workspace, int64_t workspace_bytes, void* stream);
+/* The same with REPS_PER_CLASS prototypes per class (protos_normed: (num_known * reps, d), class-major; a class's distance is
+ * the minimum over its prototypes, the prototype term runs over all of them with the own-class block excluded,
+ * prototype_learning_network.py:163-180) and any DISTANCE_TYPE. */
+osr_status osr_pln_loss_fwd_ex(const float* emb, int64_t m, int32_t d, const float* protos_normed, int32_t num_known,
+                               int32_t reps, int32_t distance_type, const int64_t* gt_classes, const float* ious,
+                               float iou_thr, float alpha, float beta, float loss_weight, float* out1, void* workspace,
+                               int64_t workspace_bytes, void* stream);
 
 /* SoftMaxClassifier.loss (softmax_classifier.py:266-285): id_map (known c -> c, num_classes -> num_known, any
  * other class is ignored), mean cross entropy over num_known+1 logits, times loss_weight. workspace 2 KiB. */
@@ -498,6 +512,11 @@ osr_status osr_pln_loss_bwd(const float* emb, int64_t m, int32_t d, const float*
                             const int64_t* gt_classes, const float* ious, float iou_thr, float alpha, float beta,
                             float loss_weight, float loss_scale, float* d_emb, float* d_protos, int32_t accumulate_protos,
                             void* workspace, int64_t workspace_bytes, void* stream);
+osr_status osr_pln_loss_bwd_ex(const float* emb, int64_t m, int32_t d, const float* protos_raw, int32_t num_known,
+                               int32_t reps, int32_t distance_type, const int64_t* gt_classes, const float* ious,
+                               float iou_thr, float alpha, float beta, float loss_weight, float loss_scale, float* d_emb,
+                               float* d_protos, int32_t accumulate_protos, void* workspace, int64_t workspace_bytes,
+                               void* stream);
 
 /* RoIAlign backward: d feature pyramid (fp32 NHWC per level, zero-initialised by the caller; `dfeat->data` are written)
  * += scatter of dout (m,P,P,c) with the forward's geometry; fp32 atomic adds. */

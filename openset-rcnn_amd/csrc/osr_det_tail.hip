@@ -7,6 +7,7 @@
 // Compile with -ffp-contract=off: IoU / clip / threshold arithmetic must round like the oracle's so that
 // kept-index lists are bit-exact.
 #include "osr_common.h"
+#include "osr_pln_dist.h"
 
 #define SCALE_CLAMP_F 4.135166556742356f  // log(1000/16)
 
@@ -340,7 +341,7 @@ extern "C" osr_status osr_l2_normalize_rows(const float* x, int32_t rows, int32_
 // PLN tail: wave per embedding row
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pln_tail_kernel(const float* __restrict__ emb, long long rows, int d,
-                                                       const float* __restrict__ protos, int num_known, int reps, float unk_thr,
+                                                       const float* __restrict__ protos, int num_known, int reps, int dist_type, float unk_thr,
                                                        long long unknown_id, const long long* __restrict__ class_map,
                                                        const int* __restrict__ rows_valid, int seg_rows,
                                                        long long* __restrict__ pred_class, float* __restrict__ min_dist) {
@@ -368,10 +369,7 @@ __global__ __launch_bounds__(256) void pln_tail_kernel(const float* __restrict__
             float md = 0.f;
             for (int q = 0; q < reps; ++q) {
                 const float* p = s_p + (long long)(c * reps + q) * d;
-                float dot = 0.f;
-                for (int i = lane; i < d; i += 64) dot += (e[i] / den) * p[i];
-                dot = osr_wave_sum(dot);
-                const float dist = 1.0f - dot;
+                const float dist = osr_pln_distance([&](int i) { return e[i] / den; }, p, d, lane, dist_type);
                 md = (q == 0 || dist < md) ? dist : md;
             }
             if (best_c < 0 || md < best) { best = md; best_c = c; }  // strict <: lower class wins ties
@@ -385,22 +383,34 @@ __global__ __launch_bounds__(256) void pln_tail_kernel(const float* __restrict__
     }
 }
 
-extern "C" osr_status osr_pln_tail(const float* emb, int64_t rows, int32_t d, const float* protos_normed, int32_t num_known,
-                                   int32_t reps, float unk_thr, int64_t unknown_id, const int64_t* class_map,
-                                   const int32_t* rows_valid, int32_t seg_rows, int64_t* pred_class, float* min_dist, void* stream) {
+extern "C" osr_status osr_pln_tail_ex(const float* emb, int64_t rows, int32_t d, const float* protos_normed, int32_t num_known,
+                                      int32_t reps, int32_t distance_type, float unk_thr, int64_t unknown_id, const int64_t* class_map,
+                                      const int32_t* rows_valid, int32_t seg_rows, int64_t* pred_class, float* min_dist, void* stream) {
+    OSR_REQUIRE(distance_type >= OSR_DIST_COS && distance_type <= OSR_DIST_L2, OSR_ERR_INVALID_ARG, "osr_pln_tail: distance_type %d", distance_type);
     OSR_REQUIRE(emb && protos_normed && pred_class && min_dist, OSR_ERR_INVALID_ARG, "osr_pln_tail: null pointer");
     OSR_REQUIRE(rows >= 0 && d >= 1 && num_known >= 1 && reps >= 1, OSR_ERR_INVALID_ARG, "osr_pln_tail: bad sizes");
-    OSR_REQUIRE((long long)num_known * reps * d <= 16384, OSR_ERR_UNSUPPORTED, "osr_pln_tail: prototypes exceed the 64 KB LDS table");
+    OSR_REQUIRE((long long)num_known * reps * d <= 36864, OSR_ERR_UNSUPPORTED, "osr_pln_tail: prototypes exceed the 144 KB LDS table");
     OSR_REQUIRE(!rows_valid || seg_rows >= 1, OSR_ERR_INVALID_ARG, "osr_pln_tail: seg_rows must be >= 1 with rows_valid");
     if (rows == 0) return OSR_OK;
     long long blocks = (rows + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     size_t smem = (size_t)num_known * reps * d * 4;
+    if (smem > 64 * 1024) {
+        static osr_dev_mask attr{0};
+        osr_once_per_device(attr, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pln_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); });
+    }
     hipLaunchKernelGGL(pln_tail_kernel, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, emb, (long long)rows, d, protos_normed,
-                       num_known, reps, unk_thr, (long long)unknown_id, (const long long*)class_map, rows_valid, seg_rows,
+                       num_known, reps, distance_type, unk_thr, (long long)unknown_id, (const long long*)class_map, rows_valid, seg_rows,
                        (long long*)pred_class, min_dist);
     OSR_CHECK_LAUNCH("osr_pln_tail");
     return OSR_OK;
+}
+
+extern "C" osr_status osr_pln_tail(const float* emb, int64_t rows, int32_t d, const float* protos_normed, int32_t num_known,
+                                   int32_t reps, float unk_thr, int64_t unknown_id, const int64_t* class_map,
+                                   const int32_t* rows_valid, int32_t seg_rows, int64_t* pred_class, float* min_dist, void* stream) {
+    return osr_pln_tail_ex(emb, rows, d, protos_normed, num_known, reps, OSR_DIST_COS, unk_thr, unknown_id, class_map, rows_valid, seg_rows, pred_class,
+                           min_dist, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -7,6 +7,7 @@
 // Reductions over rows are two-stage and fixed-order: results are bitwise reproducible.
 #include "osr_common.h"
 #include "osr_box_loss.h"
+#include "osr_pln_dist.h"
 
 struct TbLevels {
     int num_levels, num_anchors;
@@ -354,12 +355,14 @@ extern "C" osr_status osr_softmax_ce_loss_bwd(const float* logits, int64_t m, in
 // PLN hinge loss backward: d emb (m,d) and d prototypes (K,d) w.r.t. the RAW (un-normalised) prototypes
 // ------------------------------------------------------------------------------------------------------
 // pass 1 (wave per row): coefficients of the two prototypes a foreground row pulls on, and the row's d emb
-__global__ __launch_bounds__(256) void pln_bwd_rows_kernel(const float* __restrict__ emb, long long m, int d, const float* __restrict__ protos, int K,
-                                                           const long long* __restrict__ cls, const float* __restrict__ ious, float iou_thr, float alpha,
-                                                           float beta, float s, const float* __restrict__ rows, float* __restrict__ d_emb,
-                                                           int* __restrict__ pair_idx, float* __restrict__ pair_coef, float* __restrict__ row_inv) {
-    extern __shared__ __attribute__((aligned(16))) float s_p[];  // normalised prototypes [K][d]
-    for (int k = threadIdx.x >> 6; k < K; k += blockDim.x >> 6) {
+__global__ __launch_bounds__(256) void pln_bwd_rows_kernel(const float* __restrict__ emb, long long m, int d, const float* __restrict__ protos, int K, int R,
+                                                           int dist_type, const long long* __restrict__ cls, const float* __restrict__ ious, float iou_thr,
+                                                           float alpha, float beta, float s, const float* __restrict__ rows, float* __restrict__ d_emb,
+                                                           int* __restrict__ pair_idx, float* __restrict__ pair_coef, float* __restrict__ pair_dist,
+                                                           float* __restrict__ row_inv) {
+    extern __shared__ __attribute__((aligned(16))) float s_p[];  // normalised prototypes [K * R][d]
+    const int KR = K * R;
+    for (int k = threadIdx.x >> 6; k < KR; k += blockDim.x >> 6) {
         const int lane = threadIdx.x & 63;
         float ss = 0.f;
         for (int i = lane; i < d; i += 64) { const float x = protos[k * d + i]; ss += x * x; }
@@ -375,61 +378,70 @@ __global__ __launch_bounds__(256) void pln_bwd_rows_kernel(const float* __restri
         float* de = d_emb + r * d;
         const bool fg = y >= 0 && y < K && ious[r] > iou_thr;
         int i0 = -1, i1 = -1;
-        float c0 = 0.f, c1 = 0.f, rinv = 0.f;
+        float c0 = 0.f, c1 = 0.f, d0 = 0.f, d1 = 0.f, rinv = 0.f;
         if (fg) {
             const float* e = emb + r * d;
             float ss = 0.f;
             for (int i = lane; i < d; i += 64) { const float x = e[i]; ss += x * x; }
             ss = osr_wave_sum(ss);
             const float nrm = sqrtf(ss), inv = 1.0f / fmaxf(nrm, 1e-12f);
+            // own class: its nearest prototype (i0, intra); other classes: the nearest prototype of the nearest class (i1, inter)
             float intra = 0.f, inter = 1000.f;
-            int cstar = -1;
+            int pstar = -1, ystar = -1;
             for (int c = 0; c < K; ++c) {
-                float dot = 0.f;
-                for (int i = lane; i < d; i += 64) dot += (e[i] * inv) * s_p[c * d + i];
-                dot = osr_wave_sum(dot);
-                const float dist = 1.0f - dot;
-                if (c == (int)y) intra = dist;
-                else if (dist < inter) { inter = dist; cstar = c; }
+                float dist = 0.f;
+                int arg = c * R;
+                for (int q = 0; q < R; ++q) {
+                    const float dq = osr_pln_distance([&](int i) { return e[i] * inv; }, s_p + (size_t)(c * R + q) * d, d, lane, dist_type);
+                    if (q == 0 || dq < dist) { dist = dq; arg = c * R + q; }
+                }
+                if (c == (int)y) { intra = dist; ystar = arg; }
+                else if (dist < inter) { inter = dist; pstar = arg; }
             }
-            // dL/dD_y = sc [D_y > alpha];  dL/dD_c* = -sc [beta > D_c*];  D_c = 1 - ehat . phat_c
-            const float gy = intra - alpha > 0.f ? sc : 0.f, gc = (cstar >= 0 && beta - inter > 0.f) ? -sc : 0.f;
-            // d ehat = -(gy phat_y + gc phat_c*);  d e = (d ehat - ehat (ehat . d ehat)) / ||e||
+            // dL/dD_y = sc [D_y > alpha];  dL/dD_c* = -sc [beta > D_c*]
+            const float gy = intra - alpha > 0.f ? sc : 0.f, gc = (pstar >= 0 && beta - inter > 0.f) ? -sc : 0.f;
+            // d ehat = gy dD/dehat(p_y*) + gc dD/dehat(p_c*);  d e = (d ehat - ehat (ehat . d ehat)) / ||e||
             float dot = 0.f;
             for (int i = lane; i < d; i += 64) {
-                const float dh = -(gy * s_p[(int)y * d + i] + (cstar >= 0 ? gc * s_p[cstar * d + i] : 0.f));
-                dot += (e[i] * inv) * dh;
+                const float eh = e[i] * inv;
+                const float dh = gy * osr_pln_ddist_da(eh, s_p[ystar * d + i], intra, dist_type) +
+                                 (pstar >= 0 ? gc * osr_pln_ddist_da(eh, s_p[pstar * d + i], inter, dist_type) : 0.f);
+                dot += eh * dh;
             }
             dot = osr_wave_sum(dot);
             for (int i = lane; i < d; i += 64) {
-                const float dh = -(gy * s_p[(int)y * d + i] + (cstar >= 0 ? gc * s_p[cstar * d + i] : 0.f));
-                de[i] = nrm > 1e-12f ? (dh - (e[i] * inv) * dot) * inv : dh * inv;
+                const float eh = e[i] * inv;
+                const float dh = gy * osr_pln_ddist_da(eh, s_p[ystar * d + i], intra, dist_type) +
+                                 (pstar >= 0 ? gc * osr_pln_ddist_da(eh, s_p[pstar * d + i], inter, dist_type) : 0.f);
+                de[i] = nrm > 1e-12f ? (dh - eh * dot) * inv : dh * inv;
             }
-            // d phat_y += -gy ehat ; d phat_c* += -gc ehat
-            i0 = (int)y; c0 = -gy; i1 = cstar; c1 = -gc; rinv = inv;
+            // d phat_y* += gy dD/dphat ; d phat_c* += gc dD/dphat (pass 2)
+            i0 = ystar; c0 = gy; d0 = intra; i1 = pstar; c1 = gc; d1 = inter; rinv = inv;
         } else {
             for (int i = lane; i < d; i += 64) de[i] = 0.f;
         }
         if (lane == 0) {
             pair_idx[r * 2] = i0; pair_idx[r * 2 + 1] = i1;
             pair_coef[r * 2] = c0; pair_coef[r * 2 + 1] = c1;
+            pair_dist[r * 2] = d0; pair_dist[r * 2 + 1] = d1;
             row_inv[r] = rinv;
         }
     }
 }
 
-// pass 2 (one workgroup per prototype): d phat_k = sum over rows (fixed order) coef * ehat_row + the centre term, then the
-// projection through the normalisation of the raw prototype
-__global__ __launch_bounds__(256) void pln_bwd_protos_kernel(const float* __restrict__ emb, long long m, int d, const float* __restrict__ protos, int K,
-                                                             const int* __restrict__ pair_idx, const float* __restrict__ pair_coef,
-                                                             const float* __restrict__ row_inv, float alpha, float beta,
+// pass 2 (one workgroup per prototype): d phat_k = sum over rows (fixed order) coef * dD/dphat_k(ehat_row) + the centre term, then
+// the projection through the normalisation of the raw prototype
+__global__ __launch_bounds__(256) void pln_bwd_protos_kernel(const float* __restrict__ emb, long long m, int d, const float* __restrict__ protos, int K, int R,
+                                                             int dist_type, const int* __restrict__ pair_idx, const float* __restrict__ pair_coef,
+                                                             const float* __restrict__ pair_dist, const float* __restrict__ row_inv, float alpha, float beta,
                                                              float s, const float* __restrict__ rows, int accumulate, float* __restrict__ d_protos) {
-    extern __shared__ __attribute__((aligned(16))) float s_p[];  // normalised prototypes [K][d], then K norms, then K argmins
-    float* s_nrm = s_p + K * d;
-    int* s_arg = reinterpret_cast<int*>(s_nrm + K);
-    float* s_cd = reinterpret_cast<float*>(s_arg + K);
+    extern __shared__ __attribute__((aligned(16))) float s_p[];  // normalised prototypes [KR][d], then KR norms, KR argmins, KR centre distances, d staged
+    const int KR = K * R;
+    float* s_nrm = s_p + KR * d;
+    int* s_arg = reinterpret_cast<int*>(s_nrm + KR);
+    float* s_cd = reinterpret_cast<float*>(s_arg + KR);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int k = wid; k < K; k += nw) {
+    for (int k = wid; k < KR; k += nw) {
         float ss = 0.f;
         for (int i = lane; i < d; i += 64) { const float x = protos[k * d + i]; ss += x * x; }
         ss = osr_wave_sum(ss);
@@ -438,15 +450,14 @@ __global__ __launch_bounds__(256) void pln_bwd_protos_kernel(const float* __rest
         if (lane == 0) s_nrm[k] = nrm;
     }
     __syncthreads();
-    for (int k = wid; k < K; k += nw) {  // centre term: nearest other prototype of every prototype
+    for (int k = wid; k < KR; k += nw) {  // centre term: nearest prototype of another class, for every prototype
         float cd = 1000.f;
         int arg = -1;
-        for (int j = 0; j < K; ++j) {
-            if (j == k) continue;
-            float dot = 0.f;
-            for (int i = lane; i < d; i += 64) dot += s_p[k * d + i] * s_p[j * d + i];
-            dot = osr_wave_sum(dot);
-            if (1.0f - dot < cd) { cd = 1.0f - dot; arg = j; }
+        for (int j = 0; j < KR; ++j) {
+            if (j / R == k / R) continue;
+            const float* pk = s_p + (size_t)k * d;
+            const float dj = osr_pln_distance([&](int i) { return pk[i]; }, s_p + (size_t)j * d, d, lane, dist_type);
+            if (dj < cd) { cd = dj; arg = j; }
         }
         if (lane == 0) { s_arg[k] = arg; s_cd[k] = cd; }
     }
@@ -480,31 +491,33 @@ __global__ __launch_bounds__(256) void pln_bwd_protos_kernel(const float* __rest
         int q = 0;
         for (int ch = threadIdx.x; ch < d; ch += blockDim.x, ++q) {
             float acc = acc4[q];
+            const float pk = s_p[k * d + ch];
             for (int li = 0; li < nlist; ++li) {
                 const long long r = base + s_list[li];
                 const int i0 = pair_idx[r * 2], i1 = pair_idx[r * 2 + 1];
                 const float eh = emb[r * d + ch] * row_inv[r];  // ehat of the row
-                if (i0 == k) acc += pair_coef[r * 2] * eh;
-                if (i1 == k) acc += pair_coef[r * 2 + 1] * eh;
+                if (i0 == k) acc += pair_coef[r * 2] * osr_pln_ddist_db(eh, pk, pair_dist[r * 2], dist_type);
+                if (i1 == k) acc += pair_coef[r * 2 + 1] * osr_pln_ddist_db(eh, pk, pair_dist[r * 2 + 1], dist_type);
             }
             acc4[q] = acc;
         }
         __syncthreads();
     }
+    float* dph = s_p + KR * d + 3 * KR;  // d phat_k staged behind the tables
     int qc = 0;
     for (int ch = threadIdx.x; ch < d; ch += blockDim.x, ++qc) {
         float acc = acc4[qc];
-        // centre term: L += sc * relu(alpha + beta - cd_j) for every j; cd_j = 1 - phat_j . phat_arg(j)
-        //   d/d phat_k gets  -(-sc) ... : dL/dcd_j = -sc [alpha+beta > cd_j];  dcd_j/dphat_j = -phat_arg(j);  dcd_j/dphat_arg(j) = -phat_j
-        for (int j = 0; j < K; ++j) {
+        // centre term: L += sc * relu(alpha + beta - cd_j) for every prototype j; cd_j = dist(phat_j, phat_arg(j))
+        //   dL/dcd_j = -sc [alpha + beta > cd_j];  d phat_k gets dcd_j/dphat_j when k == j and dcd_j/dphat_arg(j) when k == arg(j)
+        for (int j = 0; j < KR; ++j) {
             if (!(alpha + beta - s_cd[j] > 0.f) || s_arg[j] < 0) continue;
-            if (j == k) acc += sc * s_p[s_arg[j] * d + ch];
-            if (s_arg[j] == k) acc += sc * s_p[j * d + ch];
+            const float pj = s_p[j * d + ch], pa = s_p[s_arg[j] * d + ch];
+            if (j == k) acc += -sc * osr_pln_ddist_da(pj, pa, s_cd[j], dist_type);
+            if (s_arg[j] == k) acc += -sc * osr_pln_ddist_db(pj, pa, s_cd[j], dist_type);
         }
-        s_p[K * d + 2 * K + K + ch] = acc;  // d phat_k staged behind the tables
+        dph[ch] = acc;
     }
     __syncthreads();
-    float* dph = s_p + K * d + 3 * K;
     // projection: d p = (d phat - phat (phat . d phat)) / ||p||
     __shared__ float s_dot[4];
     float part = 0.f;
@@ -521,29 +534,50 @@ __global__ __launch_bounds__(256) void pln_bwd_protos_kernel(const float* __rest
     }
 }
 
-extern "C" int64_t osr_pln_loss_bwd_workspace_bytes(int64_t m) { return 16 + m * 20; }
+extern "C" int64_t osr_pln_loss_bwd_workspace_bytes(int64_t m) { return 16 + m * 28; }
 
-extern "C" osr_status osr_pln_loss_bwd(const float* emb, int64_t m, int32_t d, const float* protos_raw, int32_t num_known, const int64_t* gt_classes,
-                                       const float* ious, float iou_thr, float alpha, float beta, float loss_weight, float loss_scale, float* d_emb,
-                                       float* d_protos, int32_t accumulate_protos, void* workspace, int64_t workspace_bytes, void* stream) {
+extern "C" osr_status osr_pln_loss_bwd_ex(const float* emb, int64_t m, int32_t d, const float* protos_raw, int32_t num_known, int32_t reps,
+                                          int32_t distance_type, const int64_t* gt_classes, const float* ious, float iou_thr, float alpha, float beta,
+                                          float loss_weight, float loss_scale, float* d_emb, float* d_protos, int32_t accumulate_protos, void* workspace,
+                                          int64_t workspace_bytes, void* stream) {
     OSR_REQUIRE(emb && protos_raw && gt_classes && ious && d_emb && d_protos && workspace, OSR_ERR_INVALID_ARG, "osr_pln_loss_bwd: null pointer");
-    OSR_REQUIRE(m >= 1 && d >= 1 && d <= 1024 && num_known >= 2 && (long long)num_known * d <= 12288, OSR_ERR_UNSUPPORTED, "osr_pln_loss_bwd: bad sizes");
+    const long long kr = (long long)num_known * reps;
+    OSR_REQUIRE(m >= 1 && d >= 1 && d <= 1024 && num_known >= 2 && reps >= 1 && (kr * d + 3 * kr + d) * 4 <= 144 * 1024, OSR_ERR_UNSUPPORTED,
+                "osr_pln_loss_bwd: bad sizes (the prototypes and their tables must fit 144 KB of LDS)");
+    OSR_REQUIRE(distance_type >= OSR_DIST_COS && distance_type <= OSR_DIST_L2, OSR_ERR_INVALID_ARG, "osr_pln_loss_bwd: distance_type %d", distance_type);
     OSR_REQUIRE(workspace_bytes >= osr_pln_loss_bwd_workspace_bytes(m), OSR_ERR_WORKSPACE, "osr_pln_loss_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float* rows = (float*)workspace;
     int* pair_idx = (int*)((char*)workspace + 16);
     float* pair_coef = (float*)((char*)workspace + 16 + m * 8);
     float* row_inv = (float*)((char*)workspace + 16 + m * 16);
+    float* pair_dist = (float*)((char*)workspace + 16 + m * 20);
     hipLaunchKernelGGL(count_rows_kernel, dim3(1), dim3(256), 0, st, (const long long*)gt_classes, (long long)m, 0, -1, rows);
     OSR_CHECK_LAUNCH("osr_pln_loss_bwd(count)");
     const float s = loss_scale * loss_weight;
-    hipLaunchKernelGGL(pln_bwd_rows_kernel, dim3(256), dim3(256), (size_t)num_known * d * 4, st, emb, (long long)m, d, protos_raw, num_known,
-                       (const long long*)gt_classes, ious, iou_thr, alpha, beta, s, (const float*)rows, d_emb, pair_idx, pair_coef, row_inv);
+    const size_t smem_rows = (size_t)kr * d * 4, smem_protos = (size_t)(kr * d + 3 * kr + d) * 4;
+    if (smem_protos > 64 * 1024) {
+        static osr_dev_mask attr{0};
+        osr_once_per_device(attr, [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pln_bwd_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pln_bwd_protos_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        });
+    }
+    hipLaunchKernelGGL(pln_bwd_rows_kernel, dim3(256), dim3(256), smem_rows, st, emb, (long long)m, d, protos_raw, num_known, reps, distance_type,
+                       (const long long*)gt_classes, ious, iou_thr, alpha, beta, s, (const float*)rows, d_emb, pair_idx, pair_coef, pair_dist, row_inv);
     OSR_CHECK_LAUNCH("osr_pln_loss_bwd(rows)");
-    hipLaunchKernelGGL(pln_bwd_protos_kernel, dim3(num_known), dim3(256), (size_t)(num_known * d + 3 * num_known + d) * 4, st, emb, (long long)m, d, protos_raw,
-                       num_known, (const int*)pair_idx, (const float*)pair_coef, (const float*)row_inv, alpha, beta, s, (const float*)rows, accumulate_protos, d_protos);
+    hipLaunchKernelGGL(pln_bwd_protos_kernel, dim3((unsigned)kr), dim3(256), smem_protos, st, emb, (long long)m, d, protos_raw, num_known, reps, distance_type,
+                       (const int*)pair_idx, (const float*)pair_coef, (const float*)pair_dist, (const float*)row_inv, alpha, beta, s, (const float*)rows,
+                       accumulate_protos, d_protos);
     OSR_CHECK_LAUNCH("osr_pln_loss_bwd(protos)");
     return OSR_OK;
+}
+
+extern "C" osr_status osr_pln_loss_bwd(const float* emb, int64_t m, int32_t d, const float* protos_raw, int32_t num_known, const int64_t* gt_classes,
+                                       const float* ious, float iou_thr, float alpha, float beta, float loss_weight, float loss_scale, float* d_emb,
+                                       float* d_protos, int32_t accumulate_protos, void* workspace, int64_t workspace_bytes, void* stream) {
+    return osr_pln_loss_bwd_ex(emb, m, d, protos_raw, num_known, 1, OSR_DIST_COS, gt_classes, ious, iou_thr, alpha, beta, loss_weight, loss_scale, d_emb,
+                               d_protos, accumulate_protos, workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------

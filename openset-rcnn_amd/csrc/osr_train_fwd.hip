@@ -12,6 +12,7 @@
 // reproducible run to run. Compile with -ffp-contract=off (labels / sampled index lists must be bit-exact).
 #include "osr_common.h"
 #include "osr_box_loss.h"
+#include "osr_pln_dist.h"
 static_assert(OSR_LOSS_IOU == OSR_BOX_LOSS_IOU && OSR_LOSS_SMOOTH_L1 == OSR_BOX_LOSS_SMOOTH_L1 && OSR_LOSS_GIOU == OSR_BOX_LOSS_GIOU &&
                   OSR_LOSS_DIOU == OSR_BOX_LOSS_DIOU && OSR_LOSS_CIOU == OSR_BOX_LOSS_CIOU, "osr_box_loss.h and include/osr.h number the losses alike");
 
@@ -613,11 +614,12 @@ extern "C" osr_status osr_roi_box_losses_fwd(const float* pred_deltas, int32_t d
 // ------------------------------------------------------------------------------------------------------
 // PLN hinge loss forward (prototype_learning_network.py:133-187, COS distance, one prototype per class)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pln_loss_kernel(const float* __restrict__ emb, long long m, int d, const float* __restrict__ protos, int K,
-                                                       const long long* __restrict__ cls, const float* __restrict__ ious, float iou_thr, float alpha,
-                                                       float beta, float* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) float s_p[];  // [K][d]
-    for (int i = threadIdx.x; i < K * d; i += blockDim.x) s_p[i] = protos[i];
+__global__ __launch_bounds__(256) void pln_loss_kernel(const float* __restrict__ emb, long long m, int d, const float* __restrict__ protos, int K, int R,
+                                                       int dist_type, const long long* __restrict__ cls, const float* __restrict__ ious, float iou_thr,
+                                                       float alpha, float beta, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float s_p[];  // [K * R][d]: R prototypes per class, class-major
+    const int KR = K * R;
+    for (int i = threadIdx.x; i < KR * d; i += blockDim.x) s_p[i] = protos[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     float v[4] = {0.f, 0.f, 0.f, 0.f};  // intra, inter, center, rows that count (class >= 0; padding rows carry -1)
@@ -632,24 +634,24 @@ __global__ __launch_bounds__(256) void pln_loss_kernel(const float* __restrict__
         const float den = fmaxf(sqrtf(ss), 1e-12f);
         float intra = 0.f, inter = 1000.f;  // the reference overwrites the own-class column with 1000 before the min
         for (int c = 0; c < K; ++c) {
-            float dot = 0.f;
-            for (int i = lane; i < d; i += 64) dot += (e[i] / den) * s_p[c * d + i];
-            dot = osr_wave_sum(dot);
-            const float dist = 1.0f - dot;
+            float dist = 0.f;  // min over the class's prototypes (prototype_learning_network.py:163)
+            for (int q = 0; q < R; ++q) {
+                const float dq = osr_pln_distance([&](int i) { return e[i] / den; }, s_p + (size_t)(c * R + q) * d, d, lane, dist_type);
+                dist = (q == 0 || dq < dist) ? dq : dist;
+            }
             if (c == (int)y) intra = dist; else inter = fminf(inter, dist);
         }
         if (lane == 0) { v[0] += fmaxf(intra - alpha, 0.f); v[1] += fmaxf(beta - inter, 0.f); }
     }
-    // prototype-to-prototype term, once (workgroup 0): c_dist[k] = min_{j != k} (1 - p_k . p_j)
+    // prototype-to-prototype term, once (workgroup 0): c_dist[k] = min over the prototypes j of OTHER classes of dist(p_k, p_j)
+    // (prototype_learning_network.py:170-180: the diagonal class blocks are overwritten with 1000)
     if (blockIdx.x == 0) {
-        for (int k = wid; k < K; k += nw) {
+        for (int k = wid; k < KR; k += nw) {
             float cd = 1000.f;
-            for (int j = 0; j < K; ++j) {
-                if (j == k) continue;
-                float dot = 0.f;
-                for (int i = lane; i < d; i += 64) dot += s_p[k * d + i] * s_p[j * d + i];
-                dot = osr_wave_sum(dot);
-                cd = fminf(cd, 1.0f - dot);
+            for (int j = 0; j < KR; ++j) {
+                if (j / R == k / R) continue;
+                const float* pk = s_p + (size_t)k * d;
+                cd = fminf(cd, osr_pln_distance([&](int i) { return pk[i]; }, s_p + (size_t)j * d, d, lane, dist_type));
             }
             if (lane == 0) v[2] += fmaxf(beta + alpha - cd, 0.f);
         }
@@ -665,20 +667,34 @@ __global__ void pln_finish(const float* __restrict__ partial, int nblocks, float
     out[0] = ((a + b) + c) * scale / fmaxf(rows, 1.0f);
 }
 
-extern "C" osr_status osr_pln_loss_fwd(const float* emb, int64_t m, int32_t d, const float* protos_normed, int32_t num_known, const int64_t* gt_classes,
-                                       const float* ious, float iou_thr, float alpha, float beta, float loss_weight, float* out1, void* workspace,
-                                       int64_t workspace_bytes, void* stream) {
+extern "C" osr_status osr_pln_loss_fwd_ex(const float* emb, int64_t m, int32_t d, const float* protos_normed, int32_t num_known, int32_t reps,
+                                          int32_t distance_type, const int64_t* gt_classes, const float* ious, float iou_thr, float alpha, float beta,
+                                          float loss_weight, float* out1, void* workspace, int64_t workspace_bytes, void* stream) {
     OSR_REQUIRE(emb && protos_normed && gt_classes && ious && out1 && workspace, OSR_ERR_INVALID_ARG, "osr_pln_loss_fwd: null pointer");
-    OSR_REQUIRE(m >= 0 && d >= 1 && num_known >= 1 && (long long)num_known * d <= 16384, OSR_ERR_UNSUPPORTED, "osr_pln_loss_fwd: bad sizes");
+    OSR_REQUIRE(m >= 0 && d >= 1 && num_known >= 1 && reps >= 1 && (long long)num_known * reps * d <= 36864, OSR_ERR_UNSUPPORTED,
+                "osr_pln_loss_fwd: bad sizes (the prototypes must fit a 144 KB LDS table)");
+    OSR_REQUIRE(distance_type >= OSR_DIST_COS && distance_type <= OSR_DIST_L2, OSR_ERR_INVALID_ARG, "osr_pln_loss_fwd: distance_type %d", distance_type);
     OSR_REQUIRE(workspace_bytes >= (int64_t)RED_BLOCKS * 4 * 4, OSR_ERR_WORKSPACE, "osr_pln_loss_fwd: workspace needs %d bytes", RED_BLOCKS * 4 * 4);
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)workspace;
-    hipLaunchKernelGGL(pln_loss_kernel, dim3(RED_BLOCKS), dim3(256), (size_t)num_known * d * 4, st, emb, (long long)m, d, protos_normed, num_known,
+    const size_t smem = (size_t)num_known * reps * d * 4;
+    if (smem > 64 * 1024) {
+        static osr_dev_mask attr{0};
+        osr_once_per_device(attr, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pln_loss_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); });
+    }
+    hipLaunchKernelGGL(pln_loss_kernel, dim3(RED_BLOCKS), dim3(256), smem, st, emb, (long long)m, d, protos_normed, num_known, reps, distance_type,
                        (const long long*)gt_classes, ious, iou_thr, alpha, beta, partial);
     OSR_CHECK_LAUNCH("osr_pln_loss_fwd");
     hipLaunchKernelGGL(pln_finish, dim3(1), dim3(64), 0, st, (const float*)partial, RED_BLOCKS, loss_weight, out1);
     OSR_CHECK_LAUNCH("osr_pln_loss_fwd(final)");
     return OSR_OK;
+}
+
+extern "C" osr_status osr_pln_loss_fwd(const float* emb, int64_t m, int32_t d, const float* protos_normed, int32_t num_known, const int64_t* gt_classes,
+                                       const float* ious, float iou_thr, float alpha, float beta, float loss_weight, float* out1, void* workspace,
+                                       int64_t workspace_bytes, void* stream) {
+    return osr_pln_loss_fwd_ex(emb, m, d, protos_normed, num_known, 1, OSR_DIST_COS, gt_classes, ious, iou_thr, alpha, beta, loss_weight, out1, workspace,
+                               workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------

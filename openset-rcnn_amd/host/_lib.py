@@ -42,6 +42,7 @@ class LossOptions(C.Structure):
 
 
 BOX_LOSS_TYPES = {"iou": 0, "smooth_l1": 1, "giou": 2, "diou": 3, "ciou": 4}
+PLN_DISTANCES = {"COS": 0, "L1": 1, "L2": 2}
 
 
 class RpnLevels(C.Structure):
@@ -95,6 +96,7 @@ PROTOTYPES = {
     "osr_gather_rows": (I32, [P, I64, I32, P, P, I32, I32, P, P]),
     "osr_l2_normalize_rows": (I32, [P, I32, I32, P, P]),
     "osr_pln_tail": (I32, [P, I64, I32, P, I32, I32, F32, I64, P, P, I32, P, P, P]),
+    "osr_pln_tail_ex": (I32, [P, I64, I32, P, I32, I32, I32, F32, I64, P, P, I32, P, P, P]),
     "osr_softmax_candidates": (I32, [P, I32, P, P, P, P, I32, I32, I64, F32, F32, P, P, P, P, P, P, P, P, P, P]),
     "osr_assemble_detections": (I32, [P, P, P, P, P, I64, I32, P, P, P, P, I64, I32, I32, I64, P, P, P, P, P, P]),
     "osr_detector_postprocess": (I32, [P, P, P, P, I32, I32, P, P, P, P, P, P, P]),
@@ -109,6 +111,7 @@ PROTOTYPES = {
     "osr_roi_box_losses_fwd": (I32, [P, I32, P, I32, I32, P, P, P, P, I64, I32, P, F32, F32, P, P, I64, P]),
     "osr_roi_box_losses_fwd_ex": (I32, [P, I32, P, I32, I32, P, P, P, P, I64, I32, P, F32, F32, P, P, P, I64, P]),
     "osr_pln_loss_fwd": (I32, [P, I64, I32, P, I32, P, P, F32, F32, F32, F32, P, P, I64, P]),
+    "osr_pln_loss_fwd_ex": (I32, [P, I64, I32, P, I32, I32, I32, P, P, F32, F32, F32, F32, P, P, I64, P]),
     "osr_softmax_ce_loss_fwd": (I32, [P, I64, I32, P, I32, F32, P, P, I64, P]),
     # training step, backward half
     "osr_conv2d_wgrad_workspace_bytes": (I64, [P]),
@@ -123,6 +126,7 @@ PROTOTYPES = {
     "osr_softmax_ce_loss_bwd": (I32, [P, I64, I32, P, I32, F32, F32, P, P, I64, P]),
     "osr_pln_loss_bwd_workspace_bytes": (I64, [I64]),
     "osr_pln_loss_bwd": (I32, [P, I64, I32, P, I32, P, P, F32, F32, F32, F32, F32, P, P, I32, P, I64, P]),
+    "osr_pln_loss_bwd_ex": (I32, [P, I64, I32, P, I32, I32, I32, P, P, F32, F32, F32, F32, F32, P, P, I32, P, I64, P]),
     "osr_roi_align_bwd": (I32, [P, I32, P, P, I64, I32, I32, I32, I32, P, I32, P]),
     "osr_relu_mask": (I32, [P, I32, P, I32, I64, P]),
     "osr_add_cast": (I32, [P, P, P, I32, I64, P]),

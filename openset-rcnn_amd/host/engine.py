@@ -28,7 +28,7 @@ DEFAULT_CFG = dict(
     obj_score_thresh=0.05, nms_thresh_test=1.0, detections_per_image=1000,
     known_score_thresh=0.05, known_nms_thresh=0.5, known_topk=50,
     unknown_score_thresh=0.0, unknown_nms_thresh=0.5, unknown_topk=50,
-    num_classes=81, num_known=20, reps_per_class=1, unknown_id=80, unk_thr=0.23,
+    num_classes=81, num_known=20, reps_per_class=1, pln_distance="COS", unknown_id=80, unk_thr=0.23,
     # training step (configs/VOC-COCO/openset_rcnn_R50_FPN_128k.yaml + [d2] defaults)
     pre_nms_topk_train=2000, rpn_batch_size=256, rpn_positive_fraction=0.5, rpn_positive_fraction_objectness=1.0,
     rpn_iou_thresholds=(0.3, 0.7), rpn_iou_thresholds_objectness=(0.1, 0.3), rpn_loc_weight=0.5, rpn_ctr_weight=0.5,
@@ -297,7 +297,7 @@ class OpensetRCNNEngine:
         emb = ops.gemm_f32(det_feats.view(n * topk1, -1), self.enc_w, self.enc_b)
         rec = ops.gemm_f32(emb, self.dec_w, self.dec_b)
         pcls, mind = ops.pln_tail(emb, self.protos, c["num_known"], c["reps_per_class"], c["unk_thr"], c["unknown_id"], self.class_map,
-                                  cnt1, topk1)
+                                  cnt1, topk1, distance=c["pln_distance"])
         logits = ops.gemm_f32(rec, self.cls_w, self.cls_b)
         # class_map (GraspNet) remaps known ids at the very end; the known/unknown split uses the un-mapped unknown id
         cands = ops.softmax_candidates(logits, c["num_known"], det_boxes.view(-1, 4), det_scores.view(-1), pcls, cnt1, n, topk1,
@@ -457,7 +457,8 @@ class OpensetRCNNEngine:
         cls_k, nck = self.known_class_targets(cls)
         emb = ops.gemm_f32(box_feats, self.enc_w, self.enc_b)
         rec = ops.gemm_f32(emb, self.dec_w, self.dec_b)
-        dml = ops.pln_loss_fwd(emb, self.protos, cls_k, ious, c["pln_iou_threshold"], c["pln_alpha"], c["pln_beta"], c["pln_loss_weight"])
+        dml = ops.pln_loss_fwd(emb, self.protos, cls_k, ious, c["pln_iou_threshold"], c["pln_alpha"], c["pln_beta"], c["pln_loss_weight"],
+                               reps=c["reps_per_class"], distance=c["pln_distance"])
         logits = ops.gemm_f32(rec, self.cls_w, self.cls_b)
         ce = ops.softmax_ce_loss_fwd(logits, cls_k, nck, c["cls_loss_weight"])
         state = dict(smp=smp, sampled=smp, boxes=boxes, pooled=pooled, h1=h1, box_feats=box_feats, pred=pred, emb=emb, rec=rec, logits=logits,

@@ -442,7 +442,8 @@ class PLN(nn.Module):
     def __init__(self, cfg: CfgNode):
         super().__init__()
         fd, ed = cfg.MODEL.ROI_BOX_HEAD.FC_DIM, cfg.MODEL.PLN.EMD_DIM
-        assert cfg.MODEL.PLN.DISTANCE_TYPE == "COS", "the yaml files use the cosine distance"
+        if cfg.MODEL.PLN.DISTANCE_TYPE not in ("COS", "L1", "L2"):
+            raise ValueError(f"MODEL.PLN.DISTANCE_TYPE '{cfg.MODEL.PLN.DISTANCE_TYPE}': one of COS, L1, L2 (prototype_learning_network.py:155-160)")
         self.encoder = nn.Linear(fd, ed)
         self.decoder = nn.Linear(ed, fd)
         for l in (self.encoder, self.decoder):
@@ -472,7 +473,7 @@ def engine_cfg_from(cfg: CfgNode) -> dict:
         obj_score_thresh=rh.OBJ_SCORE_THRESH_TEST, nms_thresh_test=rh.NMS_THRESH_TEST, detections_per_image=cfg.TEST.DETECTIONS_PER_IMAGE,
         known_score_thresh=rh.KNOWN_SCORE_THRESH, known_nms_thresh=rh.KNOWN_NMS_THRESH, known_topk=rh.KNOWN_TOPK,
         unknown_score_thresh=rh.UNKNOWN_SCORE_THRESH, unknown_nms_thresh=rh.UNKNOWN_NMS_THRESH, unknown_topk=rh.UNKNOWN_TOPK,
-        num_classes=rh.NUM_CLASSES, num_known=rh.NUM_KNOWN_CLASSES, reps_per_class=cfg.MODEL.PLN.REPS_PER_CLASS,
+        num_classes=rh.NUM_CLASSES, num_known=rh.NUM_KNOWN_CLASSES, reps_per_class=cfg.MODEL.PLN.REPS_PER_CLASS, pln_distance=cfg.MODEL.PLN.DISTANCE_TYPE,
         # the reference hard-codes the unknown id: 80 with --opendet-benchmark, else 1000
         unknown_id=80 if cfg.OPENDET_BENCHMARK else 1000, unk_thr=cfg.MODEL.PLN.UNK_THR,
         # training step

@@ -461,8 +461,14 @@ def l2_normalize_rows(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _pln_distance(name: str) -> int:
+    if name not in _lib.PLN_DISTANCES:
+        raise OsrError(f"MODEL.PLN.DISTANCE_TYPE '{name}': one of {sorted(_lib.PLN_DISTANCES)}")
+    return _lib.PLN_DISTANCES[name]
+
+
 def pln_tail(emb, protos_normed, num_known: int, reps: int, unk_thr: float, unknown_id: int, class_map=None, rows_valid=None,
-             seg_rows: int = 0):
+             seg_rows: int = 0, distance: str = "COS"):
     lib = _lib.load()
     _need(emb, torch.float32, "emb"); _need(protos_normed, torch.float32, "protos")
     if class_map is not None:
@@ -472,8 +478,8 @@ def pln_tail(emb, protos_normed, num_known: int, reps: int, unk_thr: float, unkn
     rows, d = emb.shape
     pc = torch.empty((rows,), dtype=torch.int64, device=emb.device)
     md = torch.empty((rows,), dtype=torch.float32, device=emb.device)
-    check(lib.osr_pln_tail(_p(emb), rows, d, _p(protos_normed), num_known, reps, float(unk_thr), int(unknown_id), _p(class_map),
-                           _p(rows_valid), seg_rows, _p(pc), _p(md), _stream()), "osr_pln_tail")
+    check(lib.osr_pln_tail_ex(_p(emb), rows, d, _p(protos_normed), num_known, reps, _pln_distance(distance), float(unk_thr), int(unknown_id),
+                              _p(class_map), _p(rows_valid), seg_rows, _p(pc), _p(md), _stream()), "osr_pln_tail")
     return pc, md
 
 
@@ -658,15 +664,18 @@ def roi_box_losses_fwd(pred_deltas, pred_iou, proposal_boxes, gt_boxes, gt_class
     return out
 
 
-def pln_loss_fwd(emb, protos_normed, gt_classes, ious, iou_thr: float, alpha: float, beta: float, loss_weight: float) -> torch.Tensor:
+def pln_loss_fwd(emb, protos_normed, gt_classes, ious, iou_thr: float, alpha: float, beta: float, loss_weight: float, reps: int = 1,
+                 distance: str = "COS") -> torch.Tensor:
+    """protos_normed: (num_known * reps, d), the reps prototypes of a class next to each other (prototype_learning_network.py:163)."""
     lib = _lib.load()
     _need(emb, torch.float32, "emb"); _need(protos_normed, torch.float32, "protos_normed"); _need(gt_classes, torch.int64, "gt_classes")
     _need(ious, torch.float32, "ious")
     m, d = emb.shape
     out = torch.empty((1,), dtype=torch.float32, device=emb.device)
     ws = _loss_ws(emb.device, 4)
-    check(lib.osr_pln_loss_fwd(_p(emb), m, d, _p(protos_normed), protos_normed.shape[0], _p(gt_classes), _p(ious), iou_thr, alpha, beta,
-                               loss_weight, _p(out), _p(ws), ws.numel(), _stream()), "osr_pln_loss_fwd")
+    assert protos_normed.shape[0] % reps == 0
+    check(lib.osr_pln_loss_fwd_ex(_p(emb), m, d, _p(protos_normed), protos_normed.shape[0] // reps, reps, _pln_distance(distance), _p(gt_classes),
+                                  _p(ious), iou_thr, alpha, beta, loss_weight, _p(out), _p(ws), ws.numel(), _stream()), "osr_pln_loss_fwd")
     return out
 
 
@@ -850,8 +859,9 @@ def softmax_ce_loss_bwd(logits, gt_classes, num_classes: int, loss_weight: float
     return out
 
 
-def pln_loss_bwd(emb, protos_raw, gt_classes, ious, iou_thr: float, alpha: float, beta: float, loss_weight: float, loss_scale=1.0):
-    """-> (d_emb (m,d), d_protos (K,d)) fp32; protos_raw are the un-normalised prototype parameters."""
+def pln_loss_bwd(emb, protos_raw, gt_classes, ious, iou_thr: float, alpha: float, beta: float, loss_weight: float, loss_scale=1.0, reps: int = 1,
+                 distance: str = "COS"):
+    """-> (d_emb (m,d), d_protos (K * reps,d)) fp32; protos_raw are the un-normalised prototype parameters."""
     lib = _lib.load()
     _need(emb, torch.float32, "emb"); _need(protos_raw, torch.float32, "protos_raw")
     m, d = emb.shape
@@ -859,8 +869,9 @@ def pln_loss_bwd(emb, protos_raw, gt_classes, ious, iou_thr: float, alpha: float
     dp = torch.empty_like(protos_raw)
     wsb = lib.osr_pln_loss_bwd_workspace_bytes(m)
     ws = torch.empty((wsb,), dtype=torch.uint8, device=emb.device)
-    check(lib.osr_pln_loss_bwd(_p(emb), m, d, _p(protos_raw), protos_raw.shape[0], _p(gt_classes), _p(ious), iou_thr, alpha, beta, loss_weight,
-                               loss_scale, _p(de), _p(dp), 0, _p(ws), wsb, _stream()), "osr_pln_loss_bwd")
+    assert protos_raw.shape[0] % reps == 0
+    check(lib.osr_pln_loss_bwd_ex(_p(emb), m, d, _p(protos_raw), protos_raw.shape[0] // reps, reps, _pln_distance(distance), _p(gt_classes), _p(ious),
+                                  iou_thr, alpha, beta, loss_weight, loss_scale, _p(de), _p(dp), 0, _p(ws), wsb, _stream()), "osr_pln_loss_bwd")
     return de, dp
 
 

@@ -239,7 +239,7 @@ class OpensetRCNNTrainer:
                                         iou_beta=lt["roi_iou"][1])
         d_logits = ops.softmax_ce_loss_bwd(s["logits"], s["cls_k"], s["nck"], c["cls_loss_weight"], S)
         d_emb_pln, d_protos = ops.pln_loss_bwd(s["emb"], self.master["protos"], s["cls_k"], s["ious"], c["pln_iou_threshold"], c["pln_alpha"],
-                                               c["pln_beta"], c["pln_loss_weight"], S)
+                                               c["pln_beta"], c["pln_loss_weight"], S, reps=c["reps_per_class"], distance=c["pln_distance"])
         g["protos"].copy_(d_protos)
         self._done("protos")
         d_rec = self._f32_linear_bwd(s["rec"], d_logits, self.t_cls, "cls", dy_pad=32)

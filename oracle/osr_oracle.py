@@ -595,16 +595,27 @@ def fast_rcnn_inference_single_image(boxes, scores, image_shape, feats, score_th
 # --------------------------------------------------------------------------------------
 
 
+def pln_distance(a: torch.Tensor, b: torch.Tensor, kind: str = "COS") -> torch.Tensor:
+    """MODEL.PLN.DISTANCE_TYPE between rows of a and rows of b (prototype_learning_network.py:155-160, 213-218)."""
+    if kind == "L1":
+        return torch.cdist(a, b, p=1.0)
+    if kind == "L2":
+        return torch.cdist(a, b)
+    if kind == "COS":
+        return 1.0 - a @ b.t()
+    raise ValueError(f"MODEL.PLN.DISTANCE_TYPE '{kind}'")
+
+
 def pln_inference(feats: torch.Tensor, p: Dict[str, torch.Tensor], unk_thr: float, unknown_id: int = 80,
                   num_known: int = 20, reps: int = 1, class_id: Optional[torch.Tensor] = None,
-                  prefix="roi_heads.dml"):
-    """PLN.inference, COS distance (prototype_learning_network.py:199-226). Returns
+                  prefix="roi_heads.dml", distance: str = "COS"):
+    """PLN.inference (prototype_learning_network.py:199-226). Returns
     (pred_classes int64, rec_features, min_dist, emb)."""
     rep = F.normalize(p[prefix + ".representatives"])
     emb = F.linear(feats, p[prefix + ".encoder.weight"], p[prefix + ".encoder.bias"])
     rec = F.linear(emb, p[prefix + ".decoder.weight"], p[prefix + ".decoder.bias"])
     new = F.normalize(emb)
-    dist = 1.0 - new @ rep.t()
+    dist = pln_distance(new, rep, distance)
     md, _ = torch.min(dist.reshape(-1, num_known, reps), dim=2)
     md, mi = torch.min(md, dim=1)
     unknown = md > unk_thr
@@ -796,25 +807,32 @@ def centerness_target(anchors: torch.Tensor, matched_gt: torch.Tensor, obj_label
     return c
 
 
-def pln_loss(feats, gt_classes, ious, p, alpha, beta, loss_weight, num_known=20, iou_thr=0.5, prefix="roi_heads.dml"):
-    """PLN.loss, COS distance, reps_per_class=1 (prototype_learning_network.py:133-187)."""
+def pln_loss_terms(new, rep, gt_classes, ious, alpha, beta, num_known=20, iou_thr=0.5, reps=1, distance="COS"):
+    """The three hinge sums of PLN.loss on normalised embeddings `new` and normalised prototypes `rep` (num_known * reps rows,
+    class-major): prototype_learning_network.py:149-185."""
+    fg = torch.nonzero((gt_classes >= 0) & (gt_classes < num_known) & (ious > iou_thr)).squeeze(1)
+    dist = pln_distance(new[fg], rep, distance)
+    md = dist.reshape(-1, num_known, reps).min(dim=2)[0]
+    ar = torch.arange(md.shape[0])
+    intra = md[ar, gt_classes[fg]]
+    d2 = md.clone()
+    d2[ar, gt_classes[fg]] = 1000
+    inter = d2.min(dim=1)[0] if d2.shape[0] else d2.new_zeros(0)
+    cd = pln_distance(rep, rep, distance).clone()
+    for i in range(num_known):
+        cd[i * reps:(i + 1) * reps, i * reps:(i + 1) * reps] = 1000
+    cdist = cd.min(dim=1)[0]
+    return (torch.clamp(intra - alpha, min=0).sum() + torch.clamp(beta - inter, min=0).sum()
+            + torch.clamp(beta + alpha - cdist, min=0).sum())
+
+
+def pln_loss(feats, gt_classes, ious, p, alpha, beta, loss_weight, num_known=20, iou_thr=0.5, prefix="roi_heads.dml", reps=1, distance="COS"):
+    """PLN.loss (prototype_learning_network.py:133-187); both yaml files: COS distance, one prototype per class."""
     emb = F.linear(feats, p[prefix + ".encoder.weight"], p[prefix + ".encoder.bias"])
     new = F.normalize(emb)
     rec = F.linear(emb, p[prefix + ".decoder.weight"], p[prefix + ".decoder.bias"])
     rep = F.normalize(p[prefix + ".representatives"])
-    fg = torch.nonzero((gt_classes >= 0) & (gt_classes < num_known) & (ious > iou_thr)).squeeze(1)
-    dist = 1.0 - new[fg] @ rep.t()
-    ar = torch.arange(dist.shape[0])
-    intra = dist[ar, gt_classes[fg]]
-    d2 = dist.clone()
-    d2[ar, gt_classes[fg]] = 1000
-    inter = d2.min(dim=1)[0] if d2.shape[0] else d2.new_zeros(0)
-    cd = 1.0 - rep @ rep.t()
-    cd = cd.clone()
-    cd[torch.arange(num_known), torch.arange(num_known)] = 1000
-    cdist = cd.min(dim=1)[0]
-    loss = (torch.clamp(intra - alpha, min=0).sum() + torch.clamp(beta - inter, min=0).sum()
-            + torch.clamp(beta + alpha - cdist, min=0).sum())
+    loss = pln_loss_terms(new, rep, gt_classes, ious, alpha, beta, num_known, iou_thr, reps, distance)
     return emb, rec, loss * loss_weight / max(gt_classes.numel(), 1.0)
 
 

@@ -327,3 +327,43 @@ def test_loss_type_is_validated(ops):
         check_supported_losses(dict(loss_types=dict(roi_iou=("giou", 0.0))))
     with pytest.raises(OsrError):
         ops._loss_options(("huber", 0.0), 0.0)
+
+
+@pytest.mark.parametrize("distance,reps,d", [("COS", 1, 256), ("COS", 3, 256), ("L1", 1, 256), ("L2", 1, 256), ("L1", 2, 128), ("L2", 5, 256)])
+def test_pln_loss_distances_and_prototypes_per_class(ops, distance, reps, d):
+    """MODEL.PLN.DISTANCE_TYPE 'COS' | 'L1' | 'L2' and REPS_PER_CLASS >= 1 (prototype_learning_network.py:149-187: a class's distance
+    is the minimum over its prototypes; the prototype term excludes the own-class block): loss against the oracle (1e-5), gradients
+    w.r.t. the embeddings and the raw prototypes against autograd (1e-4), inference classes / distances (pln_tail) against the oracle."""
+    gg = g(211 + reps)
+    m, K, NC = 384, 20, 81
+    cls = torch.randint(0, K, (m,), generator=gg)
+    cls[torch.rand(m, generator=gg) < 0.5] = NC
+    cls[m - 12:] = -1
+    gi = torch.rand(m, generator=gg)
+    protos = (torch.randn(K * reps, d, generator=gg) * 1.5).requires_grad_(True)
+    anchor = protos.detach()[(cls.clamp(0, K - 1) * reps + torch.randint(0, reps, (m,), generator=gg))]
+    emb = (torch.randn(m, d, generator=gg) + 0.9 * anchor).requires_grad_(True)
+    # hinge constants that leave all three terms active for every distance (the distances' scales differ)
+    with torch.no_grad():
+        dd = O.pln_distance(F.normalize(emb), F.normalize(protos), distance)
+        alpha, beta = float(dd.min(dim=1)[0].median()) * 0.9, float(dd.median()) * 1.05
+    ok = cls >= 0
+    loss = O.pln_loss_terms(F.normalize(emb[ok]), F.normalize(protos), cls[ok], gi[ok], alpha, beta, K, 0.5, reps, distance) * 0.5 / float(ok.sum())
+    loss.backward()
+    got = ops.pln_loss_fwd(emb.detach().to(DEV), F.normalize(protos.detach()).to(DEV), cls.to(DEV), gi.to(DEV), 0.5, alpha, beta, 0.5, reps=reps,
+                           distance=distance)
+    assert float(got) == pytest.approx(float(loss), rel=2e-5)
+    de, dp = ops.pln_loss_bwd(emb.detach().to(DEV), protos.detach().to(DEV), cls.to(DEV), gi.to(DEV), 0.5, alpha, beta, 0.5, loss_scale=32.0, reps=reps,
+                              distance=distance)
+    assert float(emb.grad.abs().sum()) > 0 and float(protos.grad.abs().sum()) > 0
+    assert rel(de / 32.0, emb.grad) < 1e-4
+    assert rel(dp / 32.0, protos.grad) < 1e-4
+    # inference: nearest class over min-over-reps distances, unknown beyond the threshold
+    md, mi = dd.reshape(m, K, reps).min(dim=2)[0].min(dim=1)
+    thr = float(md.median())
+    pc, mind = ops.pln_tail(emb.detach().to(DEV), F.normalize(protos.detach()).to(DEV), K, reps, thr, 80, distance=distance)
+    want = mi.clone()
+    want[md > thr] = 80
+    near = (md - thr).abs() < 1e-5 * max(thr, 1.0)
+    assert torch.equal(pc.cpu()[~near], want[~near])
+    assert rel(mind, md) < 1e-5

@@ -197,3 +197,28 @@ def test_training_step_with_the_other_reference_losses(setup):
     assert l1["loss_rpn_ctr"] < l0["loss_rpn_ctr"]              # smooth L1 with beta > 0 <= L1
     assert l1["loss_iou"] < l0["loss_iou"] and l1["loss_box_reg"] != pytest.approx(l0["loss_box_reg"], rel=1e-3)
     assert hist[-1] < 0.95 * hist[0], hist
+
+
+def test_training_step_with_l2_distance_and_two_prototypes_per_class(setup):
+    """MODEL.PLN.DISTANCE_TYPE 'L2' with REPS_PER_CLASS 2 through the whole step (prototype_learning_network.py:155-180): the
+    (40, 256) prototype parameter trains, losses stay finite and fall."""
+    from openset_rcnn_amd.host.train import OpensetRCNNTrainer
+    d = setup["dev"]
+    args = (d["images"], d["hw"], setup["h"], setup["w"], d["gt"], d["gcls"], d["gcnt"], d["keys"])
+    params = dict(setup["params"])
+    rep = params["roi_heads.dml.representatives"]
+    params["roi_heads.dml.representatives"] = torch.cat((rep, rep + 0.3 * torch.randn(rep.shape, generator=torch.Generator().manual_seed(5))), 1).reshape(-1, rep.shape[1])
+    tr = OpensetRCNNTrainer(params, cfg=dict(reps_per_class=2, pln_distance="L2", pln_alpha=0.6, pln_beta=1.2), dtype=torch.float16, device=DEV, lr=5e-5,
+                            loss_scale=512.0)
+    assert tuple(tr.master["protos"].shape) == (2 * rep.shape[0], rep.shape[1])
+    before = tr.master["protos"].clone()
+    hist = []
+    for _ in range(4):
+        losses = tr.step(*args)
+        hist.append({k: float(v) for k, v in losses.items()})
+    tot = [sum(h.values()) for h in hist]
+    assert all(torch.isfinite(torch.tensor(tot))), tot
+    assert hist[0]["loss_dml"] > 0 and tot[-1] < tot[0]
+    assert not torch.equal(tr.master["protos"], before)
+    out = tr.export_state_dict()["roi_heads.dml.representatives"]
+    assert tuple(out.shape) == (2 * rep.shape[0], rep.shape[1])
