@@ -279,3 +279,72 @@ def _check_graspnet_tail(eng, params, keep, out, sizes, thr, K, UNK, class_map):
         seen_known += int((rc != UNK).sum())
         seen_unknown += int((rc == UNK).sum())
     return seen_known, seen_unknown
+
+
+def test_graspnet_resolution_batch_of_eight(osr):
+    """BASELINE config 3's per-GPU workload: eight 1280x720 frames after ResizeShortestEdge(800, 1333) = 750x1333, padded to 768x1344
+    (SURVEY 8d), GraspNet head sizes (28 known of 88 classes, unknown id 1000), inference and one training step at full size.
+    Size-independent properties: every count within its capacity, boxes inside the image, scores descending per group, the same
+    batch split 5 + 3 gives the same detections (images are independent), the hipGraph replay reproduces the eager pass, and the
+    training step's six losses are finite with every gradient bucket written."""
+    from openset_rcnn_amd.host.engine import OpensetRCNNEngine
+    from openset_rcnn_amd.host.train import OpensetRCNNTrainer
+    from openset_rcnn_amd.host.weights import random_params, with_known_unknown_mix
+    K, UNK, n, h, w = 28, 1000, 8, 750, 1333
+    params = random_params(0, num_known=K)
+    class_map = torch.arange(0, 88, 3)[:K].to(torch.int64) + 1
+    cfg = dict(num_known=K, num_classes=88, unknown_id=UNK, unk_thr=0.09)
+    g = torch.Generator().manual_seed(21)
+    images = torch.randint(0, 256, (n, 3, h, w), generator=g, dtype=torch.uint8).to(DEV)
+    hw = torch.tensor([(h, w)] * n, dtype=torch.int32, device=DEV)
+    cal = OpensetRCNNEngine(params, cfg, torch.float16, DEV, class_map)
+    keep = {}
+    cal.forward_device(images[:2], hw[:2], 768, 1344, keep)
+    cnt = keep["cnt1"].cpu()
+    emb = torch.cat([keep["emb"].view(2, -1, keep["emb"].shape[-1])[i, :int(cnt[i])] for i in range(2)]).cpu()
+    params = with_known_unknown_mix(params, emb, unk_thr=0.09)
+    eng = OpensetRCNNEngine(params, cfg, torch.float16, DEV, class_map)
+    ob, osc, ocl, on = [t.cpu() for t in eng.forward_device(images, hw, 768, 1344)]
+    assert ob.shape == (n, 100, 4) and int(on.min()) > 0 and int(on.max()) <= 100
+    known_ids = set(class_map.tolist())
+    seen_known = seen_unknown = 0
+    for i in range(n):
+        c = int(on[i])
+        b, s, k = ob[i, :c], osc[i, :c], ocl[i, :c]
+        assert bool((b[:, 0] >= 0).all() and (b[:, 1] >= 0).all() and (b[:, 2] <= w).all() and (b[:, 3] <= h).all())
+        assert bool(torch.isfinite(s).all()) and set(k.tolist()) <= known_ids | {UNK}
+        unk = k == UNK
+        seen_known += int((~unk).sum()); seen_unknown += int(unk.sum())
+        for grp in (s[unk], s[~unk]):  # [unknown..., known...], each sorted by score (softmax_classifier.py:334)
+            assert bool((grp[1:] <= grp[:-1]).all())
+    assert seen_known > 0 and seen_unknown > 0
+    a = [t.cpu() for t in eng.forward_device(images[:5], hw[:5], 768, 1344)]
+    b2 = [t.cpu() for t in eng.forward_device(images[5:], hw[5:], 768, 1344)]
+    for full, pa, pb in zip((ob, osc, ocl, on), a, b2):
+        assert torch.equal(full, torch.cat((pa, pb)))
+    graph, gout = eng.capture(images, hw, 768, 1344, 2)
+    graph.replay()
+    torch.cuda.synchronize()
+    for full, got in zip((ob, osc, ocl, on), gout):
+        assert torch.equal(full, got.cpu())
+    # one training step of the same configuration (id_map through class_map), 6 ground-truth boxes per frame
+    tr = OpensetRCNNTrainer(params, cfg=cfg, dtype=torch.float16, device=DEV, lr=1e-5, loss_scale=512.0, class_map=class_map)
+    ngt = 6
+    ctr = torch.rand(n, ngt, 2, generator=g) * torch.tensor([w * 0.8, h * 0.8]) + 40
+    size = torch.rand(n, ngt, 2, generator=g) * 300 + 32
+    gt = torch.cat((ctr - size / 2, ctr + size / 2), dim=2)
+    gt[..., 0::2].clamp_(0, w); gt[..., 1::2].clamp_(0, h)
+    gcls = class_map[torch.randint(0, K, (n, ngt), generator=g)]
+    gcnt = torch.full((n,), ngt, dtype=torch.int32)
+    shapes = eng.pyramid_shapes(768, 1344)
+    assert shapes == [(192, 336), (96, 168), (48, 84), (24, 42), (12, 21)]
+    r = sum(a_ * b_ for a_, b_ in shapes)
+    cap = sum(min(2000, a_ * b_) for a_, b_ in shapes)
+    keys = {k_: torch.rand(s_, generator=g).to(DEV) for k_, s_ in (("rpn_reg", (n, r)), ("rpn_obj", (n, r)), ("roi", (n, cap + ngt)))}
+    tr.grad_flat.fill_(float("nan"))
+    losses = tr.step(images, hw, 768, 1344, gt.to(DEV), gcls.to(DEV), gcnt.to(DEV), keys, update=False)
+    vals = {k_: float(v) for k_, v in losses.items()}
+    assert set(vals) == {"loss_rpn_loc", "loss_rpn_ctr", "loss_box_reg", "loss_iou", "loss_dml", "loss_cls"}
+    assert all(v == v and abs(v) < 1e3 for v in vals.values()), vals
+    for name, gview in tr.grad.items():
+        assert bool(torch.isfinite(gview).all()), name  # every parameter's gradient was written (no NaN left from the fill)
