@@ -339,25 +339,65 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
     static_assert(PSTEP >= 1, "more staging pieces than MFMAs per K slice");
     // two fragment register sets: the second 32-wide step's fragments are read under the first step's MFMAs
     constexpr int FSETS = 2;
+    // One fragment of the second 32-wide step, by its rank in the order the step's MFMAs need them: A0/0, B0/0, B0/1, A0/1, the other B
+    // tiles, the other A tiles. With C64_FRAG_SPREAD these reads go out one at a time between the first step's MFMAs instead of
+    // all 2 (TM + TN) of them in front of the slice's first MFMA, where all eight waves of the workgroup, released by the same
+    // barrier, queue 192 KB of LDS reads at once.
+    constexpr int NFRAG = 2 * (TM + TN);
+    constexpr int FSTEP = (NMFMA / 2) / NFRAG > 0 ? (NMFMA / 2) / NFRAG : 1;
+#define C64_LOAD_FRAG_RANK(set, k32_, rank_)                                                                                        \
+    {                                                                                                                               \
+        constexpr int rk_ = (rank_);                                                                                                \
+        constexpr bool isa_ = rk_ == 0 || rk_ == 3 || rk_ >= 4 + 2 * (TN - 1);                                                      \
+        constexpr int t_ = rk_ < 4 ? 0 : (isa_ ? 1 + (rk_ - 4 - 2 * (TN - 1)) / 2 : 1 + (rk_ - 4) / 2);                             \
+        constexpr int hf_ = rk_ == 0 || rk_ == 1 ? 0 : (rk_ == 2 || rk_ == 3 ? 1 : (isa_ ? (rk_ - 4 - 2 * (TN - 1)) % 2 : (rk_ - 4) % 2)); \
+        const int rr_ = hf_ * 16 + (lane & 15);                                                                                     \
+        const int sl_ = (((k32_) * 4 + (lane >> 4)) ^ ((rr_ >> 1) & 7)) * 16;                                                       \
+        if constexpr (isa_) fa[set][t_ < TM ? t_ : 0][hf_] = *reinterpret_cast<const frag_t*>(sa + ((wr * TM + t_) * 32 + rr_) * 128 + sl_); \
+        else fb[set][t_ < TN ? t_ : 0][hf_] = *reinterpret_cast<const frag_t*>(sb + ((wc * TN + t_) * 32 + rr_) * 128 + sl_);        \
+    }
+#ifndef C64_FRAG_SPREAD
+#define C64_FRAG_SPREAD 0
+#endif
+    constexpr bool SPREAD = C64_FRAG_SPREAD && BM * BN >= 256 * 256;  // (the 128-wide kernels pay for it with their third wave per SIMD: 166 -> 186 registers)
 #define C64_KSLICE(ISSUE, nstage)                                                                                                   \
     {                                                                                                                               \
         frag_t fa[FSETS][TM][2], fb[FSETS][TN][2];                                                                                  \
         C64_LOAD_FRAGS(0, 0);                                                                                                       \
         _Pragma("unroll") for (int k32 = 0; k32 < 2; ++k32) {                                                                       \
-            if (k32 < 1) C64_LOAD_FRAGS(1, 1);                                                                                      \
+            if (k32 < 1 && !SPREAD) C64_LOAD_FRAGS(1, 1);                                                                  \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                          \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                      \
                     _Pragma("unroll") for (int si = 0; si < 2; ++si)                                                                \
                         _Pragma("unroll") for (int sj = 0; sj < 2; ++sj) {                                                          \
                             acc[i][j][si][sj] = Frag64<TI>::mfma16(fa[k32 % FSETS][i][si], fb[k32 % FSETS][j][sj], acc[i][j][si][sj]); \
+                            const int done_ = (((k32 * TM + i) * TN + j) * 2 + si) * 2 + sj + 1;                                    \
+                            if (SPREAD && k32 == 0 && done_ % FSTEP == 0 && done_ / FSTEP <= NFRAG) {                      \
+                                C64_SPREAD_ONE(done_ / FSTEP - 1);                                                                  \
+                                __builtin_amdgcn_sched_barrier(0);                                                                  \
+                            }                                                                                                       \
                             if (ISSUE) {                                                                                            \
-                                const int done_ = (((k32 * TM + i) * TN + j) * 2 + si) * 2 + sj + 1;                                \
                                 if (done_ % PSTEP == 0 && done_ / PSTEP <= NPIECE) {                                                \
                                     C64_ISSUE_PIECE(nstage, done_ / PSTEP - 1);                                                     \
                                     __builtin_amdgcn_sched_barrier(0);                                                              \
                                 }                                                                                                   \
                             }                                                                                                       \
                         }                                                                                                           \
+        }                                                                                                                           \
+    }
+    // (the rank is a loop-derived value, constant after unrolling: dispatch it to the constexpr form)
+#define C64_SPREAD_ONE(r_)                                                                                                          \
+    {                                                                                                                               \
+        switch (r_) {                                                                                                               \
+            case 0: C64_LOAD_FRAG_RANK(1, 1, 0); break; case 1: C64_LOAD_FRAG_RANK(1, 1, 1); break;                                 \
+            case 2: C64_LOAD_FRAG_RANK(1, 1, 2); break; case 3: C64_LOAD_FRAG_RANK(1, 1, 3); break;                                 \
+            case 4: C64_LOAD_FRAG_RANK(1, 1, 4); break; case 5: C64_LOAD_FRAG_RANK(1, 1, 5); break;                                 \
+            case 6: C64_LOAD_FRAG_RANK(1, 1, 6); break; case 7: C64_LOAD_FRAG_RANK(1, 1, 7); break;                                 \
+            case 8: C64_LOAD_FRAG_RANK(1, 1, 8 < NFRAG ? 8 : 0); break; case 9: C64_LOAD_FRAG_RANK(1, 1, 9 < NFRAG ? 9 : 0); break; \
+            case 10: C64_LOAD_FRAG_RANK(1, 1, 10 < NFRAG ? 10 : 0); break; case 11: C64_LOAD_FRAG_RANK(1, 1, 11 < NFRAG ? 11 : 0); break; \
+            case 12: C64_LOAD_FRAG_RANK(1, 1, 12 < NFRAG ? 12 : 0); break; case 13: C64_LOAD_FRAG_RANK(1, 1, 13 < NFRAG ? 13 : 0); break; \
+            case 14: C64_LOAD_FRAG_RANK(1, 1, 14 < NFRAG ? 14 : 0); break; case 15: C64_LOAD_FRAG_RANK(1, 1, 15 < NFRAG ? 15 : 0); break; \
+            default: break;                                                                                                         \
         }                                                                                                                           \
     }
 #define C64_FIRST_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
@@ -390,6 +430,8 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
         }
     }
 #undef C64_KSLICE
+#undef C64_SPREAD_ONE
+#undef C64_LOAD_FRAG_RANK
 #undef C64_LOAD_FRAGS
     __syncthreads();  // all waves done with the staging buffers before the epilogue reuses them
     C64_STAMP(2);
