@@ -13,8 +13,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
                   the summed duration of its launches, measured with HIP events on the launch stream.
   roofline_hbm -- the HBM group of SURVEY.md 8d (RoIAlign + proposal selection + NMS): algorithmic bytes per step over
                   the summed HIP-event duration, fraction of the 8 TB/s HBM peak; per kernel, and NMS as time + IoU pairs/s.
-  train_step   -- BASELINE.json config 3 (train step with the PLN contrastive loss, batch 16, one GPU), measured in the
+  train_step   -- BASELINE.json config 3 (train step with the PLN contrastive loss, batch 16 per GPU), measured in the
                   same process after the headline: ms per iteration, images/s, forward / data-gradient / weight-gradient TFLOP/s.
+                  With N > 1 every rank trains on its own images and the gradient buckets are all-reduced over RCCL from inside
+                  the backward (configs 4 / 5's pattern); a watchdog prints the headline line should that path not finish.
   cpu_baseline -- the CPU oracle ("port") timed on this box's host cores on a bounded sample of the same workload
                   (3 warm-ups + median of 5 at all cores; a 1-thread point on a smaller sample).
 """
@@ -139,8 +141,10 @@ def synthetic_gt(n: int, h: int, w: int, per_image: int = 8, seed: int = 0):
     return boxes, classes, torch.full((n,), per_image, dtype=torch.int32)
 
 
-def train_step_leg(params, tdt, device, images, image_hw, steps: int, warmup: int):
-    """BASELINE.json config 3: forward + explicit backward + SGD on one GPU (no all-reduce at N = 1), batch 16 at 800x1333."""
+def train_step_leg(params, tdt, device, images, image_hw, steps: int, warmup: int, dist=None, rank: int = 0, world: int = 1):
+    """BASELINE.json config 3: forward + explicit backward + SGD, batch 16 per GPU at 800x1333. With several ranks (configs 4 / 5's
+    pattern) every rank trains on its own images and the flat gradient buffer is all-reduced over RCCL in >= 25 MB buckets issued
+    from inside the backward (parallel.GradBuckets); the time is the maximum over the ranks, bracketed by barriers."""
     from openset_rcnn_amd.host import ops
     from openset_rcnn_amd.host.train import OpensetRCNNTrainer
     n = images.shape[0]
@@ -149,17 +153,27 @@ def train_step_leg(params, tdt, device, images, image_hw, steps: int, warmup: in
     shapes = [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
     r = sum(a * b for a, b in shapes)
     cap = sum(min(2000, a * b) for a, b in shapes)
-    g = torch.Generator().manual_seed(0)
+    g = torch.Generator().manual_seed(rank)
     keys = {k: torch.rand(s, generator=g).to(device) for k, s in (("rpn_reg", (n, r)), ("rpn_obj", (n, r)), ("roi", (n, cap + gt.shape[1])))}
     args = (images, image_hw, 800, 1344, gt.to(device), gcls.to(device), gcnt.to(device), keys)
     for _ in range(warmup):
         losses = tr.step(*args)
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         losses = tr.step(*args)
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
     # one instrumented iteration: algorithmic FLOPs of the MFMA launches per phase, HIP events around the phases
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     ops.FLOP_COUNT = dict(conv=0.0, wgrad=0.0)
@@ -176,14 +190,17 @@ def train_step_leg(params, tdt, device, images, image_hw, steps: int, warmup: in
     torch.cuda.synchronize()
     ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
     total = float(sum(float(v) for v in losses.values()))
-    return dict(config="VOC-COCO openset_rcnn_R50_FPN_128k.yaml, train step with PLN contrastive loss, batch 16, 1xMI355X (BASELINE.json config 3)",
-                ms_per_iter=round(dt * 1e3, 3), images_per_sec=round(n / dt, 2), steps=steps, warmup=warmup,
+    where = "1xMI355X (BASELINE.json config 3)" if world == 1 else \
+        f"{world}xMI355X, one process per GPU, bucketed gradient all-reduce over RCCL overlapped with the backward (BASELINE.json configs 4 / 5's pattern)"
+    return dict(config=f"VOC-COCO openset_rcnn_R50_FPN_128k.yaml, train step with PLN contrastive loss, batch 16 per GPU, {where}",
+                ms_per_iter=round(dt * 1e3, 3), images_per_sec=round(n * world / dt, 2), n_gpus=world, steps=steps, warmup=warmup,
                 forward_ms=round(ms[0], 3), backward_ms=round(ms[1], 3), update_ms=round(ms[2], 3),
+                update_ms_note="all-reduce of the whole flat gradient buffer (not overlapped in this instrumented iteration) + SGD" if world > 1 else "SGD",
                 forward_TFLOP=round(fwd["conv"] / 1e12, 3), dgrad_TFLOP=round(bwd["conv"] / 1e12, 3), wgrad_TFLOP=round(bwd["wgrad"] / 1e12, 3),
                 forward_TFLOPs=round(fwd["conv"] / ms[0] / 1e9, 1), backward_TFLOPs=round((bwd["conv"] + bwd["wgrad"]) / ms[1] / 1e9, 1),
-                whole_iteration_TFLOPs=round((fwd["conv"] + bwd["conv"] + bwd["wgrad"]) / dt / 1e12, 1),
-                trainable_params=tr.num_params, gt_boxes_per_image=8, proposals_per_image_train=cap, rois_sampled_per_image=512,
-                loss_total_last=round(total, 4), overflow_skipped_steps=tr.overflow_steps)
+                whole_iteration_TFLOPs=round((fwd["conv"] + bwd["conv"] + bwd["wgrad"]) * world / dt / 1e12, 1),
+                trainable_params=tr.num_params, gradient_bytes_all_reduced=tr.num_params * 4 if world > 1 else 0, gt_boxes_per_image=8,
+                proposals_per_image_train=cap, rois_sampled_per_image=512, loss_total_last=round(total, 4), overflow_skipped_steps=tr.overflow_steps)
 
 
 def main():
@@ -376,12 +393,38 @@ def main():
                        "micro_batch_streams": args.streams, "hipgraph": bool(args.graph)},
             "roofline": roofline, "roofline_hbm": roofline_hbm,
         }
-        if world == 1 and not args.no_train_step:
-            del eng
-            if args.graph:
-                del graph, gout
-            torch.cuda.empty_cache()
-            line["train_step"] = train_step_leg(params, tdt, dev, images, image_hw, args.train_steps, 2)
+    else:
+        line = None
+    # ---- train step leg: every rank takes part (the gradient all-reduce is a collective). With several ranks a watchdog makes
+    # sure the headline line is printed even if that collective path hangs on the node (it has only been rehearsed over gloo).
+    if not args.no_train_step:
+        del eng
+        if args.graph:
+            del graph, gout
+        torch.cuda.empty_cache()
+        guard = None
+        if world > 1:
+            import threading
+
+            def give_up():
+                if rank == 0:
+                    line["train_step"] = {"error": "the multi-rank train step did not finish within 300 s; headline unaffected"}
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+            guard = threading.Timer(300.0, give_up)
+            guard.daemon = True
+            guard.start()
+        try:
+            ts = train_step_leg(params, tdt, dev, images, image_hw, args.train_steps, 2, dist, rank, world)
+        except Exception as e:  # noqa: BLE001  (reported in the line, the headline stands)
+            if world == 1:
+                raise
+            ts = {"error": repr(e)[:400]}
+        if guard is not None:
+            guard.cancel()
+        if rank == 0:
+            line["train_step"] = ts
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(params, args.cpu_batch, one_thread=True)
         print(json.dumps(line), flush=True)
