@@ -5,6 +5,10 @@ batch 16 per GPU, synthetic 3x800x1333 uint8 BGR images, random-init weights) on
 One "step" = one full pass of the hot path over one batch per GPU: preprocess -> R50+FPN -> CF-RPN head ->
 proposal selection -> RoIAlign -> box head -> predictor -> PLN -> softmax classifier -> NMS, inputs already
 resident in HBM. Images shard across ranks with no data-path collective (weak scaling).
+The K timed steps are K such passes, each captured as one hipGraph; consecutive passes alternate over --passes-in-flight lanes
+(default 4: every lane has its own batch of images, its own activation / output buffers and its own HIP stream), so pass i + 1
+starts while pass i is still in its RoI heads -- a serving loop with four batches in flight. All K passes have completed when the
+closing synchronize returns; ms_per_step = elapsed / K (the latency of one pass alone is what --passes-in-flight 1 reports).
 
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank/GPU)
 
@@ -215,7 +219,11 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not measure HBM traffic with rocprofv3 child passes (quote the committed profile)")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--train-steps", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=2, help="micro-batch streams inside one GPU (1 = single stream)")
+    ap.add_argument("--streams", type=int, default=1, help="micro-batch streams inside one pass (1 = the pass is one stream of launches)")
+    ap.add_argument("--passes-in-flight", type=int, default=4,
+                    help="hipGraph mode: consecutive passes (steps) alternate over this many lanes, each with its own images, buffers and stream; "
+                         "1 = one pass at a time")
+    ap.add_argument("--lane-hint", type=int, default=1, help="1: pass the number of lanes to the conv tile model as its concurrency hint")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage breakdown to stderr")
     ap.add_argument("--layers", action="store_true", help="also print every MFMA launch (time, TFLOP/s, GB/s) to stderr")
@@ -275,11 +283,31 @@ def main():
         return eng.forward_device(images, image_hw, 800, 1344)
 
     if args.graph:
-        graph, gout = eng.capture(images, image_hw, 800, 1344, args.streams)
+        from openset_rcnn_amd.host import ops as _ops
+        npass = max(1, args.passes_in_flight)
+        # (the tile model's concurrency hint: how many launch streams share the GPU -- lanes x micro-batch streams)
+        with _ops.concurrent_streams(npass if args.lane_hint else 1):
+            graph, gout = eng.capture(images, image_hw, 800, 1344, args.streams)
+            lanes = [(graph, gout, torch.cuda.Stream(device=dev))]
+            lane_images = [images]
+            for li in range(1, npass):  # every lane has its own batch of images (and, through its capture, its own activations and outputs)
+                gi = torch.Generator().manual_seed(1234 + rank + 1000 * li)
+                lane_images.append(torch.randint(0, 256, (args.batch, 3, 800, 1333), generator=gi, dtype=torch.uint8).to(dev))
+                g2, o2 = eng.capture(lane_images[li], image_hw, 800, 1344, args.streams)
+                lanes.append((g2, o2, torch.cuda.Stream(device=dev)))
+        turn = [0]
 
         def step():  # noqa: F811  one hipGraph launch replays the whole pass
-            graph.replay()
-            return gout
+            if len(lanes) == 1:
+                graph.replay()
+                return gout
+            # several passes in flight: pass i is launched on lane i % P without waiting for pass i - 1 (its own buffers, its own
+            # stream); a lane's next pass queues behind its previous one. The timed region ends with a device-wide synchronize.
+            g_, o_, st_ = lanes[turn[0] % len(lanes)]
+            turn[0] += 1
+            with torch.cuda.stream(st_):
+                g_.replay()
+            return o_
 
     for _ in range(args.warmup):
         out = step()
@@ -390,7 +418,8 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world} (images sharded, no collective)",
                        "weights": "random-init (seed 0), FrozenBN folded; PLN encoder bias calibrated for a known/unknown mix at UNK_THR 0.23",
                        "detections_last_step": n_det, "unknown_detections_last_step": n_unknown, "known_detections_last_step": n_det - n_unknown,
-                       "micro_batch_streams": args.streams, "hipgraph": bool(args.graph)},
+                       "micro_batch_streams": args.streams, "hipgraph": bool(args.graph),
+                       "passes_in_flight": args.passes_in_flight if args.graph else 1},
             "roofline": roofline, "roofline_hbm": roofline_hbm,
         }
     else:
