@@ -84,6 +84,10 @@ typedef struct osr_conv_params {
     int64_t workspace_bytes; /* osr_conv2d_fwd_workspace_bytes(p) bytes the partial last dispatch round of a deep-K 1x1 / FC
                               * layer is cut along K (fixed-order fp32 partial sums: bitwise reproducible, but not bitwise
                               * equal to the un-split sum) */
+    const int32_t* row_seg_counts; /* optional (may be null), device memory: the output rows (n*ho*wo of them) come in segments */
+    int32_t row_seg_rows;          /* of row_seg_rows rows of which only the first row_seg_counts[s] carry data (a padded per-image
+                                    * proposal list: the box head's FC layers). A tile of output rows without any such row is
+                                    * skipped and its rows are left unwritten; all other rows are computed as usual. */
 } osr_conv_params;
 
 /* Workspace with which osr_conv2d_fwd splits the tail round of this layer along K; 0 when the layer does not qualify (then a

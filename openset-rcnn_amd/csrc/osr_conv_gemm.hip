@@ -285,6 +285,7 @@ static osr_status conv2d_fwd_impl(const osr_conv_params* p, const void* in, cons
         OSR_REQUIRE(p->res_mode == 0 || p->res_mode == 1, OSR_ERR_INVALID_ARG, "osr_conv2d_fwd_masked: res_mode must be 0 or 1");
     }
     OSR_REQUIRE(p->n >= 1 && p->hi >= 1 && p->wi >= 1 && p->ho >= 1 && p->wo >= 1, OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: bad spatial sizes");
+    OSR_REQUIRE(!p->row_seg_counts || p->row_seg_rows >= 1, OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: row_seg_rows must be positive with row_seg_counts");
     const bool f32_mode = p->in_dtype == OSR_F32;  // parity mode: fp32 storage and products (osr_conv_f32.hip)
     OSR_REQUIRE(f32_mode || (p->cin >= 32 && p->cin % 32 == 0), OSR_ERR_UNSUPPORTED, "osr_conv2d_fwd: cin must be a multiple of 32, got %d", p->cin);
     OSR_REQUIRE(f32_mode || (p->cout >= 8 && p->cout % 8 == 0), OSR_ERR_UNSUPPORTED, "osr_conv2d_fwd: cout must be a multiple of 8, got %d", p->cout);

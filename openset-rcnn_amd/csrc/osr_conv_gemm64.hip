@@ -163,6 +163,15 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
     const int tile_n = t % a.tiles_n, tile_m = t / a.tiles_n;
     const long long m0 = (long long)tile_m * BM;
     const int n0 = tile_n * BN;
+    if (p.row_seg_counts) {  // segmented rows (padded per-image lists): a tile without a single data row has nothing to do (wave-uniform)
+        const long long sr = p.row_seg_rows, mend = m0 + BM < a.M ? m0 + BM : a.M;
+        bool any = false;
+        for (long long sg = m0 / sr; sg * sr < mend; ++sg) {
+            const long long lo = m0 > sg * sr ? m0 : sg * sr, hi = sg * sr + p.row_seg_counts[sg];
+            any |= (hi < mend ? hi : mend) > lo;
+        }
+        if (!any) return;
+    }
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);

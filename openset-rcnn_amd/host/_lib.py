@@ -34,6 +34,7 @@ class ConvParams(C.Structure):
         ("relu", C.c_int32), ("res_mode", C.c_int32), ("pad_mode", C.c_int32),
         ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("concurrency", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("row_seg_counts", C.c_void_p), ("row_seg_rows", C.c_int32),
     ]
 
 

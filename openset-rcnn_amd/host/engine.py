@@ -97,6 +97,9 @@ class OpensetRCNNEngine:
         self._streams = []
         self.profile = None  # set to a list to collect (name, algorithmic flops, start event, end event) per MFMA launch
         self.profile_hbm = None  # set to a list to collect (name, algorithmic bytes, start event, end event, info) of the HBM-group kernels
+        # the box head's FC layers skip the tiles that hold only padding rows of the per-image proposal lists (fp16 / bf16 kernels;
+        # the fp32 parity kernel computes every row)
+        self.skip_padding_tiles = dtype != torch.float32
         self._init_rpn(params)
         self._init_roi_heads(params)
 
@@ -163,12 +166,12 @@ class OpensetRCNNEngine:
         self.profile.append((name, 2.0 * rows * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3], e0, e1, nbytes))
         return y
 
-    def _linear(self, x, w, b, relu, out_dtype=None, name="fc"):
+    def _linear(self, x, w, b, relu, out_dtype=None, name="fc", row_seg=None):
         if self.profile is None:
-            return ops.linear(x, w, b, relu=relu, out_dtype=out_dtype)
+            return ops.linear(x, w, b, relu=relu, out_dtype=out_dtype, row_seg=row_seg)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        y = ops.linear(x, w, b, relu=relu, out_dtype=out_dtype)
+        y = ops.linear(x, w, b, relu=relu, out_dtype=out_dtype, row_seg=row_seg)
         e1.record()
         nbytes = x.numel() * x.element_size() + w.numel() * w.element_size() + y.numel() * y.element_size()
         self.profile.append((name, 2.0 * x.shape[0] * w.shape[0] * w.shape[1], e0, e1, nbytes))
@@ -283,8 +286,11 @@ class OpensetRCNNEngine:
                                                                c["canonical_level"], c["canonical_size"], 2),
                            lambda: sum(f.numel() for f in fl) * es + boxes.shape[0] * (c["pooler_resolution"] ** 2 * 256 * es + 20))
         m = pooled.shape[0]
-        h1 = self._linear(pooled.view(m, -1), self.fc1_w, self.fc1_b, True, name="roi_heads.box_head.fc1")
-        box_feats = self._linear(h1, self.fc2_w, self.fc2_b, True, torch.float32, name="roi_heads.box_head.fc2")
+        # each image's list is [its proposals ..., padding]: the FC tiles that hold only padding rows are skipped (their rows of h1 /
+        # box_feats stay unwritten; nothing downstream reads past an image's count)
+        seg = (sel["counts"], cap) if self.skip_padding_tiles else None
+        h1 = self._linear(pooled.view(m, -1), self.fc1_w, self.fc1_b, True, name="roi_heads.box_head.fc1", row_seg=seg)
+        box_feats = self._linear(h1, self.fc2_w, self.fc2_b, True, torch.float32, name="roi_heads.box_head.fc2", row_seg=seg)
         pt = ops.box_predictor_tail(box_feats, self.pred_w, self.pred_b, boxes, sel["scores"].view(-1), sel["batch_idx"], image_hw,
                                     c["bbox_reg_weights"], 0 if c["mean_type"] == "geometric" else 1, c["obj_score_thresh"])
         topk1 = c["detections_per_image"]

@@ -90,10 +90,13 @@ def _new_conv_params() -> "ConvParams":
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, stride: int = 1, pad: int = 0, relu: bool = False,
            residual: Optional[torch.Tensor] = None, res_mode: int = 0, out_dtype: Optional[torch.dtype] = None,
-           out: Optional[torch.Tensor] = None, post_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, post_mask: Optional[torch.Tensor] = None,
+           row_seg: Optional[Tuple[torch.Tensor, int]] = None) -> torch.Tensor:
     """NHWC implicit-GEMM convolution. x (n,h,w,cin) f16/bf16; weight (cout,kh,kw,cin) same dtype; bias f32.
     post_mask (n,ho,wo,cout), x's dtype: the result is zeroed where post_mask <= 0, in the same launch
-    (osr_conv2d_fwd_masked; needs cin % 64 == 0, else the mask is applied by a second launch)."""
+    (osr_conv2d_fwd_masked; needs cin % 64 == 0, else the mask is applied by a second launch).
+    row_seg = (counts int32 (s,), rows per segment): the output rows are s segments of which only the first counts[i] rows carry
+    data (padded per-image lists); tiles without a data row are skipped and their rows left unwritten."""
     lib = _lib.load()
     _need(x, name="x"); _need(weight, x.dtype, "weight"); _need(bias, torch.float32, "bias")
     n, hi, wi, cin = x.shape
@@ -117,6 +120,12 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, stride: in
     p.out_stride_n, p.out_stride_h, p.out_stride_w = ho * wo * cout, wo * cout, cout
     p.relu, p.res_mode, p.pad_mode = int(relu), int(res_mode), 0
     p.in_dtype, p.out_dtype = _DT[x.dtype], _DT[out_dtype]
+    if row_seg is not None:
+        counts, seg_rows = row_seg
+        _need(counts, torch.int32, "row_seg counts")
+        if seg_rows < 1 or counts.numel() * seg_rows < n * ho * wo:
+            raise OsrError("row_seg does not cover the output rows")
+        p.row_seg_counts, p.row_seg_rows = counts.data_ptr(), int(seg_rows)
     if res_mode:
         _need(residual, x.dtype, "residual")
         rn, rh, rw, rc = residual.shape
@@ -173,10 +182,10 @@ def stem_conv(xpad: torch.Tensor, w_view: torch.Tensor, bias: torch.Tensor, hp: 
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, relu: bool = False,
-           out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-    """Fully connected layer on the MFMA path: x (m,k) f16/bf16, weight (n,k)."""
+           out_dtype: Optional[torch.dtype] = None, row_seg: Optional[Tuple[torch.Tensor, int]] = None) -> torch.Tensor:
+    """Fully connected layer on the MFMA path: x (m,k) f16/bf16, weight (n,k). row_seg: see conv2d."""
     m, k = x.shape
-    y = conv2d(x.view(1, m, 1, k), weight.view(weight.shape[0], 1, 1, k), bias, relu=relu, out_dtype=out_dtype)
+    y = conv2d(x.view(1, m, 1, k), weight.view(weight.shape[0], 1, 1, k), bias, relu=relu, out_dtype=out_dtype, row_seg=row_seg)
     return y.view(m, weight.shape[0])
 
 

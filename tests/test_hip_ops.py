@@ -705,3 +705,32 @@ def test_roi_locality_order_is_a_permutation_and_changes_nothing(ops):
     d = ops.roi_align(feats, scales, boxes, bi, 7, torch.float16)
     assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
     assert float(a[(bi < 0)].abs().sum()) == 0.0
+
+
+def test_linear_skips_tiles_of_padding_rows(ops):
+    """osr_conv_params.row_seg_counts / row_seg_rows (the box head's FC layers over padded per-image proposal lists;
+    osrcnn_roi_heads.py:304-309 runs them on the real proposals only): every data row equals the plain launch bit for bit, tiles
+    that hold padding rows only are left untouched, for the big-tile FC1 shape (with its split-K tail) and the 128-row FC2 shape."""
+    gg = g(31)
+    for (seg_rows, nseg, k, nout, dt_out) in ((4273, 16, 1024, 1024, torch.float32), (1500, 3, 12544, 1024, torch.float16), (700, 5, 256, 64, torch.float16)):
+        m = seg_rows * nseg
+        x = torch.randn(m, k, generator=gg).half().to(DEV)
+        w = (torch.randn(nout, k, generator=gg) / k ** 0.5).half().to(DEV)
+        b = torch.randn(nout, generator=gg).to(DEV)
+        counts = torch.randint(0, seg_rows + 1, (nseg,), generator=gg, dtype=torch.int32)
+        counts[0] = seg_rows
+        if nseg > 2:
+            counts[1] = 0
+            counts[2] = 1
+        want = ops.linear(x, w, b, relu=True, out_dtype=dt_out)
+        sentinel = -7.0
+        out = torch.full((1, m, 1, nout), sentinel, dtype=dt_out, device=DEV)
+        got = ops.conv2d(x.view(1, m, 1, k), w.view(nout, 1, 1, k), b, relu=True, out_dtype=dt_out, out=out, row_seg=(counts.to(DEV), seg_rows)).view(m, nout)
+        row = torch.arange(m)
+        valid = (row % seg_rows) < counts[row // seg_rows].long()
+        assert torch.equal(got[valid.to(DEV)], want[valid.to(DEV)])
+        untouched = (got == sentinel).all(dim=1).cpu()
+        assert not bool((untouched & valid).any())
+        assert bool(untouched.any()), "some tile must have been skipped"
+        wrote_pad = (~untouched) & (~valid)  # whatever was written outside the data rows is the ordinary result of those rows
+        assert torch.equal(got[wrote_pad.to(DEV)], want[wrote_pad.to(DEV)])
