@@ -17,8 +17,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
                   the summed duration of its launches, measured with HIP events on the launch stream.
   roofline_hbm -- the HBM group of SURVEY.md 8d (RoIAlign + proposal selection + NMS): algorithmic bytes per step over
                   the summed HIP-event duration, fraction of the 8 TB/s HBM peak; per kernel, and NMS as time + IoU pairs/s.
-  train_step   -- BASELINE.json config 3 (train step with the PLN contrastive loss, batch 16 per GPU), measured in the
-                  same process after the headline: ms per iteration, images/s, forward / data-gradient / weight-gradient TFLOP/s.
+  train_step   -- BASELINE.json config 3 (train step with the PLN contrastive loss, batch 16 per GPU), measured after the
+                  headline (one GPU: in a child process of this command, see train_step_child; several GPUs: in this process, all
+                  ranks): ms per iteration, images/s, forward / data-gradient / weight-gradient TFLOP/s.
                   With N > 1 every rank trains on its own images and the gradient buckets are all-reduced over RCCL from inside
                   the backward (configs 4 / 5's pattern); a watchdog prints the headline line should that path not finish.
   cpu_baseline -- the CPU oracle ("port") timed on this box's host cores on a bounded sample of the same workload
@@ -30,6 +31,7 @@ import argparse
 import json
 import os
 import statistics
+import subprocess
 import sys
 import time
 
@@ -207,6 +209,23 @@ def train_step_leg(params, tdt, device, images, image_hw, steps: int, warmup: in
                 proposals_per_image_train=cap, rois_sampled_per_image=512, loss_total_last=round(total, 4), overflow_skipped_steps=tr.overflow_steps)
 
 
+def train_step_child(args) -> dict:
+    """The single-GPU train-step leg runs in a child process after the inference measurement. In one process the two disturb each
+    other: the leg is an eager stream of ~500 launches per iteration and ran 8 % slower after the four-lane inference loop (38.0
+    against 35.1 ms; likewise with GPU_MAX_HW_QUEUES raised: every hardware queue a process has used stays in the command
+    processor's rotation), and run first it cost the inference loop 2.5 %. The child rebuilds the same weights (same seeds)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--train-only", "--train-steps", str(args.train_steps), "--dtype", args.dtype, "--batch", str(args.batch),
+           "--no-cpu-baseline", "--no-pmc"]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=os.path.dirname(os.path.abspath(__file__)))
+        last = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not last:
+            return {"error": f"train-step child exited {r.returncode}: {r.stderr.decode()[-300:]}"}
+        return json.loads(last[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,6 +238,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not measure HBM traffic with rocprofv3 child passes (quote the committed profile)")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--train-steps", type=int, default=5)
+    ap.add_argument("--train-only", action="store_true", help="(internal) run only the train-step leg and print its object")
     ap.add_argument("--streams", type=int, default=1, help="micro-batch streams inside one pass (1 = the pass is one stream of launches)")
     ap.add_argument("--passes-in-flight", type=int, default=4,
                     help="hipGraph mode: consecutive passes (steps) alternate over this many lanes, each with its own images, buffers and stream; "
@@ -275,6 +295,9 @@ def main():
     del cal_images
     params = with_known_unknown_mix(params, emb)
     del cal, keep
+    if args.train_only:  # child of the single-GPU run (see train_step_child): the train-step leg in a process of its own
+        print(json.dumps(train_step_leg(params, tdt, dev, images, image_hw, args.train_steps, 2)), flush=True)
+        return
     eng = OpensetRCNNEngine(params, dtype=tdt, device=dev)
 
     def step():
@@ -426,10 +449,16 @@ def main():
         line = None
     # ---- train step leg: every rank takes part (the gradient all-reduce is a collective). With several ranks a watchdog makes
     # sure the headline line is printed even if that collective path hangs on the node (it has only been rehearsed over gloo).
-    if not args.no_train_step:
+    if world == 1 and not args.no_train_step:
         del eng
         if args.graph:
-            del graph, gout
+            del graph, gout, lanes, lane_images, out
+        torch.cuda.empty_cache()
+        line["train_step"] = train_step_child(args)
+    elif not args.no_train_step:
+        del eng
+        if args.graph:
+            del graph, gout, lanes, lane_images, out
         torch.cuda.empty_cache()
         guard = None
         if world > 1:

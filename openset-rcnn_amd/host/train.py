@@ -105,6 +105,8 @@ class OpensetRCNNTrainer:
         self.grads_ready = False
         self._side: Optional[torch.cuda.Stream] = None  # stream of the ground-truth-only part of the forward (anchor targets)
         self.overlap_targets = True
+        self._wside: Optional[torch.cuda.Stream] = None  # stream of the weight / bias gradient launches (see _wg)
+        self.side_wgrad = True
         self._refresh_derived()
 
     def _add_conv(self, name: str, params, bias: bool):
@@ -220,10 +222,35 @@ class OpensetRCNNTrainer:
 
     def _done(self, *names: str) -> None:
         """The gradients of these parameters are final (their last launch is enqueued): a bucket they complete starts its
-        all-reduce now, under the rest of the backward."""
+        all-reduce now, under the rest of the backward. With the weight gradients on their own stream the collective is issued from
+        that stream after it has been made to wait for the main one, so it is ordered behind everything enqueued so far on both."""
         if self._overlap:
-            for k in names:
-                self.buckets.mark_done(k)
+            if self.side_wgrad and self._wside is not None:
+                self._wside.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(self._wside):
+                    for k in names:
+                        self.buckets.mark_done(k)
+            else:
+                for k in names:
+                    self.buckets.mark_done(k)
+
+    def _wg(self, fn, *reads: torch.Tensor) -> None:
+        """Run a weight / bias gradient launch group off the critical path: the chain of data gradients (dy of a layer -> dy of the
+        layer below) stays on the main stream, the launches that only consume a layer's dy and its saved input (wgrad, its split
+        reduction, the bias gradient) go to a second stream, where they fill the sparse last rounds of the data-gradient kernels
+        and vice versa. `reads`: the tensors of the main stream the launches read (kept alive for the second stream)."""
+        if not self.side_wgrad:
+            fn()
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if self._wside is None:
+            self._wside = torch.cuda.Stream(device=self.device)
+        self._wside.wait_stream(cur)
+        with torch.cuda.stream(self._wside):
+            fn()
+        if not torch.cuda.is_current_stream_capturing():
+            for t in reads:
+                t.record_stream(self._wside)
 
     def _backward(self, s, n, grad_scale: float = 1.0, overlap: bool = True):
         """Gradients of grad_scale * (sum of the six losses), times the loss scale, into self.grad. overlap: start each gradient
@@ -253,13 +280,13 @@ class OpensetRCNNTrainer:
         m = dy2.shape[0]
         # --- box head: FC2, FC1 on the MFMA kernels ---
         d_h1 = ops.conv2d_dgrad(dy2.view(1, m, 1, -1), self.wd["fc2"], (m, 1), mask=s["h1"].view(1, m, 1, -1)).view(m, -1)
-        ops.conv2d_wgrad(s["h1"].view(1, m, 1, -1), dy2.view(1, m, 1, -1), 1, 1, dw=g["fc2.w"].view(-1, 1, 1, g["fc2.w"].shape[1]))
-        ops.bias_grad(dy2, g["fc2.b"])
+        self._wg(lambda: (ops.conv2d_wgrad(s["h1"].view(1, m, 1, -1), dy2.view(1, m, 1, -1), 1, 1, dw=g["fc2.w"].view(-1, 1, 1, g["fc2.w"].shape[1])),
+                          ops.bias_grad(dy2, g["fc2.b"])), dy2)
         self._done("fc2.w", "fc2.b")
         pooled2 = s["pooled"].view(1, m, 1, -1)
         d_pooled = ops.conv2d_dgrad(d_h1.view(1, m, 1, -1), self.wd["fc1"], (m, 1))
-        ops.conv2d_wgrad(pooled2, d_h1.view(1, m, 1, -1), 1, 1, dw=g["fc1.w"].view(-1, 1, 1, g["fc1.w"].shape[1]))
-        ops.bias_grad(d_h1, g["fc1.b"])
+        self._wg(lambda: (ops.conv2d_wgrad(pooled2, d_h1.view(1, m, 1, -1), 1, 1, dw=g["fc1.w"].view(-1, 1, 1, g["fc1.w"].shape[1])),
+                          ops.bias_grad(d_h1, g["fc1.b"])), d_h1)
         self._done("fc1.w", "fc1.b")
         P = c["pooler_resolution"]
         p = s["p"]
@@ -284,8 +311,8 @@ class OpensetRCNNTrainer:
             off += rows
             roi_part = ops.add_cast(d_feat[li], None, dt) if li < 4 else None
             dP[k] = ops.conv2d_dgrad(dtl, self.wd[rn], (h, w), 1, 1, add=roi_part)
-            ops.conv2d_wgrad(p[k], dtl, 3, 3, 1, 1, dw=g[rn + ".w"], accumulate=li > 0)
-            ops.bias_grad(dtl, g[rn + ".b"], accumulate=li > 0)
+            self._wg(lambda k=k, dtl=dtl, li=li: (ops.conv2d_wgrad(p[k], dtl, 3, 3, 1, 1, dw=g[rn + ".w"], accumulate=li > 0),
+                                                  ops.bias_grad(dtl, g[rn + ".b"], accumulate=li > 0)), dt_all)
         self._done(rn + ".w", rn + ".b")
         h5, w5 = p["p5"].shape[1], p["p5"].shape[2]
         dP["p5"] = ops.pool_bwd(dP["p6"], (h5, w5), dP["p5"], 1)  # p6 = p5[::2, ::2]
@@ -299,11 +326,10 @@ class OpensetRCNNTrainer:
             dpl = dP[f"p{lvl}"]
             up = ops.pool_bwd(d_ls_prev, (h, w), None, 0) if d_ls_prev is not None else None
             d_ls = ops.conv2d_dgrad(dpl, self.wd[on], (h, w), 1, 1, add=up)
-            ops.conv2d_wgrad(ls, dpl, 3, 3, 1, 1, dw=g[on + ".w"])
-            ops.bias_grad(dpl, g[on + ".b"])
             res = s["res"][f"res{lvl}"]
-            ops.conv2d_wgrad(res, d_ls, 1, 1, dw=g[ln + ".w"])
-            ops.bias_grad(d_ls, g[ln + ".b"])
+            self._wg(lambda ls=ls, dpl=dpl, res=res, d_ls=d_ls, on=on, ln=ln: (
+                ops.conv2d_wgrad(ls, dpl, 3, 3, 1, 1, dw=g[on + ".w"]), ops.bias_grad(dpl, g[on + ".b"]),
+                ops.conv2d_wgrad(res, d_ls, 1, 1, dw=g[ln + ".w"]), ops.bias_grad(d_ls, g[ln + ".b"])), dpl, d_ls)
             self._done(on + ".w", on + ".b", ln + ".w", ln + ".b")
             if lvl > self.freeze_at:
                 d_res[lvl] = (d_ls, ln)  # the lateral's data gradient is formed together with the next stage's (see below)
@@ -321,12 +347,13 @@ class OpensetRCNNTrainer:
                 d_ls, ln = d_res[blk["stage"]]
                 G = ops.conv2d_dgrad(d_ls, self.wd[ln], (hy, wy), 1, 0, add=G, post_mask=y)
             d_o2 = ops.conv2d_dgrad(G, self.wd[pre + ".conv3"], (hy, wy), 1, 0, mask=o2)
-            ops.conv2d_wgrad(o2, G, 1, 1, dw=g[pre + ".conv3.w"])
+            self._wg(lambda o2=o2, G=G, pre=pre: ops.conv2d_wgrad(o2, G, 1, 1, dw=g[pre + ".conv3.w"]), G)
             d_o1 = ops.conv2d_dgrad(d_o2, self.wd[pre + ".conv2"], (o1.shape[1], o1.shape[2]), 1, 1, mask=o1)
-            ops.conv2d_wgrad(o1, d_o2, 3, 3, 1, 1, dw=g[pre + ".conv2.w"])
-            ops.conv2d_wgrad(x, d_o1, 1, 1, stride, 0, dw=g[pre + ".conv1.w"])
+            self._wg(lambda o1=o1, d_o2=d_o2, x=x, d_o1=d_o1, pre=pre, stride=stride: (
+                ops.conv2d_wgrad(o1, d_o2, 3, 3, 1, 1, dw=g[pre + ".conv2.w"]),
+                ops.conv2d_wgrad(x, d_o1, 1, 1, stride, 0, dw=g[pre + ".conv1.w"])), d_o2, d_o1)
             if blk["first"]:
-                ops.conv2d_wgrad(x, G, 1, 1, stride, 0, dw=g[pre + ".shortcut.w"])
+                self._wg(lambda x=x, G=G, pre=pre, stride=stride: ops.conv2d_wgrad(x, G, 1, 1, stride, 0, dw=g[pre + ".shortcut.w"]), G)
                 self._done(pre + ".shortcut.w")
             self._done(pre + ".conv3.w", pre + ".conv2.w", pre + ".conv1.w")
             if blk["first"] and blk["stage"] == self.freeze_at + 1:
@@ -341,6 +368,8 @@ class OpensetRCNNTrainer:
                 G = ops.conv2d_dgrad(G, self.wd[pre + ".shortcut"], (hx, wx), stride, 0, add=dx, post_mask=pm)
             else:
                 G = ops.conv2d_dgrad(d_o1, self.wd[pre + ".conv1"], (hx, wx), 1, 0, add=G, post_mask=pm)
+        if self.side_wgrad and self._wside is not None:  # join: the update (and any collective issued from here on) sees every weight gradient
+            torch.cuda.current_stream(self.device).wait_stream(self._wside)
 
     # ---- optimiser ------------------------------------------------------------------------------------------------
     def all_reduce_grads(self) -> int:
