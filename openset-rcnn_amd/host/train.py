@@ -259,6 +259,40 @@ class OpensetRCNNTrainer:
         self._overlap = overlap and parallel.is_dist()
         self.buckets.reset()
         dt = self.dtype
+        p = s["p"]
+        # --- CF-RPN: losses -> tail -> weight gradient of the 3x3 conv (weights shared by the five levels). This chain depends on
+        #     the forward only and meets the RoI heads' chain at the 3x3 conv's data gradient: it runs first, on the second stream,
+        #     under the RoI heads' backward (whose RoIAlign scatter is bound by the atomic rate, not by the matrix cores) ---
+        sel = s["sel"]
+        rn = "proposal_generator.rpn_head.conv"
+
+        def rpn_chain():
+            lt_ = loss_types_of(c)
+            d5 = ops.rpn_losses_bwd(sel["levels"], e.cell_anchors, n, sel["pred_deltas"], sel["pred_ctr"], s["labels"], s["obj_labels"], s["matched_boxes"],
+                                    s["ctr_target"], c["rpn_loc_weight"], c["rpn_ctr_weight"], c["rpn_batch_size"], S, box_loss=lt_["rpn_box"],
+                                    ctr_beta=lt_["rpn_ctr"][1])
+            dta, dw_tail, db_tail = ops.cfrpn_tail_bwd(s["rpn_t"], e.rpn_wtail, d5)
+            g["rpn_tail.w"].copy_(dw_tail)
+            g["rpn_tail.b"].copy_(db_tail)
+            ready = torch.cuda.current_stream(self.device).record_event()
+            off_ = 0
+            for li_, (k_, (h_, w_)) in enumerate(zip(("p2", "p3", "p4", "p5", "p6"), s["rpn_shapes"])):
+                rows_ = n * h_ * w_
+                dtl_ = dta[off_:off_ + rows_].view(n, h_, w_, 256)
+                off_ += rows_
+                ops.conv2d_wgrad(p[k_], dtl_, 3, 3, 1, 1, dw=g[rn + ".w"], accumulate=li_ > 0)
+                ops.bias_grad(dtl_, g[rn + ".b"], accumulate=li_ > 0)
+            return dta, ready
+        if self.side_wgrad:
+            cur0 = torch.cuda.current_stream(self.device)
+            if self._wside is None:
+                self._wside = torch.cuda.Stream(device=self.device)
+            self._wside.wait_stream(cur0)
+            with torch.cuda.stream(self._wside):
+                dt_all, rpn_ready = rpn_chain()
+        else:
+            dt_all, rpn_ready = rpn_chain()
+        self._done("rpn_tail.w", "rpn_tail.b", rn + ".w", rn + ".b")
         # --- RoI-head losses -> predictor / PLN / classifier (fp32 heads) ---
         lt = loss_types_of(c)
         d_pred = ops.roi_box_losses_bwd(s["pred"], s["boxes"], s["smp"]["gt_boxes"].view(-1, 4), s["cls"], s["ious"], c["num_classes"],
@@ -289,20 +323,15 @@ class OpensetRCNNTrainer:
                           ops.bias_grad(d_h1, g["fc1.b"])), d_h1)
         self._done("fc1.w", "fc1.b")
         P = c["pooler_resolution"]
-        p = s["p"]
         shapes = [(p[k].shape[1], p[k].shape[2]) for k in ("p2", "p3", "p4", "p5")]
         d_feat = ops.roi_align_bwd(d_pooled.view(m, P, P, -1), shapes, n, c["pooler_scales"], s["boxes"], s["smp"]["batch_idx"], c["canonical_level"],
                                    c["canonical_size"], 2)
-        # --- CF-RPN: losses -> tail -> 3x3 conv (weights shared by the five levels) ---
-        sel = s["sel"]
-        d5 = ops.rpn_losses_bwd(sel["levels"], e.cell_anchors, n, sel["pred_deltas"], sel["pred_ctr"], s["labels"], s["obj_labels"], s["matched_boxes"],
-                                s["ctr_target"], c["rpn_loc_weight"], c["rpn_ctr_weight"], c["rpn_batch_size"], S, box_loss=loss_types_of(c)["rpn_box"],
-                                ctr_beta=loss_types_of(c)["rpn_ctr"][1])
-        dt_all, dw_tail, db_tail = ops.cfrpn_tail_bwd(s["rpn_t"], e.rpn_wtail, d5)
-        g["rpn_tail.w"].copy_(dw_tail)
-        g["rpn_tail.b"].copy_(db_tail)
-        self._done("rpn_tail.w", "rpn_tail.b")
-        rn = "proposal_generator.rpn_head.conv"
+        # --- CF-RPN 3x3 conv: data gradient per level, joined with the RoI heads' feature gradient (the chain above it ran on the
+        #     second stream, see the top of this function) ---
+        if self.side_wgrad:
+            torch.cuda.current_stream(self.device).wait_event(rpn_ready)
+            if not torch.cuda.is_current_stream_capturing():
+                dt_all.record_stream(torch.cuda.current_stream(self.device))
         dP = {}
         off = 0
         for li, (k, (h, w)) in enumerate(zip(("p2", "p3", "p4", "p5", "p6"), s["rpn_shapes"])):
@@ -311,9 +340,6 @@ class OpensetRCNNTrainer:
             off += rows
             roi_part = ops.add_cast(d_feat[li], None, dt) if li < 4 else None
             dP[k] = ops.conv2d_dgrad(dtl, self.wd[rn], (h, w), 1, 1, add=roi_part)
-            self._wg(lambda k=k, dtl=dtl, li=li: (ops.conv2d_wgrad(p[k], dtl, 3, 3, 1, 1, dw=g[rn + ".w"], accumulate=li > 0),
-                                                  ops.bias_grad(dtl, g[rn + ".b"], accumulate=li > 0)), dt_all)
-        self._done(rn + ".w", rn + ".b")
         h5, w5 = p["p5"].shape[1], p["p5"].shape[2]
         dP["p5"] = ops.pool_bwd(dP["p6"], (h5, w5), dP["p5"], 1)  # p6 = p5[::2, ::2]
         # --- FPN: output convs, top-down adds, laterals (finest level first: its gradient flows up to the coarser sums) ---
