@@ -122,16 +122,42 @@ class OpensetRCNNTrainer:
             self.master[name + ".b"] = e.w[name + ".b"]
         self.conv_names.append(name)
 
+    def _fan(self, jobs) -> None:
+        """Independent in-place launches dealt round-robin over the trainer's streams: all start after the main stream's current
+        point, the main stream continues when all have finished. (No allocation inside the jobs: nothing changes stream.)"""
+        if not self.side_wgrad or not torch.cuda.is_available() or self.device.type != "cuda":
+            for job in jobs:
+                job()
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if self._wside is None:
+            self._wside = torch.cuda.Stream(device=self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        sts = [cur, self._wside, self._side]
+        for st in sts[1:]:
+            st.wait_stream(cur)
+        for i, job in enumerate(jobs):
+            with torch.cuda.stream(sts[i % len(sts)]):
+                job()
+        for st in sts[1:]:
+            cur.wait_stream(st)
+
     def _refresh_derived(self):
         """Everything that is a function of the parameters and read by a kernel: backward-data weights, transposed fp32 heads,
         normalised prototypes."""
         e = self.eng
-        wd = getattr(self, "wd", {})  # the buffers are allocated once and refilled in place every step (osr_pack_dgrad_weight)
-        for n in self.conv_names:
-            wd[n] = ops.pack_dgrad_weight(e.w[n + ".w"], wd.get(n))
-        wd["fc1"] = ops.pack_dgrad_weight(e.fc1_w, wd.get("fc1")).view(e.fc1_w.shape[1], 1, 1, e.fc1_w.shape[0])
-        wd["fc2"] = ops.pack_dgrad_weight(e.fc2_w, wd.get("fc2")).view(e.fc2_w.shape[1], 1, 1, e.fc2_w.shape[0])
-        self.wd = wd
+        wd = getattr(self, "wd", None)
+        if wd is None:  # first call: allocate the buffers (on the main stream); they are refilled in place every step (osr_pack_dgrad_weight)
+            wd = {n: ops.pack_dgrad_weight(e.w[n + ".w"]) for n in self.conv_names}
+            wd["fc1"] = ops.pack_dgrad_weight(e.fc1_w).view(e.fc1_w.shape[1], 1, 1, e.fc1_w.shape[0])
+            wd["fc2"] = ops.pack_dgrad_weight(e.fc2_w).view(e.fc2_w.shape[1], 1, 1, e.fc2_w.shape[0])
+            self.wd = wd
+        else:
+            jobs = [lambda n=n: ops.pack_dgrad_weight(e.w[n + ".w"], wd[n]) for n in self.conv_names]
+            jobs.append(lambda: ops.pack_dgrad_weight(e.fc1_w, wd["fc1"].view(e.fc1_w.shape[1], e.fc1_w.shape[0])))
+            jobs.append(lambda: ops.pack_dgrad_weight(e.fc2_w, wd["fc2"].view(e.fc2_w.shape[1], e.fc2_w.shape[0])))
+            self._fan(jobs)
         if not hasattr(self, "t_cls"):  # zero-padded transposes of the narrow fp32 heads: the padding rows are written once
             self.t_cls = torch.zeros((e.cls_w.shape[1], 32), dtype=torch.float32, device=e.device)    # (1024, 32): d rec = d logits(padded to 32) . W_cls
             self.t_pred = torch.zeros((e.pred_w.shape[1], 16), dtype=torch.float32, device=e.device)  # (1024, 16)
@@ -411,9 +437,10 @@ class OpensetRCNNTrainer:
         gs = 1.0 / (self.loss_scale * world)
         self._ok.fill_(1)
         ops.check_finite_(self.grad_flat, self._ok)
-        for k, pm in self.master.items():
-            lp = self.lowp.get(k)
-            ops.sgd_step_(pm, self.grad[k], self.mom[k], self.lr, self.momentum, self.weight_decay, gs, self.row_scale.get(k), lp, self._ok)
+        # ~75 in-place launches of a few microseconds each (one per parameter tensor), then ~70 repacking launches: dealt over the
+        # three streams of the trainer they run three abreast instead of one behind the other
+        self._fan([lambda k=k, pm=pm: ops.sgd_step_(pm, self.grad[k], self.mom[k], self.lr, self.momentum, self.weight_decay, gs, self.row_scale.get(k),
+                                                   self.lowp.get(k), self._ok) for k, pm in self.master.items()])
         self._refresh_derived()
         self._ok_host.copy_(self._ok, non_blocking=True)
         self._ok_event.record()
