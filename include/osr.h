@@ -145,6 +145,12 @@ osr_status osr_cfrpn_head_tail(const void* t, int32_t t_dtype, int64_t rows, int
  * envelope: run osr_conv2d_fwd + osr_cfrpn_head_tail instead. */
 osr_status osr_cfrpn_head_fwd(const osr_conv_params* p, const void* in, const void* weight, const float* bias,
                               const float* w_tail, const float* b_tail, float* deltas, float* ctr, void* stream);
+/* The same, also writing the hidden state t = relu(conv + bias) in the storage dtype, (n*ho*wo, 256) rows (hidden_out may be
+ * NULL): the training step keeps it for the head's backward (osr_cfrpn_tail_bwd, the 3x3 conv's weight gradient) instead of
+ * running the un-fused pair that writes t and reads it back. */
+osr_status osr_cfrpn_head_fwd_ex(const osr_conv_params* p, const void* in, const void* weight, const float* bias,
+                                 const float* w_tail, const float* b_tail, float* deltas, float* ctr, void* hidden_out,
+                                 void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Proposal selection: ClsFreeRPN.predict_proposals -> _decode_proposals (classification_free_rpn.py:558-610)

@@ -463,6 +463,14 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
                     if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // a few accumulators at a time: keeps the VGPR budget of the K loop
                 }
         __syncthreads();
+        if (a.out) {  // the training step keeps the hidden state for the head's backward: the tile's rows, 16 bytes per thread and store
+            TI* __restrict__ tout = reinterpret_cast<TI*>(a.out);
+            for (int q = tid; q < BM * 32; q += NT) {
+                const int row = q >> 5, ch8 = (q & 31) * 8;
+                const long long m = m0 + row;
+                if (m < a.M) *reinterpret_cast<frag_t*>(tout + m * 256 + ch8) = *reinterpret_cast<const frag_t*>(s_t + row * LDT + ch8);
+            }
+        }
         const float* s_tw = reinterpret_cast<const float*>(lds + a.tail_lds_off);
         static_assert(EPI == 0 || NT == 2 * BM, "two threads per pixel");
         const int row = tid >> 1, hf = tid & 1;
@@ -869,9 +877,17 @@ osr_status osr_conv64_run(const osr_conv_params* p, const void* in, const void* 
 // Whole ClsFreeRPNHead.forward for one level (3x3 conv + ReLU + channel L2-normalise + two 1x1 convs + sigmoid) in one
 // launch; deltas/ctr are written at pixel index n*ho*wo + oh*wo + ow. Returns OSR_ERR_UNSUPPORTED when the shape is
 // outside the fused kernel's envelope (the caller then runs osr_conv2d_fwd + osr_cfrpn_head_tail).
+extern "C" osr_status osr_cfrpn_head_fwd_ex(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const float* w_tail,
+                                            const float* b_tail, float* deltas, float* ctr, void* hidden_out, void* stream);
 extern "C" osr_status osr_cfrpn_head_fwd(const osr_conv_params* p, const void* in, const void* weight, const float* bias,
                                          const float* w_tail, const float* b_tail, float* deltas, float* ctr, void* stream) {
+    return osr_cfrpn_head_fwd_ex(p, in, weight, bias, w_tail, b_tail, deltas, ctr, nullptr, stream);
+}
+
+extern "C" osr_status osr_cfrpn_head_fwd_ex(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const float* w_tail,
+                                            const float* b_tail, float* deltas, float* ctr, void* hidden_out, void* stream) {
     OSR_REQUIRE(p && in && weight && bias && w_tail && b_tail && deltas && ctr, OSR_ERR_INVALID_ARG, "osr_cfrpn_head_fwd: null pointer");
+    OSR_REQUIRE((((uintptr_t)hidden_out) & 15) == 0, OSR_ERR_INVALID_ARG, "osr_cfrpn_head_fwd: hidden_out must be 16-byte aligned");
     OSR_REQUIRE(p->cout == 256 && p->cin % 64 == 0 && p->pad_mode == 0 && p->res_mode == 0, OSR_ERR_UNSUPPORTED,
                 "osr_cfrpn_head_fwd: fused path needs cout == 256, cin %% 64 == 0, no residual");
     OSR_REQUIRE(p->in_dtype == OSR_F16 || p->in_dtype == OSR_BF16, OSR_ERR_UNSUPPORTED, "osr_cfrpn_head_fwd: in_dtype must be f16/bf16");
@@ -886,7 +902,7 @@ extern "C" osr_status osr_cfrpn_head_fwd(const osr_conv_params* p, const void* i
     const long long in_bytes = (long long)p->n * p->in_stride_n * 2, w_bytes = (long long)p->cout * p->kh * p->kw * p->cin * 2;
     OSR_REQUIRE(osr_conv64_eligible(p, in_bytes, w_bytes), OSR_ERR_UNSUPPORTED, "osr_cfrpn_head_fwd: tensor too large for 32-bit buffer offsets");
     Conv64Args a;
-    a.p = *p; a.in = in; a.w = weight; a.bias = bias; a.res = nullptr; a.mask = nullptr; a.out = nullptr;
+    a.p = *p; a.in = in; a.w = weight; a.bias = bias; a.res = nullptr; a.mask = nullptr; a.out = hidden_out;
     a.M = (long long)p->n * p->ho * p->wo;
     a.K = p->kh * p->kw * p->cin;
     a.div_howo = fastdiv_make((unsigned)(p->ho * p->wo));

@@ -82,6 +82,7 @@ PROTOTYPES = {
     "osr_gemm_f32_tn": (I32, [P, I64, P, I64, P, I64, I32, I32, I32, P, I64, P]),
     "osr_cfrpn_head_tail": (I32, [P, I32, I64, I32, P, P, P, P, P, P, P]),
     "osr_cfrpn_head_fwd": (I32, [C.POINTER(ConvParams), P, P, P, P, P, P, P, P]),
+    "osr_cfrpn_head_fwd_ex": (I32, [C.POINTER(ConvParams), P, P, P, P, P, P, P, P, P]),
     "osr_rpn_select_capacity": (I32, [C.POINTER(RpnLevels), I32]),
     "osr_rpn_select_workspace_bytes": (I64, [C.POINTER(RpnLevels), I32, I32]),
     "osr_rpn_select": (I32, [C.POINTER(RpnLevels), P, P, P, I32, P, I32, F32, P, P, P, P, P, P, P, I64, P]),

@@ -131,6 +131,7 @@ class OpensetRCNNEngine:
             self.rpn_wtail = torch.cat((self.rpn_wd, self.rpn_wc)).contiguous()
             self.rpn_btail = torch.cat((self.rpn_bd, self.rpn_bc)).contiguous()
             self.fuse_rpn_head = self.dtype != torch.float32  # (the fused head kernel is an fp16/bf16 MFMA kernel; fp32 = parity mode)
+            self.rpn_keep_hidden = False
             sizes = c["anchor_sizes"]
             self.cell_anchors = torch.tensor([[[-s / 2.0, -s / 2.0, s / 2.0, s / 2.0]] for s in sizes], dtype=torch.float32, device=dev)
 
@@ -213,13 +214,13 @@ class OpensetRCNNEngine:
             keep.update(feats)
         return out
 
-    def _rpn_level_fused(self, f, deltas, ctr):
+    def _rpn_level_fused(self, f, deltas, ctr, hidden=None):
         w, b = self.w["proposal_generator.rpn_head.conv.w"], self.w["proposal_generator.rpn_head.conv.b"]
         if self.profile is None:
-            return ops.cfrpn_head_fused(f, w, b, self.rpn_wtail, self.rpn_btail, deltas, ctr)
+            return ops.cfrpn_head_fused(f, w, b, self.rpn_wtail, self.rpn_btail, deltas, ctr, hidden)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        ops.cfrpn_head_fused(f, w, b, self.rpn_wtail, self.rpn_btail, deltas, ctr)
+        ops.cfrpn_head_fused(f, w, b, self.rpn_wtail, self.rpn_btail, deltas, ctr, hidden)
         e1.record()
         rows = deltas.shape[0]
         self.profile.append(("proposal_generator.rpn_head.conv+tail", 2.0 * rows * 256 * (2304 + 5), e0, e1,
@@ -253,10 +254,11 @@ class OpensetRCNNEngine:
             # one launch per level: 3x3 conv + ReLU + normalise + both 1x1 + sigmoid, hidden state never leaves the chip
             deltas = torch.empty((sum(rows), 4), dtype=torch.float32, device=self.device)
             ctr = torch.empty((sum(rows),), dtype=torch.float32, device=self.device)
-            t_all = None
+            # (rpn_keep_hidden: the trainer's engine also wants the hidden state, for the head's backward)
+            t_all = torch.empty((sum(rows), 256), dtype=self.dtype, device=self.device) if self.rpn_keep_hidden else None
             off = 0
             for f, r in zip(fl, rows):
-                self._rpn_level_fused(f, deltas[off:off + r], ctr[off:off + r])
+                self._rpn_level_fused(f, deltas[off:off + r], ctr[off:off + r], None if t_all is None else t_all[off:off + r])
                 off += r
         else:
             t_all = torch.empty((sum(rows), 256), dtype=self.dtype, device=self.device)

@@ -252,9 +252,10 @@ def cfrpn_head_tail(t: torch.Tensor, w_delta, b_delta, w_ctr, b_ctr) -> Tuple[to
 
 
 def cfrpn_head_fused(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, w_tail: torch.Tensor, b_tail: torch.Tensor,
-                     deltas_out: Optional[torch.Tensor] = None, ctr_out: Optional[torch.Tensor] = None):
+                     deltas_out: Optional[torch.Tensor] = None, ctr_out: Optional[torch.Tensor] = None, hidden_out: Optional[torch.Tensor] = None):
     """ClsFreeRPNHead.forward for one level in one launch. x (n,h,w,256) f16/bf16, weight (256,3,3,256) packed,
-    w_tail (5,256) fp32 [deltas rows 0-3, centerness row 4], b_tail (5). Returns deltas (n*h*w, 4), ctr (n*h*w)."""
+    w_tail (5,256) fp32 [deltas rows 0-3, centerness row 4], b_tail (5). Returns deltas (n*h*w, 4), ctr (n*h*w).
+    hidden_out (n*h*w, 256), x's dtype: also receives the hidden state relu(conv + bias) (the training step keeps it)."""
     lib = _lib.load()
     _need(x, name="x"); _need(weight, x.dtype, "weight"); _need(bias, torch.float32, "bias")
     _need(w_tail, torch.float32, "w_tail"); _need(b_tail, torch.float32, "b_tail")
@@ -272,7 +273,10 @@ def cfrpn_head_fused(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, 
     p.in_stride_n, p.in_stride_h, p.in_stride_w = hi * wi * cin, wi * cin, cin
     p.relu, p.res_mode, p.pad_mode = 1, 0, 0
     p.in_dtype = p.out_dtype = _DT[x.dtype]
-    check(lib.osr_cfrpn_head_fwd(C.byref(p), _p(x), _p(weight), _p(bias), _p(w_tail), _p(b_tail), _p(deltas), _p(ctr), _stream()),
+    if hidden_out is not None:
+        _need(hidden_out, x.dtype, "hidden_out")
+        assert hidden_out.numel() == rows * 256
+    check(lib.osr_cfrpn_head_fwd_ex(C.byref(p), _p(x), _p(weight), _p(bias), _p(w_tail), _p(b_tail), _p(deltas), _p(ctr), _p(hidden_out), _stream()),
           "osr_cfrpn_head_fwd")
     return deltas, ctr
 

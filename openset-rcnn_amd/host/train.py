@@ -45,7 +45,7 @@ class OpensetRCNNTrainer:
         self.frozen_bn = frozen_bn or {}
         self.row_scale: Dict[str, torch.Tensor] = {}
         self.eng = OpensetRCNNEngine(params, cfg, dtype, device, class_map)
-        self.eng.fuse_rpn_head = False  # the hidden state of the head is needed by its backward
+        self.eng.rpn_keep_hidden = True  # the hidden state of the head is needed by its backward: the fused head kernel also writes it
         self.dtype, self.device = dtype, self.eng.device
         self.lr, self.momentum, self.weight_decay, self.loss_scale = lr, momentum, weight_decay, loss_scale
         self.freeze_at = freeze_at

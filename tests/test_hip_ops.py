@@ -639,6 +639,17 @@ def test_cfrpn_head_fused_matches_two_step_and_oracle(ops):
     dr, cr = O.cfrpn_head_tail(tq.permute(0, 2, 3, 1).reshape(-1, 256), pq)
     assert_close(d_f, dr, rtol=2e-3, atol=2e-3, name="fused vs oracle deltas")  # 1 fp16 ulp flips of t before the normalise
     assert_close(c_f, cr, rtol=2e-3, atol=1e-3, name="fused vs oracle ctr")
+    # osr_cfrpn_head_fwd_ex: the same launch also hands out the hidden state (the training step keeps it for the head's backward),
+    # for the small-level (128-row tiles) and the large-level (256-row tiles, >= 512 of them) instantiation
+    for xx in (xd, nhwc(torch.randn(2, 256, 264, 256, generator=gg).half()).to(DEV)):
+        rows = xx.shape[0] * xx.shape[1] * xx.shape[2]
+        hid = torch.full((rows, 256), -1.0, dtype=torch.float16, device=DEV)
+        d_h, c_h = ops.cfrpn_head_fused(xx, wd, b.to(DEV), wt.to(DEV), bt.to(DEV), hidden_out=hid)
+        d_0, c_0 = ops.cfrpn_head_fused(xx, wd, b.to(DEV), wt.to(DEV), bt.to(DEV))
+        assert torch.equal(d_h, d_0) and torch.equal(c_h, c_0)
+        tt = ops.conv2d(xx, wd, b.to(DEV), 1, 1, relu=True).view(-1, 256)
+        assert float((hid.float() - tt.float()).abs().max()) <= 2e-3 * float(tt.float().abs().max())  # (one fp16 ulp: another tile's K order)
+        assert float(hid.min()) >= 0.0
 
 
 def test_detector_postprocess(ops):
