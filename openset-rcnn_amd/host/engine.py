@@ -401,7 +401,8 @@ class OpensetRCNNEngine:
         return self.id_map[cls].contiguous(), self.cfg["num_known"]  # a gather: cls == -1 reads the last slot (-1)
 
     # ---- training step, forward half ----------------------------------------------------------------------
-    def pyramid_shapes(self, hp: int, wp: int):
+    @staticmethod
+    def pyramid_shapes(hp: int, wp: int):
         """(h, w) of p2..p6 for a padded hp x wp batch: stem 7x7/2 pad 3, max pool 3x3/2 pad 1, stride-2 1x1 convs, p6 = p5 subsampled."""
         down = lambda v: (v - 1) // 2 + 1  # noqa: E731
         h, w = (hp + 6 - 7) // 2 + 1, (wp + 6 - 7) // 2 + 1

@@ -94,3 +94,22 @@ def test_train_loader_resume_continues_the_exact_stream(osr, toy_dicts, monkeypa
     r1 = take(D.build_detection_train_loader(toy_dicts, D.DatasetMapper(cfg, True, seed=5), 4, seed=5, rank=1, world=2), 4)
     for it in range(4):
         assert [r0[it][0], r1[it][0], r0[it][1], r1[it][1]] == full[it]
+
+
+def test_host_side_option_tables_and_pyramid_shapes(osr):
+    """Host logic that needs no GPU: the (type, beta) -> osr_loss_options translation and the PLN distance table refuse unknown
+    names; pyramid_shapes reproduces the stride arithmetic of the stem (7x7/2 pad 3), the 3x3/2 max pool, the stride-2 1x1 convs
+    and LastLevelMaxPool for the two benchmark resolutions (800x1344 and GraspNet's 768x1344) and an odd size."""
+    from openset_rcnn_amd.host import ops
+    from openset_rcnn_amd.host.engine import OpensetRCNNEngine
+    o = ops._loss_options(("giou", 0.0), 0.25)
+    assert (o.box_loss_type, o.box_smooth_l1_beta, o.aux_smooth_l1_beta) == (2, 0.0, 0.25)
+    assert [ops._loss_options((k, 0.5), 0.0).box_loss_type for k in ("iou", "smooth_l1", "giou", "diou", "ciou")] == [0, 1, 2, 3, 4]
+    with pytest.raises(ops.OsrError):
+        ops._loss_options(("l2", 0.0), 0.0)
+    assert [ops._pln_distance(k) for k in ("COS", "L1", "L2")] == [0, 1, 2]
+    with pytest.raises(ops.OsrError):
+        ops._pln_distance("cosine")
+    assert OpensetRCNNEngine.pyramid_shapes(800, 1344) == [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
+    assert OpensetRCNNEngine.pyramid_shapes(768, 1344) == [(192, 336), (96, 168), (48, 84), (24, 42), (12, 21)]
+    assert OpensetRCNNEngine.pyramid_shapes(256, 352) == [(64, 88), (32, 44), (16, 22), (8, 11), (4, 6)]
