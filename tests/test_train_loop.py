@@ -14,6 +14,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda:0"
 LOSS_KEYS = {"loss_rpn_loc", "loss_rpn_ctr", "loss_box_reg", "loss_iou", "loss_dml", "loss_cls"}
+
+
 def _cfg(osr, yaml="voc_coco.yaml", extra=()):
     from openset_rcnn_amd.host.config import add_openset_rcnn_config, get_cfg
     cfg = get_cfg()
