@@ -72,15 +72,26 @@ class OpensetRCNNEngine:
     1/16 of the fp16 matrix rate), the arithmetic the reference itself runs in -- boxes, scores and embeddings then agree with the
     fp32 oracle to summation order (tests/test_e2e_parity.py)."""
 
+    FP32_POINTS = ("backbone", "rpn_hidden", "pooled", "h1")
+
     def __init__(self, params: Dict[str, torch.Tensor], cfg: Optional[dict] = None, dtype: torch.dtype = torch.float16,
-                 device: str = "cuda", class_map: Optional[torch.Tensor] = None):
+                 device: str = "cuda", class_map: Optional[torch.Tensor] = None, fp32_points: Sequence[str] = ()):
+        """fp32_points (diagnostic; fast mode only): storage points of the fp16 path kept in fp32 instead, to measure what each one
+        costs in agreement with the fp32 reference (tests/test_e2e_parity.py): "backbone" (stem .. FPN outputs computed by the
+        fp32 kernels, the pyramid handed on in fp16), "rpn_hidden" (the CF-RPN hidden state: un-fused head, fp32 t), "pooled"
+        (RoIAlign output and FC1 in fp32), "h1" (FC1 output and FC2 in fp32). The layers behind such a point run on the fp32
+        kernels (1/16 of the matrix rate): a measurement aid, not a product configuration."""
         self.cfg = dict(DEFAULT_CFG)
         if cfg:
             self.cfg.update(cfg)
         self.dtype = dtype
         self.device = torch.device(device)
         dev = self.device
+        self.fp32_points = frozenset(fp32_points) if dtype != torch.float32 else frozenset()
+        assert self.fp32_points <= set(self.FP32_POINTS), self.fp32_points
         self.w = self._pack_convs(params)
+        if "backbone" in self.fp32_points:
+            self._bb32 = OpensetRCNNEngine({k: v for k, v in params.items() if k.startswith("backbone.")}, cfg, torch.float32, device)
         c = self.cfg
         self.has_backbone = "backbone.bottom_up.stem.conv1.weight" in params
         self.class_map = None if class_map is None else class_map.to(torch.int64).to(dev)
@@ -130,7 +141,8 @@ class OpensetRCNNEngine:
             self.rpn_bc = f32("proposal_generator.rpn_head.centerness.bias")
             self.rpn_wtail = torch.cat((self.rpn_wd, self.rpn_wc)).contiguous()
             self.rpn_btail = torch.cat((self.rpn_bd, self.rpn_bc)).contiguous()
-            self.fuse_rpn_head = self.dtype != torch.float32  # (the fused head kernel is an fp16/bf16 MFMA kernel; fp32 = parity mode)
+            # (the fused head kernel is an fp16/bf16 MFMA kernel that parks the hidden state in the storage dtype; fp32 = parity mode)
+            self.fuse_rpn_head = self.dtype != torch.float32 and "rpn_hidden" not in self.fp32_points
             self.rpn_keep_hidden = False
             sizes = c["anchor_sizes"]
             self.cell_anchors = torch.tensor([[[-s / 2.0, -s / 2.0, s / 2.0, s / 2.0]] for s in sizes], dtype=torch.float32, device=dev)
@@ -141,9 +153,11 @@ class OpensetRCNNEngine:
         self.has_roi = "roi_heads.box_predictor.iou_pred.weight" in params
         if not self.has_roi:
             return
-        self.fc1_w = pack_fc1_weight(params["roi_heads.box_head.fc1.weight"], 256, c["pooler_resolution"], dtype).to(dev)
+        fc1_dt = torch.float32 if "pooled" in self.fp32_points else dtype
+        fc2_dt = torch.float32 if "h1" in self.fp32_points else dtype
+        self.fc1_w = pack_fc1_weight(params["roi_heads.box_head.fc1.weight"], 256, c["pooler_resolution"], fc1_dt).to(dev)
         self.fc1_b = params["roi_heads.box_head.fc1.bias"].float().to(dev)
-        self.fc2_w = params["roi_heads.box_head.fc2.weight"].to(dtype).contiguous().to(dev)
+        self.fc2_w = params["roi_heads.box_head.fc2.weight"].to(fc2_dt).contiguous().to(dev)
         self.fc2_b = params["roi_heads.box_head.fc2.bias"].float().to(dev)
         self.pred_w = torch.cat((f32("roi_heads.box_predictor.bbox_pred.weight"), f32("roi_heads.box_predictor.iou_pred.weight"))).contiguous()
         self.pred_b = torch.cat((f32("roi_heads.box_predictor.bbox_pred.bias"), f32("roi_heads.box_predictor.iou_pred.bias"))).contiguous()
@@ -164,22 +178,29 @@ class OpensetRCNNEngine:
         rows = y.numel() // w.shape[0]
         nbytes = x.numel() * x.element_size() + w.numel() * w.element_size() + y.numel() * y.element_size() + \
             (residual.numel() * residual.element_size() if residual is not None else 0)
-        self.profile.append((name, 2.0 * rows * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3], e0, e1, nbytes))
+        flops = 2.0 * rows * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3]
+        self.profile.append((name, flops, e0, e1, nbytes, flops))
         return y
 
-    def _linear(self, x, w, b, relu, out_dtype=None, name="fc", row_seg=None):
+    def _linear(self, x, w, b, relu, out_dtype=None, name="fc", row_seg=None, real_rows=None):
+        """real_rows (profiling only): how many of x's rows carry data. The padding rows of the per-image proposal lists are not
+        algorithmic work: FLOPs and bytes are credited for the real rows only, the nominal figure (all rows of the
+        fixed-capacity list) is kept beside it."""
         if self.profile is None:
             return ops.linear(x, w, b, relu=relu, out_dtype=out_dtype, row_seg=row_seg)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         y = ops.linear(x, w, b, relu=relu, out_dtype=out_dtype, row_seg=row_seg)
         e1.record()
-        nbytes = x.numel() * x.element_size() + w.numel() * w.element_size() + y.numel() * y.element_size()
-        self.profile.append((name, 2.0 * x.shape[0] * w.shape[0] * w.shape[1], e0, e1, nbytes))
+        rr = x.shape[0] if real_rows is None else int(real_rows)
+        nbytes = rr * x.shape[1] * x.element_size() + w.numel() * w.element_size() + rr * y.shape[1] * y.element_size()
+        self.profile.append((name, 2.0 * rr * w.shape[0] * w.shape[1], e0, e1, nbytes, 2.0 * x.shape[0] * w.shape[0] * w.shape[1]))
         return y
 
     def _backbone(self, images: torch.Tensor, hp: int, wp: int, keep: Optional[dict] = None, normalized: bool = False) -> Dict[str, torch.Tensor]:
         c = self.cfg
+        if "backbone" in self.fp32_points:  # diagnostic: the fp32 kernels compute the pyramid, the heads get it in the storage dtype
+            return {k: v.to(self.dtype) for k, v in self._bb32._backbone(images, hp, wp, None, normalized).items()}
         mean, std = ((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)) if normalized else (c["pixel_mean"], c["pixel_std"])
         xpad = ops.preprocess(images, hp, wp, mean, std, self.dtype)
         if self.profile is not None:
@@ -189,7 +210,7 @@ class OpensetRCNNEngine:
         if self.profile is not None:
             e1.record()
             self.profile.append(("backbone.bottom_up.stem.conv1", 2.0 * x.numel() * 147, e0, e1,
-                                 xpad.numel() * 2 + x.numel() * 2))  # 7*7*3 real taps
+                                 xpad.numel() * 2 + x.numel() * 2, 2.0 * x.numel() * 147))  # 7*7*3 real taps
         if keep is not None:
             keep["stem"] = x
         x = ops.maxpool3x3s2(x)
@@ -224,7 +245,7 @@ class OpensetRCNNEngine:
         e1.record()
         rows = deltas.shape[0]
         self.profile.append(("proposal_generator.rpn_head.conv+tail", 2.0 * rows * 256 * (2304 + 5), e0, e1,
-                             f.numel() * 2 + w.numel() * 2 + rows * 20))
+                             f.numel() * 2 + w.numel() * 2 + rows * 20, 2.0 * rows * 256 * (2304 + 5)))
 
     def _hbm(self, name, fn, nbytes, info=None):
         """Run fn(); with profile_hbm set, bracket it with HIP events on the launch stream and record its ALGORITHMIC bytes
@@ -261,10 +282,11 @@ class OpensetRCNNEngine:
                 self._rpn_level_fused(f, deltas[off:off + r], ctr[off:off + r], None if t_all is None else t_all[off:off + r])
                 off += r
         else:
-            t_all = torch.empty((sum(rows), 256), dtype=self.dtype, device=self.device)
+            t_dt = torch.float32 if "rpn_hidden" in self.fp32_points else self.dtype
+            t_all = torch.empty((sum(rows), 256), dtype=t_dt, device=self.device)
             off = 0
             for f, r in zip(fl, rows):
-                self._conv(f, "proposal_generator.rpn_head.conv", 1, 1, relu=True, out=t_all[off:off + r])
+                self._conv(f, "proposal_generator.rpn_head.conv", 1, 1, relu=True, out=t_all[off:off + r], out_dtype=t_dt)
                 off += r
             deltas, ctr = ops.cfrpn_head_tail(t_all, self.rpn_wd, self.rpn_bd, self.rpn_wc, self.rpn_bc)
         k = self.cfg["pre_nms_topk_test"] if topk is None else topk
@@ -283,16 +305,25 @@ class OpensetRCNNEngine:
         boxes = sel["boxes"].view(-1, 4)
         fl = [feats[k] for k in ("p2", "p3", "p4", "p5")]
         es = fl[0].element_size()
-        # algorithmic bytes: the pyramid once + the pooled output once + the RoIs
-        pooled = self._hbm("roi_align", lambda: ops.roi_align(fl, c["pooler_scales"], boxes, sel["batch_idx"], c["pooler_resolution"], self.dtype,
+        # algorithmic bytes: the pyramid once + the pooled rows of the REAL RoIs once + their boxes (the padding rows of
+        # the fixed-capacity lists are zero-filled, not algorithmic output); `info` carries (real rows, nominal bytes)
+        profiling = self.profile is not None or self.profile_hbm is not None
+        real = int(sel["counts"].sum()) if profiling else None  # (a host sync: attribution passes only)
+        row_b = c["pooler_resolution"] ** 2 * 256 * es + 20
+        pooled_dt = torch.float32 if "pooled" in self.fp32_points else self.dtype
+        h1_dt = torch.float32 if self.fp32_points & {"pooled", "h1"} else None  # (the fp32 kernel writes fp32 only)
+        pooled = self._hbm("roi_align", lambda: ops.roi_align(fl, c["pooler_scales"], boxes, sel["batch_idx"], c["pooler_resolution"], pooled_dt,
                                                                c["canonical_level"], c["canonical_size"], 2),
-                           lambda: sum(f.numel() for f in fl) * es + boxes.shape[0] * (c["pooler_resolution"] ** 2 * 256 * es + 20))
+                           lambda: sum(f.numel() for f in fl) * es + real * row_b,
+                           lambda o: dict(real_rois=real, list_rows=boxes.shape[0], nominal_bytes=sum(f.numel() for f in fl) * es + boxes.shape[0] * row_b))
         m = pooled.shape[0]
         # each image's list is [its proposals ..., padding]: the FC tiles that hold only padding rows are skipped (their rows of h1 /
         # box_feats stay unwritten; nothing downstream reads past an image's count)
-        seg = (sel["counts"], cap) if self.skip_padding_tiles else None
-        h1 = self._linear(pooled.view(m, -1), self.fc1_w, self.fc1_b, True, name="roi_heads.box_head.fc1", row_seg=seg)
-        box_feats = self._linear(h1, self.fc2_w, self.fc2_b, True, torch.float32, name="roi_heads.box_head.fc2", row_seg=seg)
+        seg = (sel["counts"], cap) if self.skip_padding_tiles and not self.fp32_points & {"pooled", "h1"} else None
+        h1 = self._linear(pooled.view(m, -1), self.fc1_w, self.fc1_b, True, h1_dt, name="roi_heads.box_head.fc1", row_seg=seg, real_rows=real)
+        if "pooled" in self.fp32_points and "h1" not in self.fp32_points:
+            h1 = h1.to(self.dtype)  # (diagnostic configuration: FC1 ran in fp32, h1 is stored in the fast path's dtype again)
+        box_feats = self._linear(h1, self.fc2_w, self.fc2_b, True, torch.float32, name="roi_heads.box_head.fc2", row_seg=seg, real_rows=real)
         pt = ops.box_predictor_tail(box_feats, self.pred_w, self.pred_b, boxes, sel["scores"].view(-1), sel["batch_idx"], image_hw,
                                     c["bbox_reg_weights"], 0 if c["mean_type"] == "geometric" else 1, c["obj_score_thresh"])
         topk1 = c["detections_per_image"]

@@ -23,7 +23,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 from torch import nn
 
-from . import ops
+from . import ops, parallel
 from .config import CfgNode
 from .engine import DEFAULT_CFG, OpensetRCNNEngine
 from .engine_std import StandardRCNNEngine
@@ -698,7 +698,7 @@ class GeneralizedRCNN(_EngineOwner):
         trainer = self.trainer()
         tensors = self._train_tensors(batched_inputs, self.sampler_generator)
         with torch.no_grad():
-            trainer.poll_overflow()
+            trainer.poll_overflow(wait=parallel.is_dist())  # (several ranks: all apply the same verdicts at the same iteration)
             losses, saved = trainer._forward(*tensors)
         names = list(losses)
         outs = _ExplicitBackward.apply(self._grad_hook(), trainer, saved, tensors[0].shape[0], *[losses[k] for k in names])

@@ -263,6 +263,8 @@ def cfrpn_head_fused(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, 
     cout, kh, kw, _ = weight.shape
     pad = kh // 2
     rows = n * hi * wi
+    if FLOP_COUNT is not None:
+        FLOP_COUNT["conv"] += 2.0 * rows * cout * (kh * kw * cin + 5)  # the 3x3 conv + the five 1x1 outputs of the fused tail
     deltas = deltas_out if deltas_out is not None else torch.empty((rows, 4), dtype=torch.float32, device=x.device)
     ctr = ctr_out if ctr_out is not None else torch.empty((rows,), dtype=torch.float32, device=x.device)
     _need(deltas, torch.float32, "deltas"); _need(ctr, torch.float32, "ctr")

@@ -125,12 +125,23 @@ class GradBuckets:
         self.issued = [False] * len(self.buckets)
 
     def mark_done(self, name: str) -> None:
-        b = self.owner[name]
-        self.pending[b].discard(name)
-        if not self.pending[b] and not self.issued[b]:
-            self._issue(b)
+        for b in self.mark_ready((name,)):
+            self.issue(b)
 
-    def _issue(self, b: int) -> None:
+    def mark_ready(self, names: Sequence[str]) -> List[int]:
+        """Record that these parameters' gradients are final; returns the buckets this completes (not yet issued): the caller
+        issues them with `issue(b)` from the stream it wants the collective ordered behind."""
+        ready: List[int] = []
+        for name in names:
+            b = self.owner[name]
+            self.pending[b].discard(name)
+            if not self.pending[b] and not self.issued[b] and b not in ready:
+                ready.append(b)
+        return ready
+
+    def issue(self, b: int) -> None:
+        if self.issued[b]:
+            return
         self.issued[b] = True
         if is_dist() and dist.get_world_size() > 1:
             bk = self.buckets[b]
@@ -140,7 +151,7 @@ class GradBuckets:
         """Issue whatever the backward did not mark (a bucket with an untracked parameter), wait for all, re-arm."""
         for b in range(len(self.buckets)):
             if not self.issued[b]:
-                self._issue(b)
+                self.issue(b)
         for w in self.works:
             w.wait()
         self.reset()

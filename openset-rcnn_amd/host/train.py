@@ -14,6 +14,7 @@ Data parallel: one process per GPU; `all_reduce_grads()` sums the single flat fp
 wraps the model in DDP) and the update divides by the world size."""
 from __future__ import annotations
 
+import collections
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -34,11 +35,68 @@ def warmup_multistep_lr(iteration: int, base_lr: float, steps: Tuple[int, ...], 
     return lr
 
 
+class DynamicLossScale:
+    """Host half of the overflow guard: one (event, pinned slot) per update, drained IN ORDER. The device half is a flag that
+    osr_check_finite clears and every osr_sgd_step launch of the iteration reads (a poisoned update changes nothing, no host
+    sync). `record(flag)` queues that flag's copy into a slot of its own right after an update; `poll(wait)` applies the verdicts
+    of the updates that have finished -- an overflow halves the scale (floor 1.0), `growth_interval` consecutive clean updates
+    double it again, never past the configured scale (what torch's GradScaler does) -- so no verdict is ever overwritten however
+    far the host runs ahead of the GPU, and the scale is not a one-way ratchet."""
+
+    def __init__(self, scale: float, growth_interval: int = 2000, device: Optional[torch.device] = None):
+        self.scale, self.scale_max, self.growth_interval = float(scale), float(scale), int(growth_interval)
+        self.cuda = device is not None and torch.device(device).type == "cuda"
+        self.queue: collections.deque = collections.deque()
+        self.free: List[torch.Tensor] = []
+        self.overflow_steps = 0
+        self.clean_steps = 0  # consecutive clean updates since the last overflow / growth
+
+    def record(self, ok_flag: torch.Tensor) -> None:
+        """ok_flag: (1,) int32 on the trainer's device, 1 = the update just enqueued was applied, 0 = skipped."""
+        if self.free:
+            slot = self.free.pop()
+        else:
+            slot = torch.ones((1,), dtype=torch.int32)
+            if self.cuda:
+                slot = slot.pin_memory()
+        slot.copy_(ok_flag, non_blocking=True)
+        ev = None
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+        self.queue.append((ev, slot))
+
+    def poll(self, wait: bool = False) -> bool:
+        """True when at least one of the drained updates had been skipped."""
+        any_overflow = False
+        while self.queue:
+            ev, slot = self.queue[0]
+            if ev is not None:
+                if wait:
+                    ev.synchronize()
+                elif not ev.query():
+                    break
+            self.queue.popleft()
+            ok = int(slot[0]) == 1
+            self.free.append(slot)
+            if ok:
+                self.clean_steps += 1
+                if self.growth_interval > 0 and self.clean_steps >= self.growth_interval and self.scale < self.scale_max:
+                    self.scale = min(self.scale_max, self.scale * 2.0)
+                    self.clean_steps = 0
+            else:
+                any_overflow = True
+                self.overflow_steps += 1
+                self.clean_steps = 0
+                self.scale = max(1.0, self.scale * 0.5)
+        return any_overflow
+
+
 class OpensetRCNNTrainer:
     def __init__(self, params: Dict[str, torch.Tensor], cfg: Optional[dict] = None, dtype: torch.dtype = torch.float16, device: str = "cuda",
                  lr: float = 0.005, momentum: float = 0.9, weight_decay: float = 1e-4, loss_scale: float = 1024.0, freeze_at: int = 2,
                  frozen_bn: Optional[Dict[str, Tuple[torch.Tensor, torch.Tensor]]] = None, class_map: Optional[torch.Tensor] = None,
-                 bucket_bytes: int = 25 << 20):
+                 bucket_bytes: int = 25 << 20, scale_growth_interval: int = 2000):
         """params: BN-folded parameters under detectron2 names (what the engine reads). frozen_bn (optional): for convs followed by
         FrozenBatchNorm, name -> (un-folded weight (cout,cin,kh,kw), per-channel scale gamma/sqrt(var+eps)): the trainable parameter
         is the un-folded weight (weight decay acts on it, the chain rule multiplies the kernel's gradient by the scale)."""
@@ -47,7 +105,8 @@ class OpensetRCNNTrainer:
         self.eng = OpensetRCNNEngine(params, cfg, dtype, device, class_map)
         self.eng.rpn_keep_hidden = True  # the hidden state of the head is needed by its backward: the fused head kernel also writes it
         self.dtype, self.device = dtype, self.eng.device
-        self.lr, self.momentum, self.weight_decay, self.loss_scale = lr, momentum, weight_decay, loss_scale
+        self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
+        self.scaler = DynamicLossScale(loss_scale, scale_growth_interval, self.eng.device)
         self.freeze_at = freeze_at
         e, dev = self.eng, self.eng.device
         f32 = lambda t: t.detach().float().contiguous().to(dev)  # noqa: E731
@@ -95,12 +154,9 @@ class OpensetRCNNTrainer:
         self.buckets = parallel.GradBuckets(self.grad_flat, layout, bucket_bytes)
         self.mom = {k: torch.zeros_like(t) for k, t in self.master.items()}
         self.num_params = sum(t.numel() for t in self.master.values())
-        # overflow guard: device flag read by every osr_sgd_step launch, mirrored into pinned host memory after the update
+        # overflow guard: device flag read by every osr_sgd_step launch; its host half is self.scaler (DynamicLossScale)
         self._ok = torch.ones((1,), dtype=torch.int32, device=dev)
-        self._ok_host = torch.ones((1,), dtype=torch.int32).pin_memory() if dev.type == "cuda" else torch.ones((1,), dtype=torch.int32)
-        self._ok_event = torch.cuda.Event()
-        self._ok_pending = False
-        self.overflow_steps = 0
+        self._cside: Optional[torch.cuda.Stream] = None  # stream the gradient buckets' collectives are issued from (see _done)
         self._overlap = False
         self.grads_ready = False
         self._side: Optional[torch.cuda.Stream] = None  # stream of the ground-truth-only part of the forward (anchor targets)
@@ -108,6 +164,18 @@ class OpensetRCNNTrainer:
         self._wside: Optional[torch.cuda.Stream] = None  # stream of the weight / bias gradient launches (see _wg)
         self.side_wgrad = True
         self._refresh_derived()
+
+    @property
+    def loss_scale(self) -> float:
+        return self.scaler.scale
+
+    @loss_scale.setter
+    def loss_scale(self, v: float) -> None:  # (a resumed checkpoint restores the scale it was written with)
+        self.scaler.scale = float(v)
+
+    @property
+    def overflow_steps(self) -> int:
+        return self.scaler.overflow_steps
 
     def _add_conv(self, name: str, params, bias: bool):
         e = self.eng
@@ -248,17 +316,27 @@ class OpensetRCNNTrainer:
 
     def _done(self, *names: str) -> None:
         """The gradients of these parameters are final (their last launch is enqueued): a bucket they complete starts its
-        all-reduce now, under the rest of the backward. With the weight gradients on their own stream the collective is issued from
-        that stream after it has been made to wait for the main one, so it is ordered behind everything enqueued so far on both."""
-        if self._overlap:
-            if self.side_wgrad and self._wside is not None:
-                self._wside.wait_stream(torch.cuda.current_stream(self.device))
-                with torch.cuda.stream(self._wside):
-                    for k in names:
-                        self.buckets.mark_done(k)
-            else:
-                for k in names:
-                    self.buckets.mark_done(k)
+        all-reduce now, under the rest of the backward. The collective is issued from a stream of its own that waits for two
+        EVENTS -- the main stream's and the weight-gradient stream's current points -- so it is ordered behind everything enqueued
+        so far on both, and neither of the two compute streams waits for the other or for the collective (a wait_stream of the
+        weight-gradient stream on the main one at every call re-serialised the two streams the single-GPU step gains 2 ms from)."""
+        if not self._overlap:
+            return
+        ready = self.buckets.mark_ready(names)
+        if not ready:
+            return
+        if self.device.type != "cuda":
+            for b in ready:
+                self.buckets.issue(b)
+            return
+        if self._cside is None:
+            self._cside = torch.cuda.Stream(device=self.device)
+        self._cside.wait_event(torch.cuda.current_stream(self.device).record_event())
+        if self.side_wgrad and self._wside is not None:
+            self._cside.wait_event(self._wside.record_event())
+        with torch.cuda.stream(self._cside):
+            for b in ready:
+                self.buckets.issue(b)
 
     def _wg(self, fn, *reads: torch.Tensor) -> None:
         """Run a weight / bias gradient launch group off the critical path: the chain of data gradients (dy of a layer -> dy of the
@@ -282,6 +360,7 @@ class OpensetRCNNTrainer:
         """Gradients of grad_scale * (sum of the six losses), times the loss scale, into self.grad. overlap: start each gradient
         bucket's all-reduce as soon as the backward has passed it (several ranks only; all_reduce_grads() then just waits)."""
         e, c, g, S = self.eng, self.eng.cfg, self.grad, self.loss_scale * grad_scale
+        self._scale_used = self.loss_scale  # the update divides out the scale THIS backward multiplied in, whatever a poll does in between
         self._overlap = overlap and parallel.is_dist()
         self.buckets.reset()
         dt = self.dtype
@@ -434,7 +513,7 @@ class OpensetRCNNTrainer:
         """SGD on every master, gated on the device by the overflow flag: an iteration whose (all-reduced) gradients hold an inf or
         NaN changes neither parameters nor momentum (the reference trains in fp32 and cannot overflow; fp16 gradients can). The
         flag is read back lazily by `poll_overflow()` -- no host sync here."""
-        gs = 1.0 / (self.loss_scale * world)
+        gs = 1.0 / (getattr(self, "_scale_used", self.loss_scale) * world)
         self._ok.fill_(1)
         ops.check_finite_(self.grad_flat, self._ok)
         # ~75 in-place launches of a few microseconds each (one per parameter tensor), then ~70 repacking launches: dealt over the
@@ -442,29 +521,24 @@ class OpensetRCNNTrainer:
         self._fan([lambda k=k, pm=pm: ops.sgd_step_(pm, self.grad[k], self.mom[k], self.lr, self.momentum, self.weight_decay, gs, self.row_scale.get(k),
                                                    self.lowp.get(k), self._ok) for k, pm in self.master.items()])
         self._refresh_derived()
-        self._ok_host.copy_(self._ok, non_blocking=True)
-        self._ok_event.record()
-        self._ok_pending = True
+        self.scaler.record(self._ok)
 
     def poll_overflow(self, wait: bool = False) -> bool:
-        """True when the last finished update was skipped because of non-finite gradients. Then the loss scale is halved (dynamic
-        loss scaling; floor 1.0) and `overflow_steps` counts it. Cheap: reads a pinned flag once its copy event has completed
-        (`wait=True` blocks for it: the checkpoint writer does, so that no skipped or half-applied state is written blind)."""
-        if not self._ok_pending or not (wait or self._ok_event.query()):
-            return False
-        if wait:
-            self._ok_event.synchronize()
-        self._ok_pending = False
-        if int(self._ok_host[0]) == 1:
-            return False
-        self.overflow_steps += 1
-        self.loss_scale = max(1.0, self.loss_scale * 0.5)
-        return True
+        """Drain, IN ORDER, the verdicts of the updates that have finished (wait=True: of every update issued so far). True when
+        at least one of them was skipped because of non-finite gradients. Dynamic loss scaling as GradScaler does it: an
+        overflow halves the scale (floor 1.0) and counts in `overflow_steps`; `scale_growth_interval` consecutive clean updates
+        double it again, never past the configured scale. Every update has a pinned slot of its own, so a verdict is never lost
+        however far the host runs ahead. With several ranks step() calls this with wait=True: every rank then applies the same
+        verdicts (they are functions of the all-reduced gradient) at the same iteration, and the scales cannot drift apart.
+        (`wait=True` is also what the checkpoint writer uses, so that no skipped or half-applied state is written blind.)"""
+        return self.scaler.poll(wait)
 
     def step(self, images, image_hw, hp, wp, gt_boxes, gt_classes, gt_count, keys, update: bool = True) -> Dict[str, torch.Tensor]:
         """One iteration: returns the loss dict (GPU scalars). update=False leaves the parameters untouched (gradients stay in
         self.grad, scaled by loss_scale)."""
-        self.poll_overflow()  # the previous iteration's verdict (already on the host by now): adjusts the loss scale
+        # earlier iterations' verdicts adjust the loss scale here, at one deterministic point of the iteration; with several ranks
+        # the call waits for them, so that all ranks change the scale at the same iteration (see poll_overflow)
+        self.poll_overflow(wait=parallel.is_dist())
         losses, saved = self._forward(images, image_hw, hp, wp, gt_boxes, gt_classes, gt_count, keys)
         self._backward(saved, images.shape[0], overlap=update)
         if update:

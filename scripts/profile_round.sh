@@ -10,7 +10,7 @@ TAG=${1:-r01_d}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train-step --no-pmc --streams 1 --no-graph"
+CMD="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train-step --no-pmc --no-parity --streams 1 --no-graph"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 $CMD > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o run -- python3 $CMD > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o run -- python3 $CMD > $OUT/pmc_write.log 2>&1

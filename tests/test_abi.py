@@ -59,3 +59,16 @@ def test_argument_validation_needs_no_gpu(osr):
 def test_no_cpu_fallback(osr):
     with pytest.raises(osr.OsrError):
         osr.ops.l2_normalize_rows(torch.zeros(4, 8))  # CPU tensor: refused, not computed on the host
+
+
+def test_shipped_library_has_no_environment_dependence(osr):
+    """The tuning knobs are compile-time constants in the product build (an -DOSR_EXPERIMENT diagnostic build reads them from the
+    environment; scripts/ab_*.sh): libosr_hip.so neither imports getenv nor carries a knob's name."""
+    import subprocess
+    import __graft_entry__ as ge
+    ge.build()
+    und = subprocess.run(["nm", "-D", "--undefined-only", osr._lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und
+    blob = open(osr._lib.LIB_PATH, "rb").read()
+    for knob in (b"OSR_CONV_BK32", b"OSR_CONV_FORCE_TILE", b"OSR_CONV_MODEL_BIG", b"OSR_RPN_BIG_MIN_TILES", b"OSR_CONV_TAP_MINOR"):
+        assert knob not in blob, knob

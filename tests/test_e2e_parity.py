@@ -102,6 +102,16 @@ def test_parity_mode_detections_match_the_fp32_oracle(world):
     assert frac >= 0.95, frac
     assert tot[1] == tot[0]  # class ids equal on every match
     world["keep32"] = keep
+    # north_star: "fp32 box/score/embedding within 1e-4" -- END TO END, on the matched detections: box corners within 1e-4 of the
+    # image extent (relative) and scores within 1e-4 absolute, not just IoU >= 0.99 / 1e-2
+    from openset_rcnn_amd.host.agreement import detection_agreement
+    ag = detection_agreement(dets, ref)
+    extent = float(max(H, W))
+    print(f"[parity mode] matched {ag['matched']}: max |box diff| {ag['max_box_abs_diff_px']:.3e} px "
+          f"({ag['max_box_abs_diff_px'] / extent:.2e} of the image extent), max |score diff| {ag['max_score_abs_diff']:.3e}")
+    assert ag["matched"] == tot[0]
+    assert ag["max_box_abs_diff_px"] / extent <= 1e-4, ag
+    assert ag["max_score_abs_diff"] <= 1e-4, ag
 
 
 def test_parity_mode_dense_stages_within_1e_4(world):
@@ -164,9 +174,33 @@ def test_fast_mode_detection_agreement_is_reported(world):
     loose = [agreement(g, r, iou_thr=0.9, score_tol=5e-2) for g, r in zip(dets, ref)]
     lfrac = sum(m for m, *_ in loose) / max(sum(max(ng, nr) for _, _, ng, nr in loose), 1)
     print(f"[fast mode] at IoU >= 0.9, |dscore| <= 5e-2: {lfrac:.3f}")
+    # bf16 storage (8 significant bits) is a TRAINING storage type here (bench.py does not offer it for inference): reported only
     _, dets_bf = _run(world, torch.bfloat16)
-    _report("fast mode, bf16 storage", dets_bf, ref)
-    assert frac >= 0.5 and lfrac >= frac, (frac, lfrac)
+    _report("fast mode, bf16 storage (training-only storage type)", dets_bf, ref)
+    # measured 0.91 on MI355X (rounds 2 and 3): a regression of the fp16 path's agreement below 0.85 fails
+    assert frac >= 0.85 and lfrac >= frac, (frac, lfrac)
+
+
+def test_which_fp16_storage_point_costs_the_agreement(world):
+    """the fast path re-run with each fp16 storage point kept in fp32 in turn (engine fp32_points, a
+    diagnostic: the layers behind the point run on the fp32 kernels). Reported; asserted only that no such point makes the
+    agreement WORSE by more than noise, and that the all-fp32-heads-behind-an-fp16-backbone configuration is reported next to the
+    fp32-backbone one -- the numbers say where the 9 % goes."""
+    ref = world["ref"]
+    res = {}
+    for pts in ((), ("rpn_hidden",), ("pooled",), ("h1",), ("pooled", "h1"), ("rpn_hidden", "pooled", "h1"), ("backbone",)):
+        eng = world["Engine"](world["params"], dtype=torch.float16, device=DEV, fp32_points=pts)
+        out = eng.forward(world["images"].to(DEV), world["sizes"])
+        torch.cuda.synchronize()
+        dets = [(d["pred_boxes"], d["scores"], d["pred_classes"]) for d in eng.to_instances(out, N)]
+        frac, _ = _report("fast mode, fp32 at " + ("+".join(pts) if pts else "(nothing: the benchmark path)"), dets, ref)
+        res[pts] = frac
+        del eng
+    print("\n[storage points] " + "; ".join(f"{'+'.join(k) or 'none'}: {v:.3f}" for k, v in res.items()))
+    base = res[()]
+    assert base >= 0.85
+    for k, v in res.items():
+        assert v >= base - 0.05, (k, v, base)
 
 
 def test_parity_mode_at_benchmark_resolution(osr):

@@ -618,6 +618,63 @@ def test_softmax_candidates_nms_assemble_vs_oracle(ops):
         assert bool((rc[:nu] == 80).all()) and bool((rc[nu:] != 80).all())  # [unknown..., known...]
 
 
+def test_inference_tail_all_known_single_unknown_and_all_unknown(ops):
+    """The branches softmax_classifier.py:317-344 and prototype_learning_network.py:218-222 fix (tests/test_oracle_kat.py (ix)) on
+    the HIP path: an image whose detections are ALL known (the `known.all()` branch: the unknown leg contributes nothing), one
+    with exactly ONE unknown (the 0-d `squeeze()` index) and one with no known detection -- kept lists, scores, classes and the
+    [unknown..., known...] order against the oracle, bit for bit on indices."""
+    cfg = dict(O.VOC_COCO_CFG)
+    w = torch.zeros(21, 256)
+    for k in range(20):
+        w[k, k] = 10.0
+    p = {"roi_heads.softmaxcls.cls_score.weight": w, "roi_heads.softmaxcls.cls_score.bias": torch.zeros(21)}
+    boxes = torch.tensor([[10.0, 10.0, 50.0, 50.0], [60.0, 60.0, 90.0, 90.0], [12.0, 12.0, 52.0, 52.0]])
+    scores = torch.tensor([0.9, 0.8, 0.7])
+    rec = torch.zeros(3, 256)
+    rec[0, 4] = 1.0
+    rec[1, 7] = 1.0
+    rec[2, 4] = 1.0
+    cases = [torch.tensor([4, 7, 4]), torch.tensor([4, 80, 4]), torch.tensor([80, 80, 80])]
+    n, seg = len(cases), 8
+    det_boxes = torch.zeros(n, seg, 4)
+    det_scores = torch.zeros(n, seg)
+    pred_cls = torch.full((n, seg), -1, dtype=torch.int64)
+    logits = torch.zeros(n, seg, 21)
+    refs = []
+    for i, cls in enumerate(cases):
+        det_boxes[i, :3], det_scores[i, :3], pred_cls[i, :3] = boxes, scores, cls
+        logits[i, :3] = F.linear(rec, w)
+        refs.append(O.softmax_classifier_inference(boxes, scores, cls, rec, (100, 100), p, cfg))
+    cnt = torch.tensor([3] * n, dtype=torch.int32)
+    cands = ops.softmax_candidates(logits.view(-1, 21).to(DEV), 20, det_boxes.view(-1, 4).to(DEV), det_scores.view(-1).to(DEV),
+                                   pred_cls.view(-1).to(DEV), cnt.to(DEV), n, seg, 80, cfg["known_score_thresh"], cfg["unknown_score_thresh"])
+    assert cands["u_count"].cpu().tolist() == [0, 1, 3]
+    kk, kc = ops.nms_topk(cands["k_boxes"], cands["k_scores"], cands["k_cls"], None, n, seg * 20, cands["k_count"], cfg["known_nms_thresh"],
+                          cfg["known_topk"])
+    uk, uc = ops.nms_topk(cands["u_boxes"], cands["u_scores"], None, None, n, seg, cands["u_count"], cfg["unknown_nms_thresh"],
+                          cfg["unknown_topk"])
+    ob, osc, ocl, on = ops.assemble_detections(cands, kk, kc, uk, uc, n, 80)
+    assert on.cpu().tolist() == [2, 2, 2]
+    for i in range(n):
+        rb, rs, rc = refs[i]
+        c = int(on[i])
+        assert c == len(rb) and torch.equal(ocl[i, :c].cpu(), rc), (i, ocl[i, :c].cpu(), rc)
+        assert_close(osc[i, :c], rs, rtol=1e-6, atol=1e-7, name="scores")
+        assert torch.equal(ob[i, :c].cpu(), rb)
+    assert ocl[0, :2].cpu().tolist() == [4, 7] and ocl[1, :2].cpu().tolist() == [80, 4] and ocl[2, :2].cpu().tolist() == [80, 80]
+    # PLN: exactly one unknown / none / a single unknown detection
+    protos = torch.eye(20, 256)
+    f = torch.zeros(3, 256)
+    f[0, 2] = 1.0
+    f[1, 9] = 4.0
+    f[2, 200] = 1.0
+    assert ops.pln_tail(f.to(DEV), protos.to(DEV), 20, 1, 0.23, 80)[0].cpu().tolist() == [2, 9, 80]
+    assert ops.pln_tail(f[:2].contiguous().to(DEV), protos.to(DEV), 20, 1, 0.23, 80)[0].cpu().tolist() == [2, 9]
+    assert ops.pln_tail(f[2:].contiguous().to(DEV), protos.to(DEV), 20, 1, 0.23, 80)[0].cpu().tolist() == [80]
+    cm = torch.arange(100, 120, dtype=torch.int64)
+    assert ops.pln_tail(f.to(DEV), protos.to(DEV), 20, 1, 0.23, 1000, class_map=cm.to(DEV))[0].cpu().tolist() == [102, 109, 1000]
+
+
 def test_cfrpn_head_fused_matches_two_step_and_oracle(ops):
     """Fused ClsFreeRPNHead level (one launch) == conv + tail (two launches) == oracle on fp16-rounded operands."""
     gg = g(51)

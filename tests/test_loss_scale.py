@@ -1,0 +1,59 @@
+"""Host half of the fp16 overflow guard (openset_rcnn_amd.host.train.DynamicLossScale): every update's verdict is applied, in
+order, however late it is polled; the scale grows back after a run of clean updates. CPU: the device flag is a CPU tensor."""
+import torch
+
+
+def _flag(ok: bool) -> torch.Tensor:
+    return torch.tensor([1 if ok else 0], dtype=torch.int32)
+
+
+def test_no_verdict_is_lost_when_the_host_runs_ahead(osr):
+    from openset_rcnn_amd.host.train import DynamicLossScale
+    sc = DynamicLossScale(1024.0, growth_interval=0)
+    # two updates issued back to back, polled only afterwards: the first one overflowed, the second did not. A single shared
+    # host flag (round 2) would have been overwritten by the second update and the overflow would never have been seen.
+    sc.record(_flag(False))
+    sc.record(_flag(True))
+    assert sc.poll() is True
+    assert sc.scale == 512.0 and sc.overflow_steps == 1 and sc.clean_steps == 1
+    assert sc.poll() is False and sc.scale == 512.0  # reported once
+    # three more, two of them poisoned
+    for ok in (False, True, False):
+        sc.record(_flag(ok))
+    assert sc.poll(wait=True) is True and sc.scale == 128.0 and sc.overflow_steps == 3
+    # the pinned slots are recycled, not re-allocated per update
+    assert len(sc.free) == 3 and not sc.queue
+
+
+def test_scale_grows_back_after_clean_updates_and_stops_at_the_configured_scale(osr):
+    from openset_rcnn_amd.host.train import DynamicLossScale
+    sc = DynamicLossScale(1024.0, growth_interval=4)
+    sc.record(_flag(False))
+    sc.record(_flag(False))
+    sc.poll()
+    assert sc.scale == 256.0
+    for _ in range(3):
+        sc.record(_flag(True))
+    sc.poll()
+    assert sc.scale == 256.0 and sc.clean_steps == 3
+    sc.record(_flag(True))
+    sc.poll()
+    assert sc.scale == 512.0 and sc.clean_steps == 0
+    for _ in range(12):
+        sc.record(_flag(True))
+    sc.poll()
+    assert sc.scale == 1024.0  # never past the configured scale
+    # an overflow in the middle of a clean run restarts the count
+    for ok in (True, True, True, False, True):
+        sc.record(_flag(ok))
+    sc.poll()
+    assert sc.scale == 512.0 and sc.clean_steps == 1
+
+
+def test_floor_of_the_scale(osr):
+    from openset_rcnn_amd.host.train import DynamicLossScale
+    sc = DynamicLossScale(2.0, growth_interval=0)
+    for _ in range(3):
+        sc.record(_flag(False))
+    sc.poll()
+    assert sc.scale == 1.0 and sc.overflow_steps == 3

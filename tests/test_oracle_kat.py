@@ -389,3 +389,58 @@ def test_box_pln_ce_loss_kats():
     _, _, loss = O.pln_loss(feats, torch.tensor([0, 81]), torch.tensor([0.9, 0.9]), p, alpha=0.1, beta=1.5, loss_weight=2.0, num_known=3)
     # row 0: relu(0-.1)=0 + relu(1.5-1)=.5 ; prototypes: 3 * relu(1.6-1)=1.8 ; * 2 / 2 rows
     assert float(loss) == pytest.approx((0.5 + 1.8) * 2.0 / 2, rel=1e-6)
+
+
+# (ix) branches of the inference tail the reference text fixes ---------------------------------
+def test_pln_inference_single_and_zero_unknown_edges():
+    """prototype_learning_network.py:218-222: `unknown = (min_dist > thr).nonzero().squeeze()` is a 0-d index when exactly one
+    detection is unknown and an empty one when none is; `min_index[unknown] = 80` must then change exactly one / no entry."""
+    p = _pln_params()
+    f = torch.zeros(3, 256)
+    f[0, 2] = 1.0
+    f[1, 9] = 4.0
+    f[2, 200] = 1.0  # orthogonal to every prototype: the ONLY unknown
+    cls, _, md, _ = O.pln_inference(f, p, unk_thr=0.23, unknown_id=80)
+    assert cls.tolist() == [2, 9, 80] and md.tolist() == pytest.approx([0.0, 0.0, 1.0], abs=1e-6)
+    cls0, _, _, _ = O.pln_inference(f[:2], p, unk_thr=0.23, unknown_id=80)  # no unknown at all
+    assert cls0.tolist() == [2, 9]
+    cls1, _, _, _ = O.pln_inference(f[2:], p, unk_thr=0.23, unknown_id=80)  # a single detection, unknown
+    assert cls1.tolist() == [80]
+    # GraspNet form (:221-222): class_id maps the prototype index first, THEN the unknown entries are overwritten with 1000
+    class_id = torch.arange(100, 120)
+    cg, _, _, _ = O.pln_inference(f, p, unk_thr=0.23, unknown_id=1000, class_id=class_id)
+    assert cg.tolist() == [102, 109, 1000]
+
+
+def _cls_params(num_known=20, fdim=256):
+    w = torch.zeros(num_known + 1, fdim)
+    for k in range(num_known):
+        w[k, k] = 10.0  # feature k lights up class k
+    return {"roi_heads.softmaxcls.cls_score.weight": w, "roi_heads.softmaxcls.cls_score.bias": torch.zeros(num_known + 1)}
+
+
+def test_softmax_classifier_all_known_and_all_unknown_branches():
+    """softmax_classifier.py:317-344: with every detection known (`known.all()`) the result is the known leg alone -- no unknown
+    call, no concatenation; with unknowns present the order is [unknown..., known...]; with NO known detection the known leg
+    runs on an empty set and contributes nothing."""
+    p = _cls_params()
+    cfg = dict(O.VOC_COCO_CFG)
+    boxes = torch.tensor([[10.0, 10.0, 50.0, 50.0], [60.0, 60.0, 90.0, 90.0], [12.0, 12.0, 52.0, 52.0]])
+    scores = torch.tensor([0.9, 0.8, 0.7])
+    rec = torch.zeros(3, 256)
+    rec[0, 4] = 1.0
+    rec[1, 7] = 1.0
+    rec[2, 4] = 1.0
+    # (a) all known: box 2 overlaps box 0 (IoU 0.82) in the same class 4 -> suppressed by the per-class NMS; classes 4 and 7 survive
+    kb, ks, kc = O.softmax_classifier_inference(boxes, scores, torch.tensor([4, 7, 4]), rec, (100, 100), p, cfg)
+    pk = float(torch.softmax(torch.tensor([10.0] + [0.0] * 20), 0)[0])
+    assert sorted(kc.tolist()) == [4, 7] and len(kb) == 2
+    assert ks.tolist() == pytest.approx([pk, pk], rel=1e-6)
+    assert not (kc == 80).any()
+    # (b) one unknown in the middle: it comes FIRST in the output, with its objectness score, then the known ones
+    ob, os_, oc = O.softmax_classifier_inference(boxes, scores, torch.tensor([4, 80, 4]), rec, (100, 100), p, cfg)
+    assert oc.tolist() == [80, 4] and os_.tolist() == pytest.approx([0.8, pk], rel=1e-6)
+    assert ob[0].tolist() == [60.0, 60.0, 90.0, 90.0]
+    # (c) nothing known: only the class-agnostic leg; boxes 0 and 2 overlap -> the lower-scored one is suppressed
+    ub, us, uc = O.softmax_classifier_inference(boxes, scores, torch.tensor([80, 80, 80]), rec, (100, 100), p, cfg)
+    assert uc.tolist() == [80, 80] and us.tolist() == pytest.approx([0.9, 0.8])

@@ -207,3 +207,23 @@ def test_overflow_guard_skips_the_update_and_halves_the_scale(osr):
     snap = tr.master["fc2.w"].clone()
     tr._update(1)
     assert tr.poll_overflow(wait=True) is True and tr.loss_scale == 256.0 and torch.equal(tr.master["fc2.w"], snap)
+
+
+def test_back_to_back_steps_keep_every_overflow_verdict(osr):
+    """with step() called in a loop the host runs ahead of the GPU; every update's verdict must still be applied.
+    A loss scale of 2^40 overflows the fp16 activation gradients of every iteration: two steps issued back to back without any
+    host sync in between, polled afterwards -> two skipped updates, scale quartered, parameters untouched."""
+    from openset_rcnn_amd.host import modeling as M
+    cfg = _cfg(osr)
+    torch.manual_seed(0)
+    model = M.build_model(cfg)
+    tr = model.make_trainer(lr=1e-4, loss_scale=float(2 ** 40))
+    data = _data(list(range(20)))
+    tensors = model._train_tensors(data, torch.Generator().manual_seed(1))
+    torch.cuda.synchronize()
+    before = {k: v.clone() for k, v in tr.master.items()}
+    tr.step(*tensors)
+    tr.step(*tensors)  # (its own poll at the top may or may not see the first verdict yet: either way nothing may be lost)
+    assert tr.poll_overflow(wait=True) in (True, False)
+    assert tr.overflow_steps == 2 and tr.loss_scale == float(2 ** 38)
+    assert all(torch.equal(v, before[k]) for k, v in tr.master.items())
