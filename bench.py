@@ -418,10 +418,10 @@ def main(argv=None) -> int:
         # (the tile model's concurrency hint: how many launch streams share the GPU -- lanes x micro-batch streams)
         with _ops.concurrent_streams(npass if args.lane_hint else 1):
             torch.cuda.synchronize()
-            mem0 = torch.cuda.memory_allocated(dev)
+            mem0 = torch.cuda.memory_reserved(dev)
             graph, gout = eng.capture(images, image_hw, 800, 1344, args.streams)
             torch.cuda.synchronize()
-            lane_gb = (torch.cuda.memory_allocated(dev) - mem0 + images.numel()) / 1e9  # one lane: its graph's private pool + its images
+            lane_gb = (torch.cuda.memory_reserved(dev) - mem0 + images.numel()) / 1e9  # one lane: its graph's private pool + its images
             lanes = [(graph, gout, torch.cuda.Stream(device=dev))]
             lane_images = [images]
             for li in range(1, npass):  # every lane has its own batch of images (and, through its capture, its own activations and outputs)

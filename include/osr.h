@@ -109,6 +109,28 @@ osr_status osr_conv2d_fwd(const osr_conv_params* p, const void* in, const void* 
 osr_status osr_conv2d_fwd_masked(const osr_conv_params* p, const void* in, const void* weight, const float* bias,
                                  const void* residual, const void* mask, void* out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * One whole ResNet bottleneck block in ONE launch: y = relu(conv3(relu(conv2(relu(conv1(x))))) + shortcut(x)),
+ * 1x1 -> 3x3 (pad 1) -> 1x1, stride 1, FrozenBN folded into weights / biases ([d2] BottleneckBlock.forward, built by
+ * build_resnet_fpn_backbone for /root/reference/configs/Base-RCNN-FPN.yaml:3-8). The two cmid-channel intermediates never
+ * leave the chip: the block reads x once and writes y once (the three separate convolutions of a res2 block are HBM-bound
+ * and move twice the bytes). Fused shapes: the res2 blocks -- cmid 64, cout 256, and either cin 256 with the identity
+ * shortcut (has_proj 0) or cin 64 with a 1x1 projection shortcut wsc / bsc (has_proj 1). Anything else returns
+ * OSR_ERR_UNSUPPORTED with nothing launched: run osr_conv2d_fwd three (four) times instead.
+ * in (n,h,w,cin), out (n,h,w,cout) NHWC contiguous, dtype f16/bf16; weights packed [cout][kh][kw][cin] in the same dtype,
+ * biases fp32. Same K order and the same rounding points as the separate launches; with has_proj the shortcut's output
+ * is accumulated in fp32 with conv3 instead of being rounded to the storage dtype first (one rounding fewer).
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct osr_bottleneck_params {
+    int32_t n, h, w;
+    int32_t cin, cmid, cout;
+    int32_t dtype;    /* osr_dtype of in, out and the weights */
+    int32_t has_proj; /* 1: projection shortcut (wsc, bsc); 0: identity (cin == cout) */
+} osr_bottleneck_params;
+osr_status osr_bottleneck_fwd(const osr_bottleneck_params* p, const void* in, const void* w1, const float* b1,
+                              const void* w2, const float* b2, const void* w3, const float* b3, const void* wsc,
+                              const float* bsc, void* out, void* stream);
+
 /* [d2] F.max_pool2d(k=3,s=2,p=1) of the ResNet stem, NHWC contiguous. */
 osr_status osr_maxpool3x3s2(const void* in, int32_t n, int32_t hi, int32_t wi, int32_t c, void* out, int32_t dtype,
                             void* stream);

@@ -23,6 +23,7 @@ SOURCES = {
     "osr_conv_gemm.hip": [],
     "osr_conv_gemm64.hip": [],
     "osr_conv_f32.hip": [],
+    "osr_bottleneck.hip": [],
     "osr_rpn.hip": ["-ffp-contract=off"],
     "osr_roi_align.hip": ["-ffp-contract=off"],
     "osr_det_tail.hip": ["-ffp-contract=off"],

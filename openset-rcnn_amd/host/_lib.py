@@ -38,6 +38,11 @@ class ConvParams(C.Structure):
     ]
 
 
+class BottleneckParams(C.Structure):
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin", C.c_int32), ("cmid", C.c_int32), ("cout", C.c_int32),
+                ("dtype", C.c_int32), ("has_proj", C.c_int32)]
+
+
 class LossOptions(C.Structure):
     _fields_ = [("box_loss_type", C.c_int32), ("box_smooth_l1_beta", C.c_float), ("aux_smooth_l1_beta", C.c_float)]
 
@@ -75,6 +80,7 @@ PROTOTYPES = {
     "osr_conv2d_fwd_workspace_bytes": (I64, [C.POINTER(ConvParams)]),
     "osr_conv2d_fwd_describe": (I32, [C.POINTER(ConvParams), I32, P, I32]),
     "osr_conv2d_fwd_masked": (I32, [C.POINTER(ConvParams), P, P, P, P, P, P, P]),
+    "osr_bottleneck_fwd": (I32, [C.POINTER(BottleneckParams), P, P, P, P, P, P, P, P, P, P, P]),
     "osr_maxpool3x3s2": (I32, [P, I32, I32, I32, I32, P, I32, P]),
     "osr_subsample2": (I32, [P, I32, I32, I32, I32, P, I32, P]),
     "osr_gemm_f32": (I32, [P, I64, P, P, P, I64, I32, I32, I32, I32, P]),

@@ -111,6 +111,8 @@ class OpensetRCNNEngine:
         # the box head's FC layers skip the tiles that hold only padding rows of the per-image proposal lists (fp16 / bf16 kernels;
         # the fp32 parity kernel computes every row)
         self.skip_padding_tiles = dtype != torch.float32
+        # the three (four) convolutions of a res2 block run as ONE launch (osr_bottleneck_fwd): fp16 / bf16 storage only
+        self.fuse_res2 = dtype != torch.float32
         self._init_rpn(params)
         self._init_roi_heads(params)
 
@@ -182,6 +184,30 @@ class OpensetRCNNEngine:
         self.profile.append((name, flops, e0, e1, nbytes, flops))
         return y
 
+    def _bottleneck(self, x, pre: str, first: bool, stride: int = 1):
+        """One [d2] BottleneckBlock (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + shortcut, ReLU after each). res2's blocks run as one
+        fused launch when the engine allows it (the intermediates never reach HBM); everything else as separate launches."""
+        w = self.w
+        if self.fuse_res2 and stride == 1 and w[pre + ".conv1.w"].shape[0] == 64:
+            if self.profile is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            y = ops.bottleneck(x, w[pre + ".conv1.w"], w[pre + ".conv1.b"], w[pre + ".conv2.w"], w[pre + ".conv2.b"], w[pre + ".conv3.w"],
+                               w[pre + ".conv3.b"], w[pre + ".shortcut.w"] if first else None, w[pre + ".shortcut.b"] if first else None)
+            if y is not None:
+                if self.profile is not None:
+                    e1.record()
+                    names = ["conv1", "conv2", "conv3"] + (["shortcut"] if first else [])
+                    px = y.numel() // y.shape[-1]
+                    flops = sum(2.0 * px * w[f"{pre}.{c}.w"].numel() for c in names)
+                    nbytes = x.numel() * x.element_size() + y.numel() * y.element_size() + sum(w[f"{pre}.{c}.w"].numel() for c in names) * x.element_size()
+                    self.profile.append((pre + " (fused block)", flops, e0, e1, nbytes, flops))
+                return y
+        sc = self._conv(x, pre + ".shortcut", stride) if first else x
+        o = self._conv(x, pre + ".conv1", stride, relu=True)
+        o = self._conv(o, pre + ".conv2", 1, 1, relu=True)
+        return self._conv(o, pre + ".conv3", relu=True, residual=sc, res_mode=1)
+
     def _linear(self, x, w, b, relu, out_dtype=None, name="fc", row_seg=None, real_rows=None):
         """real_rows (profiling only): how many of x's rows carry data. The padding rows of the per-image proposal lists are not
         algorithmic work: FLOPs and bytes are credited for the real rows only, the nominal figure (all rows of the
@@ -219,10 +245,7 @@ class OpensetRCNNEngine:
             for b in range(nb):
                 pre = f"backbone.bottom_up.res{si + 2}.{b}"
                 stride = 2 if (b == 0 and si > 0) else 1  # MSRA: stride in the first 1x1
-                sc = self._conv(x, pre + ".shortcut", stride) if b == 0 else x
-                o = self._conv(x, pre + ".conv1", stride, relu=True)
-                o = self._conv(o, pre + ".conv2", 1, 1, relu=True)
-                x = self._conv(o, pre + ".conv3", relu=True, residual=sc, res_mode=1)
+                x = self._bottleneck(x, pre, b == 0, stride)
             feats[f"res{si + 2}"] = x
         out = {}
         prev = self._conv(feats["res5"], "backbone.fpn_lateral5")

@@ -189,6 +189,39 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, relu: bool
     return y.view(m, weight.shape[0])
 
 
+def bottleneck(x: torch.Tensor, w1, b1, w2, b2, w3, b3, wsc=None, bsc=None) -> Optional[torch.Tensor]:
+    """One whole bottleneck block in one launch (osr_bottleneck_fwd): x (n,h,w,cin) f16/bf16, weights packed (cout,kh,kw,cin) in
+    x's dtype, biases fp32; wsc / bsc = the projection shortcut (None: identity). Returns y (n,h,w,cout), or None when the shape
+    is outside the fused kernel's envelope (the caller then runs the separate convolutions)."""
+    lib = _lib.load()
+    _need(x, name="x")
+    if x.dtype not in (torch.float16, torch.bfloat16):
+        return None
+    n, h, w, cin = x.shape
+    cmid, cout = w1.shape[0], w3.shape[0]
+    for t, nm in ((w1, "w1"), (w2, "w2"), (w3, "w3")):
+        _need(t, x.dtype, nm)
+    for t, nm in ((b1, "b1"), (b2, "b2"), (b3, "b3")):
+        _need(t, torch.float32, nm)
+    if tuple(w1.shape) != (cmid, 1, 1, cin) or tuple(w2.shape) != (cmid, 3, 3, cmid) or tuple(w3.shape) != (cout, 1, 1, cmid):
+        raise OsrError("bottleneck: weight shapes do not form a 1x1 -> 3x3 -> 1x1 block")
+    p = _lib.BottleneckParams()
+    p.n, p.h, p.w, p.cin, p.cmid, p.cout = n, h, w, cin, cmid, cout
+    p.dtype, p.has_proj = _DT[x.dtype], int(wsc is not None)
+    if wsc is not None:
+        _need(wsc, x.dtype, "wsc"); _need(bsc, torch.float32, "bsc")
+        if tuple(wsc.shape) != (cout, 1, 1, cin):
+            raise OsrError("bottleneck: projection weight shape")
+    out = torch.empty((n, h, w, cout), dtype=x.dtype, device=x.device)
+    st = lib.osr_bottleneck_fwd(C.byref(p), _p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(wsc), _p(bsc), _p(out), _stream())
+    if st == _lib.ERR_UNSUPPORTED:
+        return None
+    check(st, "osr_bottleneck_fwd")
+    if FLOP_COUNT is not None:
+        FLOP_COUNT["conv"] += 2.0 * n * h * w * (cin * cmid + 9 * cmid * cmid + cmid * cout + (cin * cout if wsc is not None else 0))
+    return out
+
+
 def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     _need(x, name="x")

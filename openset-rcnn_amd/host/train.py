@@ -263,12 +263,14 @@ class OpensetRCNNTrainer:
             for b in range(nb):
                 pre = f"backbone.bottom_up.res{si + 2}.{b}"
                 stride = 2 if (b == 0 and si > 0) else 1
+                if si + 2 <= self.freeze_at:  # frozen stage: nothing of the block is needed by the backward (res2: one fused launch)
+                    x = e._bottleneck(x, pre, b == 0, stride)
+                    continue
                 sc = e._conv(x, pre + ".shortcut", stride) if b == 0 else x
                 o1 = e._conv(x, pre + ".conv1", stride, relu=True)
                 o2 = e._conv(o1, pre + ".conv2", 1, 1, relu=True)
                 y = e._conv(o2, pre + ".conv3", relu=True, residual=sc, res_mode=1)
-                if si + 2 > self.freeze_at:
-                    blocks.append(dict(pre=pre, x=x, o1=o1, o2=o2, y=y, stride=stride, first=b == 0, stage=si + 2))
+                blocks.append(dict(pre=pre, x=x, o1=o1, o2=o2, y=y, stride=stride, first=b == 0, stage=si + 2))
                 x = y
             feats[f"res{si + 2}"] = x
         s["blocks"], s["res"] = blocks, feats
