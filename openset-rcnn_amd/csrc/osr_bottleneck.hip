@@ -227,11 +227,16 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(BnArgs a) {
             for (int T = 0; T < 4; ++T) acc[j][T] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            // tap `tap` has landed for this wave when at most the pieces of the taps issued after it are outstanding
-            if (tap <= 6) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (tap == 7) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // ... and for every wave; every wave has also finished reading tap - 1's slot
+            // RAW: tap `tap` has landed for this wave when at most the pieces of the taps issued after it are outstanding (counted
+            // vmcnt), and for every wave behind the barrier. WAR: the slot restaged below, (tap + 3) & 3, is the one tap - 1 was read
+            // from -- the compiler rotates the loop, so a wave's last fragment reads of tap - 1 are issued just in front of this
+            // barrier and may still be IN FLIGHT when it arrives: lgkmcnt(0) retires them first. Without it another wave's LDS-DMA
+            // could land in the slot before a queued ds_read had been served -- seen as one wrong tile in a few thousand, and only in
+            // the first launches after the GPU had idled (at a low shader clock the DMA's latency shrinks in shader cycles).
+            // Wait and barrier are ONE asm statement: s_barrier alone is no compiler barrier for memory operations.
+            if (tap <= 6) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (tap == 7) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (tap + 3 < 9) BN_STAGE_TAP(tap + 3);
             const int ky = tap / 3, kx = tap - ky * 3;
             const unsigned char* wb = lds + BN_WBUF + (tap & 3) * 8192;

@@ -121,3 +121,44 @@ def test_engine_uses_the_fused_block_and_agrees_with_the_unfused_engine(osr):
     for k in ("p2", "p3", "p4", "p5"):
         fa, fb = keep_f["feats"][k].float(), keep_u["feats"][k].float()
         assert float((fa - fb).abs().max()) <= 2e-2 * float(fb.abs().max()), k
+
+
+def test_fused_blocks_in_a_chain_between_other_launches_are_exact(ops, osr):
+    """Regression test of a write-after-read race in the conv2 tap ring (round 3): a wave's last fragment reads of a weight slot
+    could still be in flight when another wave's LDS-DMA for the tap three ahead landed in that slot. It showed as one wrong tile
+    in a few thousand, only when the fused launches ran between launches of OTHER kernels and batch sizes (steady-state
+    back-to-back launches of the same kernel never showed it). The scenario that reproduced it six times in thirty chains: unfused
+    chains of 8, 8, 5 and 3 images, then the fused res2 chain; the identity blocks must reproduce the separate launches bit for
+    bit on their own inputs, every time."""
+    from openset_rcnn_amd.host.engine import OpensetRCNNEngine
+    from openset_rcnn_amd.host.weights import random_params
+    n, h, w = 8, 750, 1333
+    g = torch.Generator().manual_seed(21)
+    images = torch.randint(0, 256, (n, 3, h, w), generator=g, dtype=torch.uint8).to(DEV)
+    eng = OpensetRCNNEngine(random_params(0), None, torch.float16, DEV)
+    c = eng.cfg
+
+    def front(imgs, fused):
+        eng.fuse_res2 = fused
+        xpad = ops.preprocess(imgs, 768, 1344, c["pixel_mean"], c["pixel_std"], eng.dtype)
+        x = ops.stem_conv(xpad, eng.w["backbone.bottom_up.stem.conv1.w"], eng.w["backbone.bottom_up.stem.conv1.b"], 768, 1344, relu=True)
+        x = ops.maxpool3x3s2(x)
+        outs = [x]
+        for b in range(3):
+            x = eng._bottleneck(x, f"backbone.bottom_up.res2.{b}", b == 0, 1)
+            outs.append(x)
+        torch.cuda.synchronize()
+        return outs
+
+    for rep in range(4):
+        for nn in (8, 8, 5, 3):
+            front(images[:nn], False)
+        runs = [front(images, True), front(images, True), front(images[:5], True), front(images[5:], True), front(images, True)]
+        eng.fuse_res2 = False
+        for o in runs:
+            for b in (1, 2):
+                want = eng._bottleneck(o[b], f"backbone.bottom_up.res2.{b}", False, 1)
+                assert torch.equal(o[b + 1], want), (rep, b, int((o[b + 1] != want).sum()))
+        assert all(torch.equal(u, v) for u, v in zip(runs[0], runs[1])) and all(torch.equal(u, v) for u, v in zip(runs[0], runs[4]))
+        del runs
+        torch.cuda.empty_cache()
