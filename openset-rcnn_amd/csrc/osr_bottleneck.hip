@@ -16,6 +16,14 @@
 //   3. conv3 (+ projection): each wave owns 64 of the 256 output channels; its weight fragments come from global memory once
 //      and stay in registers; pixels from mid2 (and, for the projection, x's centre pixels from global memory as extra K).
 //      bias, identity residual (the same address as the store), ReLU, 16-byte stores.
+// What bounds it (round 3, profiles/r03_bottleneck_*.txt): not HBM (1.1-1.7 GB per block at 3.3 TB/s), not the matrix cores (23 %
+// busy) -- the per-CU fill rate of the vector memory pipe. A tile moves 360 KB through it (halo pixels 96 KB, residual 64 KB,
+// weights 136 KB, stores 64 KB); at the 23-70 GB/s a CU draws from HBM / Infinity Cache / L2 (MI355X_MICROARCH.md, indexed rows)
+// that is ~10 us per tile and CU = 335 us per block, which is what it takes. Re-arrangements that only move waiting around
+// measured the same or worse (all loads of conv3 requested under conv2; a channel-split barrier-free conv2: twice the LDS
+// reads; persistent workgroups that stage the next tile's w1 and request its pixels under conv3: entry 6.9 -> 1.4 us per tile,
+// conv2 / conv3 longer by as much). What would help is fewer bytes per pixel: 16 x 16 tiles (weights per pixel halved, halo 1.27x
+// instead of 1.41x) and the residual taken from conv1's fragments instead of a second read.
 // The MFMA operand roles are SWAPPED against osr_conv_gemm64.hip (weights = A, pixels = B): D = W . X^T puts four consecutive
 // output channels of one pixel into each lane, and with the row permutation below two MFMAs give a lane eight consecutive
 // channels = one 16-byte chunk -- LDS writes (ds_write_b128) and global stores need no transposition through LDS.
@@ -48,7 +56,20 @@ struct BnArgs {
     int n, h, w;
     int tiles_y, tiles_x;
     unsigned x_bytes, y_bytes, w1_bytes, w2_bytes, w3_bytes, wsc_bytes;
+#ifdef BN_STAMPS
+    unsigned long long* dbg;
+#endif
 };
+
+// Diagnostic build only (-DBN_STAMPS, never shipped; scripts/exp_bottleneck_stamps.py): wave 0 of every workgroup records
+// s_memrealtime (100 MHz) at entry, when conv1 may start, after conv1, after conv2, after conv3 and when its stores have drained.
+#ifdef BN_STAMPS
+static unsigned long long* g_bn_stamps = nullptr;
+extern "C" void osr_debug_set_bn_stamps(unsigned long long* p) { g_bn_stamps = p; }
+#define BN_STAMP(i) if (a.dbg && tid == 0) a.dbg[(long long)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define BN_STAMP(i)
+#endif
 
 #define BN_TH 8
 #define BN_TW 16
@@ -87,6 +108,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(BnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
+    BN_STAMP(0);
 
     // XCD-aware bijective remap of the linear block id: an XCD walks a contiguous run of tiles (row-major inside an image), so the
     // halo pixels a tile shares with its neighbours are fetched into one L2
@@ -147,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(BnArgs a) {
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (w1's LDS-DMA pieces of this wave; the pixel loads with them)
     __syncthreads();
+    BN_STAMP(1);
 
     // swizzled byte offset of this lane's 16-byte read of LDS row `row`, logical chunk `chunk` (rows of 128 B)
 #define BN_SW(row, chunk) ((row) * 128 + ((((chunk)) ^ (((row) >> 1) & 7)) << 4))
@@ -188,6 +211,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(BnArgs a) {
         }
     }
     __syncthreads();  // mid1 complete; every wave is done with w1
+    BN_STAMP(2);
 
     // ---- conv3's weight fragments: global -> registers, in flight under conv2 (this wave's 64 output channels) ----
     frag_t w3f[4][2];
@@ -272,6 +296,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(BnArgs a) {
         }
     }
     __syncthreads();  // mid2 complete
+    BN_STAMP(3);
 
     // ---- 3. conv3 (+ projection) for this wave's 64 channels, 32 pixels (two output rows) at a time ----
     const float* s_b3 = reinterpret_cast<const float*>(lds + BN_BIAS) + 128 + wid * 64;
@@ -343,6 +368,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(BnArgs a) {
                 __builtin_amdgcn_raw_buffer_store_b128(cv.u, rs_y, ooff[cur][j] == BN_OOB ? BN_OOB : ooff[cur][j] + (unsigned)((wid * 64 + 32 * p + 8 * g) * 2), 0, 0);
             }
     }
+    BN_STAMP(4);
+#ifdef BN_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (stamp 5: this wave's stores have left the CU)
+    BN_STAMP(5);
+#endif
 }
 
 template <class TI>
@@ -381,6 +411,9 @@ extern "C" osr_status osr_bottleneck_fwd(const osr_bottleneck_params* p, const v
     a.x = in; a.y = out; a.w1 = w1; a.w2 = w2; a.w3 = w3; a.wsc = wsc; a.b1 = b1; a.b2 = b2; a.b3 = b3; a.bsc = bsc;
     a.n = p->n; a.h = p->h; a.w = p->w;
     a.tiles_y = (p->h + BN_TH - 1) / BN_TH; a.tiles_x = (p->w + BN_TW - 1) / BN_TW;
+#ifdef BN_STAMPS
+    a.dbg = g_bn_stamps;
+#endif
     a.x_bytes = (unsigned)xb; a.y_bytes = (unsigned)yb;
     a.w1_bytes = (unsigned)(64 * p->cin * 2); a.w2_bytes = 64 * 9 * 64 * 2; a.w3_bytes = 256 * 64 * 2; a.wsc_bytes = (unsigned)(256 * p->cin * 2);
     OSR_REQUIRE((long long)a.n * a.tiles_y * a.tiles_x < (1ll << 31), OSR_ERR_UNSUPPORTED, "osr_bottleneck_fwd: too many tiles");
