@@ -155,7 +155,7 @@ def measure_traffic(timeout_s: int = 150):
                 d = os.path.join(tmp, counter)
                 cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "run", "--", sys.executable,
                        os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--no-train-step", "--no-pmc",
-                       "--no-parity", "--streams", "1", "--no-graph"]
+                       "--no-parity", "--no-pcie", "--streams", "1", "--no-graph"]
                 env = dict(os.environ, TMPDIR="/tmp")
                 # a session of its own: on a time-out the WHOLE group is killed (rocprofv3 and the profiled python under it) and
                 # waited for, so that nothing of it still runs on the GPU beside the legs that follow
@@ -265,7 +265,7 @@ def train_step_child(args) -> dict:
     against 35.1 ms; likewise with GPU_MAX_HW_QUEUES raised: every hardware queue a process has used stays in the command
     processor's rotation), and run first it cost the inference loop 2.5 %. The child rebuilds the same weights (same seeds)."""
     cmd = [sys.executable, os.path.abspath(__file__), "--train-only", "--train-steps", str(args.train_steps), "--dtype", args.dtype, "--batch", str(args.batch),
-           "--no-cpu-baseline", "--no-pmc", "--no-parity"]
+           "--no-cpu-baseline", "--no-pmc", "--no-parity", "--no-pcie"]
     try:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=os.path.dirname(os.path.abspath(__file__)))
         last = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
@@ -274,6 +274,45 @@ def train_step_child(args) -> dict:
         return json.loads(last[-1])
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)[:300]}
+
+
+def pcie_leg(lanes, dev, batch: int, steps: int, warm: int = 2):
+    """The PCIe-inclusive rate: every step's 16 frames start in HOST memory as decoded 600x1000x3 uint8 images, go through a pinned
+    staging buffer and an asynchronous H2D copy on a copy stream, are resized ON THE DEVICE to 800x1333 (osr_resize_bilinear_u8:
+    Pillow's BILINEAR, bit-exact -- what [d2] ResizeShortestEdge does on the host in the reference's loader, train.py:129) straight
+    into a lane's input batch, and the lane's captured pass runs behind an event. Uploads / resizes of the next batch overlap the
+    passes in flight (the lanes of the headline). `value` never includes this; the boundary takes device buffers."""
+    import numpy as np
+    from openset_rcnn_amd.host.data import DeviceResizer
+    rz = DeviceResizer(dev)
+    rng = np.random.RandomState(7)
+    frames = [rng.randint(0, 256, (600, 1000, 3)).astype(np.uint8) for _ in range(batch)]
+    turn = [0]
+
+    def step():
+        g_, o_, st_, imgs_ = lanes[turn[0] % len(lanes)]
+        turn[0] += 1
+        rz.stream.wait_stream(st_)  # the lane's previous pass has read its input batch before it is overwritten
+        for i, f in enumerate(frames):
+            rz(f, (800, 1333), out=imgs_[i], wait=False)
+        st_.wait_event(rz.done)
+        with torch.cuda.stream(st_):
+            g_.replay()
+        return o_
+
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return dict(images_per_sec=round(batch * steps / el, 2), ms_per_step=round(el / steps * 1e3, 3), steps=steps, passes_in_flight=len(lanes),
+                source=f"{batch} decoded frames of 600x1000x3 uint8 in host memory per step (28.8 MB)",
+                path="host frame -> pinned staging -> async H2D (copy stream) -> osr_resize_bilinear_u8 to 3x800x1333 (Pillow BILINEAR, bit-exact) "
+                     "into the lane's input batch -> the captured pass; overlapped with the passes in flight",
+                note="single host thread fills the pinned buffers (a memcpy per frame); image decode (JPEG) is not included")
 
 
 def parity_leg(tdt, dev, images, image_hw, steps: int = 2):
@@ -338,6 +377,7 @@ def main(argv=None) -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true", help="skip the config-3 train-step leg")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure HBM traffic with rocprofv3 child passes (quote the committed profile)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg (host frames -> upload -> device resize -> pass)")
     ap.add_argument("--no-parity", action="store_true", help="skip the fast-mode-vs-fp32 agreement / parity-mode throughput leg")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--train-steps", type=int, default=5)
@@ -422,14 +462,14 @@ def main(argv=None) -> int:
             graph, gout = eng.capture(images, image_hw, 800, 1344, args.streams)
             torch.cuda.synchronize()
             lane_gb = (torch.cuda.memory_reserved(dev) - mem0 + images.numel()) / 1e9  # one lane: its graph's private pool + its images
-            lanes = [(graph, gout, torch.cuda.Stream(device=dev))]
+            lanes = [(graph, gout, torch.cuda.Stream(device=dev), images)]
             lane_images = [images]
             for li in range(1, npass):  # every lane has its own batch of images (and, through its capture, its own activations and outputs)
                 gi = torch.Generator().manual_seed(1234 + rank + 1000 * li)
                 lane_images.append(torch.randint(0, 256, (args.batch, 3, 800, 1333), generator=gi, dtype=torch.uint8).to(dev))
                 g2, o2 = eng.capture(lane_images[li], image_hw, 800, 1344, args.streams)
-                lanes.append((g2, o2, torch.cuda.Stream(device=dev)))
-        for g_, _, st_ in lanes:  # first replay of every lane's graph (one-time upload of the executable graph), untimed and outside the W warm-up steps
+                lanes.append((g2, o2, torch.cuda.Stream(device=dev), lane_images[li]))
+        for g_, _, st_, _ in lanes:  # first replay of every lane's graph (one-time upload of the executable graph), untimed and outside the W warm-up steps
             with torch.cuda.stream(st_):
                 g_.replay()
         torch.cuda.synchronize()
@@ -441,7 +481,7 @@ def main(argv=None) -> int:
                 return gout
             # several passes in flight: pass i is launched on lane i % P without waiting for pass i - 1 (its own buffers, its own
             # stream); a lane's next pass queues behind its previous one. The timed region ends with a device-wide synchronize.
-            g_, o_, st_ = lanes[turn[0] % len(lanes)]
+            g_, o_, st_, _ = lanes[turn[0] % len(lanes)]
             turn[0] += 1
             with torch.cuda.stream(st_):
                 g_.replay()
@@ -476,7 +516,7 @@ def main(argv=None) -> int:
     # ---- one pass at a time: the same K steps on lane 0 alone (its graph, its stream; 16 images in flight, as in config 2) ----
     single_pass = None
     if args.graph and len(lanes) > 1:
-        g0, o0, st0 = lanes[0]
+        g0, o0, st0, _ = lanes[0]
 
         def step_single():
             with torch.cuda.stream(st0):
@@ -486,6 +526,14 @@ def main(argv=None) -> int:
         single_pass = dict(ms_per_step=round(el1 / args.steps * 1e3, 3), images_per_sec=round(world * args.batch * args.steps / el1, 2), passes_in_flight=1,
                            note="the same captured pass, one lane, one stream: every step starts when the previous one has finished on the device queue "
                                 "(ms_per_step is then the latency of a pass)")
+
+    # ---- the same loop fed from host memory: upload + on-device resize overlapped with the passes in flight (rank 0, one GPU) ----
+    pcie = None
+    if args.graph and world == 1 and not args.no_pcie:
+        try:
+            pcie = pcie_leg(lanes, dev, args.batch, args.steps)
+        except Exception as e:  # noqa: BLE001  (reported in the line; the headline stands)
+            pcie = {"error": repr(e)[:300]}
 
     # ---- rooflines of the two kernel groups, measured live with HIP events on the launch stream ----
     # (the single-stream full-batch pass picks other tile configurations than the micro-batched one: run it once untimed so
@@ -596,6 +644,8 @@ def main(argv=None) -> int:
         }
         if single_pass is not None:
             line["single_pass"] = single_pass
+        if pcie is not None:
+            line["pcie_inclusive"] = pcie
     else:
         line = None
 

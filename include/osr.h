@@ -131,6 +131,24 @@ osr_status osr_bottleneck_fwd(const osr_bottleneck_params* p, const void* in, co
                               const void* w2, const float* b2, const void* w3, const float* b3, const void* wsc,
                               const float* bsc, void* out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * ResizeShortestEdge on the device for uint8 images: [d2] ResizeTransform.apply_image = PIL Image.resize(BILINEAR)
+ * (INPUT.MIN_SIZE_TEST / MAX_SIZE_TEST, /root/reference/configs/Base-RCNN-FPN.yaml:43; the loader the reference builds
+ * at train.py:129 does it on the host). Pillow's algorithm (Resample.c): separable triangle filter whose support grows
+ * with the down-scaling factor, horizontal pass into an 8-bit intermediate, then the vertical pass, 22-bit fixed-point
+ * coefficients. The caller computes the tables on the host from the two sizes (Pillow's precompute_coeffs +
+ * normalize_coeffs_8bpc: bounds (n,2) = first input index and tap count per output index, coef (n,k) int32); the result
+ * is the PIL image bit for bit.
+ * in: (h, w, 3) uint8 interleaved (row stride in bytes); out: (3, nh, nw) uint8 planar -- the "image" tensor of a model
+ * input dict; tmp: osr_resize_tmp_bytes(y_rows, nw) bytes, rows [y_first, y_first + y_rows) = the input rows the vertical
+ * pass reads (Pillow resamples only those horizontally).
+ * --------------------------------------------------------------------------------------------------------- */
+int64_t osr_resize_tmp_bytes(int32_t rows, int32_t nw);
+osr_status osr_resize_bilinear_u8(const uint8_t* in, int32_t h, int32_t w, int64_t in_row_stride, const int32_t* xbounds,
+                                  const int32_t* xcoef, int32_t kx, const int32_t* ybounds, const int32_t* ycoef,
+                                  int32_t ky, int32_t y_first, int32_t y_rows, int32_t nh, int32_t nw, uint8_t* tmp,
+                                  int64_t tmp_bytes, uint8_t* out, void* stream);
+
 /* [d2] F.max_pool2d(k=3,s=2,p=1) of the ResNet stem, NHWC contiguous. */
 osr_status osr_maxpool3x3s2(const void* in, int32_t n, int32_t hi, int32_t wi, int32_t c, void* out, int32_t dtype,
                             void* stream);

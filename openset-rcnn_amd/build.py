@@ -20,6 +20,7 @@ ARCH = "gfx950"
 SOURCES = {
     "osr_status.hip": [],
     "osr_preproc_pool.hip": ["-ffp-contract=off"],
+    "osr_resize.hip": [],
     "osr_conv_gemm.hip": [],
     "osr_conv_gemm64.hip": [],
     "osr_conv_f32.hip": [],

@@ -44,10 +44,131 @@ def resize_image(img: np.ndarray, new_hw: Tuple[int, int]) -> np.ndarray:
     return np.asarray(Image.fromarray(img).resize((new_hw[1], new_hw[0]), Image.BILINEAR))
 
 
+# ---- ResizeShortestEdge on the device (osr_resize_bilinear_u8): Pillow's resampling tables, computed on the host -----------------
+_PIL_PRECISION_BITS = 22  # Pillow Resample.c: 32 - 8 - 2
+
+
+def pil_resample_coeffs(in_size: int, out_size: int):
+    """Pillow's precompute_coeffs + normalize_coeffs_8bpc (src/libImaging/Resample.c) for the BILINEAR (triangle, support 1) filter
+    and the full box (0, in_size): per output index its first input index and tap count (bounds, (out,2) int32) and the taps'
+    22-bit fixed-point weights (coef, (out,ksize) int32). Python floats are C doubles, so every intermediate rounds as in C."""
+    import math
+    scale = in_size / out_size  # (in1 - in0) / outSize with in0 = 0
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    coef = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)  # (int) truncates toward zero, like C
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        k = []
+        ww = 0.0
+        for x in range(xmax):
+            t = (x + xmin - center + 0.5) * ss
+            t = -t if t < 0.0 else t
+            w = 1.0 - t if t < 1.0 else 0.0
+            k.append(w)
+            ww += w
+        for x in range(xmax):
+            v = k[x] / ww if ww != 0.0 else k[x]
+            coef[xx, x] = int(-0.5 + v * (1 << _PIL_PRECISION_BITS)) if v < 0 else int(0.5 + v * (1 << _PIL_PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return bounds, coef
+
+
+def pil_resize_emulated(img: np.ndarray, new_hw: Tuple[int, int]) -> np.ndarray:
+    """The two passes of Pillow's ImagingResample on the host in numpy integers (the CPU statement of what the device kernels do;
+    tests pin it to PIL.Image.resize bit for bit): horizontal pass over the rows the vertical pass reads, 8-bit intermediate,
+    vertical pass."""
+    h, w = img.shape[:2]
+    nh, nw = new_hw
+    xb, xc = pil_resample_coeffs(w, nw)
+    yb, yc = pil_resample_coeffs(h, nh)
+    y_first, y_last = int(yb[0, 0]), int(yb[-1, 0] + yb[-1, 1])
+    src = img[y_first:y_last].astype(np.int64)
+    half = 1 << (_PIL_PRECISION_BITS - 1)
+    tmp = np.empty((y_last - y_first, nw, 3), dtype=np.uint8)
+    for xx in range(nw):
+        x0, n = int(xb[xx, 0]), int(xb[xx, 1])
+        acc = (src[:, x0:x0 + n, :] * xc[xx, :n].astype(np.int64)[None, :, None]).sum(axis=1) + half
+        tmp[:, xx, :] = np.clip(acc >> _PIL_PRECISION_BITS, 0, 255).astype(np.uint8)
+    t64 = tmp.astype(np.int64)
+    out = np.empty((nh, nw, 3), dtype=np.uint8)
+    for yy in range(nh):
+        y0, n = int(yb[yy, 0]) - y_first, int(yb[yy, 1])
+        acc = (t64[y0:y0 + n] * yc[yy, :n].astype(np.int64)[:, None, None]).sum(axis=0) + half
+        out[yy] = np.clip(acc >> _PIL_PRECISION_BITS, 0, 255).astype(np.uint8)
+    return out
+
+
+class DeviceResizer:
+    """ResizeShortestEdge of decoded frames ON THE GPU: the (H, W, 3) uint8 frame goes through a pinned staging buffer to the
+    device on a copy stream of its own and is resampled there (osr_resize_bilinear_u8: Pillow's algorithm, bit-exact), so the host
+    spends no time on the resize and the upload of the next frames overlaps the detector. Returns the (3, nh, nw) uint8 CUDA tensor
+    a model input dict carries as "image"; the caller's stream is made to wait for the copy stream's work (an event, no host
+    sync). Coefficient tables are cached per (input size, output size) pair."""
+
+    def __init__(self, device, max_pixels: int = 4096 * 4096):
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.tables = {}
+        self.staging = []  # ring of pinned host buffers: one frame is being copied while the next is filled
+        self.turn = 0
+        self.max_bytes = max_pixels * 3
+
+    def _axis(self, n_in: int, n_out: int):
+        key = (n_in, n_out)
+        if key not in self.tables:
+            b, c = pil_resample_coeffs(n_in, n_out)
+            self.tables[key] = (torch.from_numpy(b).to(self.device), torch.from_numpy(c).to(self.device), int(b[0, 0]), int(b[-1, 0] + b[-1, 1]), c.shape[1])
+        return self.tables[key]
+
+    def __call__(self, img: np.ndarray, new_hw: Tuple[int, int], out: Optional[torch.Tensor] = None, wait: bool = True) -> torch.Tensor:
+        """out: a (3, nh, nw) uint8 CUDA tensor to write into (a slice of a batch buffer). wait=False: the caller's stream is NOT made
+        to wait here -- it waits once for `self.done` after a whole batch (one event per batch instead of one per frame)."""
+        from . import ops
+        h, w = img.shape[:2]
+        nh, nw = int(new_hw[0]), int(new_hw[1])
+        nbytes = h * w * 3
+        if len(self.staging) < 2:
+            self.staging.append((torch.empty((max(nbytes, 1 << 22),), dtype=torch.uint8).pin_memory(), torch.cuda.Event()))
+        slot = self.turn % len(self.staging)
+        self.turn += 1
+        buf, ev = self.staging[slot]
+        if buf.numel() < nbytes:
+            buf = torch.empty((nbytes,), dtype=torch.uint8).pin_memory()
+            self.staging[slot] = (buf, ev)
+        ev.synchronize()  # the previous copy out of this pinned buffer has finished (no-op for an unrecorded event)
+        buf[:nbytes].view(h, w, 3).numpy()[...] = img  # (one host pass: gathers a flipped / strided view into the pinned buffer)
+        xb, xc, _, _, kx = self._axis(w, nw)
+        yb, yc, y_first, y_last, ky = self._axis(h, nh)
+        cur = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self.stream):
+            dsrc = buf[:nbytes].to(self.device, non_blocking=True)
+            ev.record(self.stream)
+            out = ops.resize_bilinear_u8(dsrc.view(h, w, 3), xb, xc, kx, yb, yc, ky, y_first, y_last - y_first, nh, nw, out=out)
+            self.done = self.stream.record_event()
+        if wait:
+            cur.wait_event(self.done)
+            out.record_stream(cur)
+        return out
+
+
 class DatasetMapper:
     """dataset dict -> model input dict ([d2] DatasetMapper with the default augmentations of cfg.INPUT)."""
 
-    def __init__(self, cfg, is_train: bool, seed: int = 0):
+    def __init__(self, cfg, is_train: bool, seed: int = 0, device_resize: Optional[DeviceResizer] = None):
+        """device_resize: a DeviceResizer -- the frame is resized on the GPU and "image" is a CUDA tensor (the host then only
+        decodes and flips); None: PIL on the host, as the reference's mapper."""
+        self.device_resize = device_resize
         self.is_train = is_train
         self.format = cfg.INPUT.FORMAT
         if is_train:
@@ -72,8 +193,11 @@ class DatasetMapper:
             img = img[:, ::-1]
         size = int(self.min_sizes[rng.randint(len(self.min_sizes))]) if self.is_train else int(self.min_sizes[0])
         nh, nw = shortest_edge_size(h, w, size, self.max_size) if size > 0 else (h, w)
-        img = resize_image(np.ascontiguousarray(img), (nh, nw))
-        out["image"] = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1)))
+        if self.device_resize is not None:
+            out["image"] = self.device_resize(img, (nh, nw))  # (3, nh, nw) uint8 on the GPU, bit-identical to the PIL result
+        else:
+            img = resize_image(np.ascontiguousarray(img), (nh, nw))
+            out["image"] = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1)))
         if self.is_train and "annotations" in d:
             boxes = np.array([a["bbox"] for a in d["annotations"] if not a.get("iscrowd", 0)], dtype=np.float32).reshape(-1, 4)
             classes = [a["category_id"] for a in d["annotations"] if not a.get("iscrowd", 0)]

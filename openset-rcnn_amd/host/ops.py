@@ -222,6 +222,30 @@ def bottleneck(x: torch.Tensor, w1, b1, w2, b2, w3, b3, wsc=None, bsc=None) -> O
     return out
 
 
+def resize_bilinear_u8(img: torch.Tensor, xbounds, xcoef, kx: int, ybounds, ycoef, ky: int, y_first: int, y_rows: int, nh: int, nw: int,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """PIL Image.resize(BILINEAR) of an (h, w, 3) uint8 CUDA image with Pillow's coefficient tables (host/data.py:
+    pil_resample_coeffs) -> (3, nh, nw) uint8 (osr_resize_bilinear_u8)."""
+    lib = _lib.load()
+    _need(img, torch.uint8, "img")
+    for t, nm in ((xbounds, "xbounds"), (xcoef, "xcoef"), (ybounds, "ybounds"), (ycoef, "ycoef")):
+        _need(t, torch.int32, nm)
+    h, w, c = img.shape
+    if c != 3 or xbounds.shape[0] != nw or ybounds.shape[0] != nh or xcoef.shape[1] != kx or ycoef.shape[1] != ky:
+        raise OsrError("resize_bilinear_u8: table shapes do not match the sizes")
+    tmp_bytes = int(lib.osr_resize_tmp_bytes(y_rows, nw))
+    tmp = torch.empty((tmp_bytes,), dtype=torch.uint8, device=img.device)
+    if out is None:
+        out = torch.empty((3, nh, nw), dtype=torch.uint8, device=img.device)
+    else:
+        _need(out, torch.uint8, "out")
+        if tuple(out.shape) != (3, nh, nw):
+            raise OsrError("resize_bilinear_u8: out must be (3, nh, nw)")
+    check(lib.osr_resize_bilinear_u8(_p(img), h, w, w * 3, _p(xbounds), _p(xcoef), kx, _p(ybounds), _p(ycoef), ky, y_first, y_rows, nh, nw, _p(tmp),
+                                     tmp_bytes, _p(out), _stream()), "osr_resize_bilinear_u8")
+    return out
+
+
 def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     _need(x, name="x")

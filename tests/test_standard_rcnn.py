@@ -176,8 +176,17 @@ def test_base_rcnn_fpn_on_two_synthetic_coco_images(osr, coco_toy, dtype):
         rb, rs, rc, _ = O.fast_rcnn_output_inference(bf[i, :counts[i]].cpu(), eb, (480, 640), params)
         m = int(res[3][i])
         assert m == len(rb)
-        assert torch.equal(res[2][i, :m].cpu(), rc)
-        assert torch.allclose(res[0][i, :m].cpu(), rb, rtol=1e-5, atol=1e-4) and torch.allclose(res[1][i, :m].cpu(), rs, atol=1e-6)
+        # the same detections with the same scores; two detections whose scores agree to 1e-6 may come in either order (the oracle's
+        # torch-CPU matrix products and the device's exact-fp32 MFMA sum in different orders, so a near-tie can sort either way)
+        gb, gs, gc = res[0][i, :m].cpu(), res[1][i, :m].cpu(), res[2][i, :m].cpu()
+        assert torch.allclose(gs, rs, atol=1e-6)
+        used = torch.zeros(m, dtype=torch.bool)
+        for j in range(m):
+            ok = (gc == rc[j]) & ((gs - rs[j]).abs() <= 1e-6) & ((gb - rb[j]).abs().amax(dim=1) <= 1e-4 + 1e-5 * rb[j].abs().max()) & ~used
+            assert bool(ok.any()), (i, j, int(rc[j]), float(rs[j]))
+            k = int(torch.nonzero(ok)[0])
+            assert abs(k - j) <= 2, (j, k)  # (only neighbours in the sorted list can swap)
+            used[k] = True
     if dtype == torch.float32:  # parity mode: the whole network against the fp32 oracle
         ref, _ = O.standard_detector_inference([b["image"] for b in batch], params, roi_align_fn=CO.roi_align)
         matched = total = 0
