@@ -168,7 +168,7 @@ def measure_traffic(timeout_s: int = 150):
                     kill_group(proc)
                     return None
                 out[counter] = PS.counter_sum(d, passes)
-        conv = lambda c, f: sum(v[0] for k, v in out[c].items() if k.startswith("conv_igemm") or k.startswith("splitk_reduce")) * 1024 * f / 1e9  # noqa: E731
+        conv = lambda c, f: sum(v[0] for k, v in out[c].items() if k.startswith("conv_igemm") or k.startswith("splitk_reduce") or k.startswith("bottleneck64")) * 1024 * f / 1e9  # noqa: E731
         roi = lambda c, f: sum(v[0] for k, v in out[c].items() if k.startswith("roi_align")) * 1024 * f / 1e9  # noqa: E731
         return (round(conv("FETCH_SIZE", 2) + conv("WRITE_SIZE", 1), 2), round(roi("FETCH_SIZE", 2) + roi("WRITE_SIZE", 1), 2),
                 "measured in this run: two child passes of `bench.py --steps 2 --warmup 1 --streams 1 --no-graph` under rocprofv3 --pmc FETCH_SIZE "

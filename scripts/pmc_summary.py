@@ -15,6 +15,9 @@ def short(name):
     if m:
         split = ",split-K tail" if m.group(10) == "1" else ""
         return f"conv_igemm64<{m.group(4)}x{m.group(5)},{m.group(6)}x{m.group(7)} waves,epi{m.group(8)},stages{1 + int(m.group(9))},out={'f32' if m.group(3) == 'f' else 'same'}{split}>"
+    m = re.match(r"_Z\d+(bottleneck64_kernel)I(DF16_|DF16b)Li(\d+)ELi(\d)E", name)
+    if m:
+        return f"bottleneck64<cin {m.group(3)},{'projection' if m.group(4) == '1' else 'identity'}>"
     m = re.match(r"_Z\d+([a-z_0-9]+?)(I|E|P|v)", name)
     return m.group(1) if m else name.split("(")[0][:60]
 
@@ -65,14 +68,14 @@ def main():
     mfma = mfma_pass(out_dir + "/pmc_mfma")
     kernels = {}
     for k, (c, t) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
-        if t / steps < 20e3:
+        if t / steps < 20e3 and not k.startswith("splitk_reduce"):
             continue
         kernels[k] = dict(launches_per_step=round(c / steps, 2), ms_per_step=round(t / steps / 1e6, 3), avg_us=round(t / c / 1e3, 1),
                           fetch_GB_per_step_x2corrected=round(2 * fetch.get(k, (0, 0))[0] * 1024 / 1e9, 3),
                           write_GB_per_step=round(write.get(k, (0, 0))[0] * 1024 / 1e9, 3))
         if k in mfma:
             kernels[k].update(mfma_util=mfma[k]["mfma_util"], clock_GHz=mfma[k]["clock_GHz"], mfma_executed_TFLOP_per_step=round(mfma[k]["mfma_TFLOP"] / steps, 3))
-    conv = [v for k, v in kernels.items() if k.startswith("conv_igemm")]
+    conv = [v for k, v in kernels.items() if k.startswith("conv_igemm") or k.startswith("bottleneck64") or k.startswith("splitk_reduce")]
     print(json.dumps(dict(
         note="scripts/profile_round.sh: rocprofv3 --kernel-trace --stats, then --pmc FETCH_SIZE, --pmc WRITE_SIZE and --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 in separate passes of "
              "`bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train-step --streams 1 --no-graph` (`steps` passes of the path each: 2 warm-up + 5 timed + the attribution passes + the 4-image calibration pass); FETCH_SIZE doubled per "
