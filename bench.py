@@ -543,7 +543,7 @@ def main(argv=None) -> int:
     eng.profile, eng.profile_hbm = [], []
     eng.forward_device(images, image_hw, 800, 1344)  # attribution pass: one stream, so each launch can be bracketed
     torch.cuda.synchronize()
-    prof, prof_hbm = eng.profile, eng.profile_hbm
+    prof, prof_hbm = eng.resolve_profile()  # (device-side counts are read only now: no host sync inside the bracketed pass)
     eng.profile = eng.profile_hbm = None
     mfma_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1, _, _ in prof)
     mfma_flops = sum(f for _, f, _, _, _, _ in prof)          # algorithmic: real rows of the proposal lists only

@@ -218,9 +218,12 @@ class OpensetRCNNEngine:
         e0.record()
         y = ops.linear(x, w, b, relu=relu, out_dtype=out_dtype, row_seg=row_seg)
         e1.record()
-        rr = x.shape[0] if real_rows is None else int(real_rows)
-        nbytes = rr * x.shape[1] * x.element_size() + w.numel() * w.element_size() + rr * y.shape[1] * y.element_size()
-        self.profile.append((name, 2.0 * rr * w.shape[0] * w.shape[1], e0, e1, nbytes, 2.0 * x.shape[0] * w.shape[0] * w.shape[1]))
+        # (real_rows may be a callable that reads a device count: it is resolved by resolve_profile() AFTER the pass, so that no host
+        # sync sits between the launches of the attribution pass -- a sync in front of a kernel makes it start on an idle, down-clocked GPU)
+        rows_of = (lambda: x.shape[0]) if real_rows is None else (real_rows if callable(real_rows) else (lambda: int(real_rows)))
+        kx, ky, es_x, es_y, wbytes, kn = x.shape[1], y.shape[1], x.element_size(), y.element_size(), w.numel() * w.element_size(), w.shape[0] * w.shape[1]
+        self.profile.append((name, lambda: 2.0 * rows_of() * kn, e0, e1, lambda: rows_of() * kx * es_x + wbytes + rows_of() * ky * es_y,
+                             2.0 * x.shape[0] * kn))
         return y
 
     def _backbone(self, images: torch.Tensor, hp: int, wp: int, keep: Optional[dict] = None, normalized: bool = False) -> Dict[str, torch.Tensor]:
@@ -279,8 +282,17 @@ class OpensetRCNNEngine:
         e0.record()
         out = fn()
         e1.record()
-        self.profile_hbm.append((name, float(nbytes() if callable(nbytes) else nbytes), e0, e1, info(out) if info else None))
+        self.profile_hbm.append((name, nbytes() if callable(nbytes) else nbytes, e0, e1, info(out) if info else None))
         return out
+
+    def resolve_profile(self):
+        """After the profiled pass has been synchronised: evaluate the entries that were left as callables (they read device-side
+        counts; evaluating them inside the pass would put a host sync between its launches). Returns (profile, profile_hbm) with
+        plain numbers."""
+        val = lambda v: v() if callable(v) else v  # noqa: E731
+        prof = [(n, float(val(f)), e0, e1, float(val(nb)), float(nom)) for n, f, e0, e1, nb, nom in (self.profile or [])]
+        hbm = [(n, float(val(nb)), e0, e1, val(info)) for n, nb, e0, e1, info in (self.profile_hbm or [])]
+        return prof, hbm
 
     # ---- CF-RPN ---------------------------------------------------------------------------------------------
     def _levels(self, shapes, n):
@@ -331,22 +343,27 @@ class OpensetRCNNEngine:
         # algorithmic bytes: the pyramid once + the pooled rows of the REAL RoIs once + their boxes (the padding rows of
         # the fixed-capacity lists are zero-filled, not algorithmic output); `info` carries (real rows, nominal bytes)
         profiling = self.profile is not None or self.profile_hbm is not None
-        real = int(sel["counts"].sum()) if profiling else None  # (a host sync: attribution passes only)
+        _real = []
+
+        def real():  # the number of proposals that exist: read from the device once, when first asked (after the pass: resolve_profile)
+            if not _real:
+                _real.append(int(sel["counts"].sum()))
+            return _real[0]
         row_b = c["pooler_resolution"] ** 2 * 256 * es + 20
         pooled_dt = torch.float32 if "pooled" in self.fp32_points else self.dtype
         h1_dt = torch.float32 if self.fp32_points & {"pooled", "h1"} else None  # (the fp32 kernel writes fp32 only)
         pooled = self._hbm("roi_align", lambda: ops.roi_align(fl, c["pooler_scales"], boxes, sel["batch_idx"], c["pooler_resolution"], pooled_dt,
                                                                c["canonical_level"], c["canonical_size"], 2),
-                           lambda: sum(f.numel() for f in fl) * es + real * row_b,
-                           lambda o: dict(real_rois=real, list_rows=boxes.shape[0], nominal_bytes=sum(f.numel() for f in fl) * es + boxes.shape[0] * row_b))
+                           lambda: (lambda: sum(f.numel() for f in fl) * es + real() * row_b),
+                           lambda o: (lambda: dict(real_rois=real(), list_rows=boxes.shape[0], nominal_bytes=sum(f.numel() for f in fl) * es + boxes.shape[0] * row_b)))
         m = pooled.shape[0]
         # each image's list is [its proposals ..., padding]: the FC tiles that hold only padding rows are skipped (their rows of h1 /
         # box_feats stay unwritten; nothing downstream reads past an image's count)
         seg = (sel["counts"], cap) if self.skip_padding_tiles and not self.fp32_points & {"pooled", "h1"} else None
-        h1 = self._linear(pooled.view(m, -1), self.fc1_w, self.fc1_b, True, h1_dt, name="roi_heads.box_head.fc1", row_seg=seg, real_rows=real)
+        h1 = self._linear(pooled.view(m, -1), self.fc1_w, self.fc1_b, True, h1_dt, name="roi_heads.box_head.fc1", row_seg=seg, real_rows=real if profiling else None)
         if "pooled" in self.fp32_points and "h1" not in self.fp32_points:
             h1 = h1.to(self.dtype)  # (diagnostic configuration: FC1 ran in fp32, h1 is stored in the fast path's dtype again)
-        box_feats = self._linear(h1, self.fc2_w, self.fc2_b, True, torch.float32, name="roi_heads.box_head.fc2", row_seg=seg, real_rows=real)
+        box_feats = self._linear(h1, self.fc2_w, self.fc2_b, True, torch.float32, name="roi_heads.box_head.fc2", row_seg=seg, real_rows=real if profiling else None)
         pt = ops.box_predictor_tail(box_feats, self.pred_w, self.pred_b, boxes, sel["scores"].view(-1), sel["batch_idx"], image_hw,
                                     c["bbox_reg_weights"], 0 if c["mean_type"] == "geometric" else 1, c["obj_score_thresh"])
         topk1 = c["detections_per_image"]
@@ -366,10 +383,10 @@ class OpensetRCNNEngine:
                                        c["unknown_id"], c["known_score_thresh"], c["unknown_score_thresh"])
         kk, kc = self._hbm("nms_topk(known, per class)", lambda: ops.nms_topk(cands["k_boxes"], cands["k_scores"], cands["k_cls"], None, n, topk1 * c["num_known"],
                                                                               cands["k_count"], c["known_nms_thresh"], c["known_topk"]),
-                           lambda: int(cands["k_count"].sum()) * 24, lambda o: cands["k_count"])
+                           lambda: (lambda: int(cands["k_count"].sum()) * 24), lambda o: cands["k_count"])
         uk, uc = self._hbm("nms_topk(unknown, class-agnostic)", lambda: ops.nms_topk(cands["u_boxes"], cands["u_scores"], None, None, n, topk1, cands["u_count"],
                                                                                      c["unknown_nms_thresh"], c["unknown_topk"]),
-                           lambda: int(cands["u_count"].sum()) * 20, lambda o: cands["u_count"])
+                           lambda: (lambda: int(cands["u_count"].sum()) * 20), lambda o: cands["u_count"])
         ob, osc, ocl, on = ops.assemble_detections(cands, kk, kc, uk, uc, n, c["unknown_id"], self.class_map)
         if keep is not None:
             keep.update(pooled=pooled, h1=h1, box_feats=box_feats, pred=pt, keep1=keep1, cnt1=cnt1, det_boxes=det_boxes,

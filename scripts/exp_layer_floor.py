@@ -21,7 +21,7 @@ for rep in range(REPS):
     eng.profile = []
     eng.forward_device(images, hw, 800, 1344)
     torch.cuda.synchronize()
-    for i, (name, fl, e0, e1, nb, _nominal) in enumerate(eng.profile):
+    for i, (name, fl, e0, e1, nb, _nominal) in enumerate(eng.resolve_profile()[0]):
         k = (i, name)
         a = acc.setdefault(k, [fl, nb, 0.0])
         a[2] += e0.elapsed_time(e1) / REPS
