@@ -388,6 +388,7 @@ def main(argv=None) -> int:
                          "1 = one pass at a time")
     ap.add_argument("--lane-hint", type=int, default=1, help="1: pass the number of lanes to the conv tile model as its concurrency hint")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--no-chain", action="store_true", help="(A/B) run res3's conv2 and conv3 as separate launches instead of osr_conv2d_chain_fwd")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage breakdown to stderr")
     ap.add_argument("--layers", action="store_true", help="also print every MFMA launch (time, TFLOP/s, GB/s) to stderr")
     argv = list(sys.argv[1:] if argv is None else argv)
@@ -445,6 +446,8 @@ def main(argv=None) -> int:
         print(json.dumps(train_step_leg(params, tdt, dev, images, image_hw, args.train_steps, 2)), flush=True)
         return 0
     eng = OpensetRCNNEngine(params, dtype=tdt, device=dev)
+    if args.no_chain:
+        eng.chain_res3 = False
 
     def step():
         if args.streams > 1:

@@ -109,6 +109,16 @@ osr_status osr_conv2d_fwd(const osr_conv_params* p, const void* in, const void* 
 osr_status osr_conv2d_fwd_masked(const osr_conv_params* p, const void* in, const void* weight, const float* bias,
                                  const void* residual, const void* mask, void* out, void* stream);
 
+/* A bottleneck's 3x3 convolution and the 1x1 convolution behind it in ONE launch ([d2] BottleneckBlock.forward: conv2 -> conv3 ->
+ * `out += shortcut; relu`, /root/reference/configs/Base-RCNN-FPN.yaml:3-8):
+ *     out = relu(conv1x1(act(conv(in, weight) + bias), w3) + bias3 + residual),   act = ReLU when p->relu.
+ * p describes the FIRST convolution (its output, cout channels, never reaches HBM; out_dtype == in_dtype f16/bf16; res_mode,
+ * out_stride_* and row_seg_* are ignored); w3 is [cout3][cout] in the same dtype, bias3 fp32; residual and out are dense
+ * (n*ho*wo, cout3) tensors of that dtype. Same K order and rounding points as osr_conv2d_fwd twice: bit-identical results.
+ * Fused shapes: cout == 128, cout3 == 512 (the res3 blocks); anything else returns OSR_ERR_UNSUPPORTED, nothing launched. */
+osr_status osr_conv2d_chain_fwd(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* w3,
+                                const float* bias3, int32_t cout3, const void* residual, void* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * One whole ResNet bottleneck block in ONE launch: y = relu(conv3(relu(conv2(relu(conv1(x))))) + shortcut(x)),
  * 1x1 -> 3x3 (pad 1) -> 1x1, stride 1, FrozenBN folded into weights / biases ([d2] BottleneckBlock.forward, built by

@@ -94,6 +94,11 @@ struct Conv64Args {
     // slices, which write raw fp32 partial sums (no bias / ReLU) into slab s = out + s * split_stride floats.
     int tile0, ntile, ksplit;
     long long split_stride;
+    // chained 1x1 convolution (EPI == 2, osr_conv2d_chain_fwd): out = relu(conv1x1(relu(conv(in) + bias), w3) + bias3 + res)
+    const void* w3;        // [cout3][cout] packed, storage dtype
+    const float* bias3;
+    int cout3;
+    unsigned w3_bytes, out_bytes;  // buffer sizes of w3 and of out / res (dense rows of cout3 elements)
 #ifdef C64_STAMPS
     unsigned long long* dbg;
 #endif
@@ -130,6 +135,13 @@ template <> __device__ __forceinline__ void store8_64<bf16_t>(bf16_t* p, const f
 }
 
 typedef __attribute__((address_space(3))) void lds_void_t;
+typedef unsigned c64_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int c64_chain_perm(int row) { return (row & ~31) | (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3); }
+template <int N> __device__ __forceinline__ void c64_wait_vm_lgkm_barrier() {  // ONE statement: the compiler may not put anything between the waits and the barrier
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void c64_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // SPLIT = 1: the split-K tail launch (fp32 partial sums of a K range per workgroup); a template parameter so that the ordinary
 // instantiations carry none of its registers (four more VGPRs cost the 128 x 128 single-buffer kernel its third wave per SIMD).
@@ -210,8 +222,12 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
     for (int j = 0; j < B_PIECES; ++j) {
         const int row = (wid * B_PIECES + j) * 8 + lrow;
         const unsigned chunk = (unsigned)(slot ^ ((row >> 1) & 7));
-        const long long o = ((long long)(n0 + row) * a.K + chunk * 8) * 2;
-        b_off[j] = (n0 + row < p.cout && o < (long long)OOB_OFF) ? (unsigned)o : OOB_OFF;
+        // EPI == 2 runs the MFMAs with the weights as the A operand (D = W X^T: a lane then holds output channels of ONE pixel); LDS row
+        // rho of a 32-row group takes weight row 8 ((rho >> 2) & 3) + 4 (rho >> 4) + (rho & 3), so that the lane's rows 4g..4g+3 of the
+        // two 16-row sub-tiles are the eight consecutive channels 8g..8g+7 (one 16-byte chunk of the parked image / of the output)
+        const int wrow = EPI == 2 ? c64_chain_perm(row) : row;
+        const long long o = ((long long)(n0 + wrow) * a.K + chunk * 8) * 2;
+        b_off[j] = (n0 + wrow < p.cout && o < (long long)OOB_OFF) ? (unsigned)o : OOB_OFF;
     }
 
     int kh = 0, kw = 0, c0 = 0;  // tap / channel origin of the current K slice (non-stem)
@@ -317,6 +333,16 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
             }
         }
     }
+    float cb2[EPI == 2 ? TN : 1][8];  // EPI == 2: the conv bias of this lane's eight consecutive channels per 32-channel group
+    if constexpr (EPI == 2) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float* bp = a.bias + (wc * TN + j) * 32 + (lane >> 4) * 8;
+            const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
+            cb2[j][0] = b0.x; cb2[j][1] = b0.y; cb2[j][2] = b0.z; cb2[j][3] = b0.w;
+            cb2[j][4] = b1.x; cb2[j][5] = b1.y; cb2[j][6] = b1.z; cb2[j][7] = b1.w;
+        }
+    }
     float tbias[EPI == 1 ? TN : 1][2];  // per-lane conv bias of its output columns ([.][1] only differs for 16x16 sub-tiles)
     if constexpr (EPI == 1) {
         // tail weights -> LDS (behind the staging / t-tile region); per-lane conv bias of its TN output columns
@@ -379,7 +405,8 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
                 _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                      \
                     _Pragma("unroll") for (int si = 0; si < 2; ++si)                                                                \
                         _Pragma("unroll") for (int sj = 0; sj < 2; ++sj) {                                                          \
-                            acc[i][j][si][sj] = Frag64<TI>::mfma16(fa[k32 % FSETS][i][si], fb[k32 % FSETS][j][sj], acc[i][j][si][sj]); \
+                            acc[i][j][si][sj] = EPI == 2 ? Frag64<TI>::mfma16(fb[k32 % FSETS][j][sj], fa[k32 % FSETS][i][si], acc[i][j][si][sj]) \
+                                                         : Frag64<TI>::mfma16(fa[k32 % FSETS][i][si], fb[k32 % FSETS][j][sj], acc[i][j][si][sj]); \
                             const int done_ = (((k32 * TM + i) * TN + j) * 2 + si) * 2 + sj + 1;                                    \
                             if (SPREAD && k32 == 0 && done_ % FSTEP == 0 && done_ / FSTEP <= NFRAG) {                      \
                                 C64_SPREAD_ONE(done_ / FSTEP - 1);                                                                  \
@@ -444,6 +471,161 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
 #undef C64_LOAD_FRAGS
     __syncthreads();  // all waves done with the staging buffers before the epilogue reuses them
     C64_STAMP(2);
+
+    if constexpr (EPI == 2) {
+        // ---- chained 1x1 convolution (a bottleneck's conv2 -> conv3 + residual, osr_conv2d_chain_fwd). relu(conv + bias) of the tile is
+        // parked in LDS in the storage dtype -- the same rounding point as the separate launches -- as two swizzled 64-channel slices
+        // (the layout of a staged A tile). Each wave then keeps its 64 pixels x 128 channels as MFMA fragments in registers and walks
+        // the chained layer's output channels 64 at a time: a stage = 64 weight rows x K = 128 (16 KB) through a three-slot LDS-DMA
+        // ring, two stages ahead; the residual and bias of a stage are requested two stages ahead as well (buffer loads; a wave's
+        // vector-memory operations return in order, so the counted waits below only ever wait for operations issued at least a
+        // stage earlier). Weights are the A operand: a lane ends up with eight consecutive output channels of one pixel and stores
+        // 16 bytes, no transposition. One asm statement per stage: s_waitcnt vmcnt(N) lgkmcnt(0); s_barrier (the slot restaged behind
+        // it was read in the previous stage: those reads have retired).
+        static_assert(EPI != 2 || (BN == 128 && WN == 2 && TM == 2 && TWO == 1 && SPLIT == 0), "chained 1x1: 128 output channels, 64 x 64 per wave, two staging buffers");
+        constexpr int CH_A = 0, CH_SL = BM * 128, CH_W = 2 * CH_SL, CH_STG = 16384, CH_NS = 8, CH_NR = 6, CH_PW = 16 / NW;  // 8 stages of 64 channels: cout3 == 512
+        union FU { frag_t f; c64_u32x4 u; };
+        const int g = lane >> 4, l15 = lane & 15;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int si = 0; si < 2; ++si) {
+                    const int r = (wr * TM + i) * 32 + si * 16 + l15;
+                    const int chunk = j * 4 + g;
+                    frag_t t;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float v0 = acc[i][j][si][0][q] + cb2[j][q], v1 = acc[i][j][si][1][q] + cb2[j][4 + q];
+                        t[q] = (TI)(p.relu ? fmaxf(v0, 0.f) : v0);
+                        t[4 + q] = (TI)(p.relu ? fmaxf(v1, 0.f) : v1);
+                    }
+                    *reinterpret_cast<frag_t*>(lds + CH_A + wc * CH_SL + r * 128 + ((chunk ^ ((r >> 1) & 7)) << 4)) = t;
+                }
+        const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w3), 0, a.w3_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res), 0, a.out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_b3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias3), 0, (unsigned)a.cout3 * 4u, 0x00020000);
+        unsigned w3_off[CH_PW];  // this lane's share of a stage: pieces wid * CH_PW + j of 16 (piece = K half (pc >> 3), rows (pc & 7) * 8 ..)
+#pragma unroll
+        for (int j = 0; j < CH_PW; ++j) {
+            const int pc = wid * CH_PW + j, ksl = pc >> 3, row = (pc & 7) * 8 + lrow;
+            const int chunk = slot ^ ((row >> 1) & 7);
+            w3_off[j] = (unsigned)((c64_chain_perm(row) * 128 + ksl * 64 + chunk * 8) * 2);
+        }
+        unsigned o_off[TM][2];  // byte offset of this lane's pixel row in out / res (dense rows of cout3 elements), + its channel group
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int si = 0; si < 2; ++si) {
+                const long long m = m0 + (wr * TM + i) * 32 + si * 16 + l15;
+                o_off[i][si] = m < a.M ? (unsigned)((m * a.cout3 + wc * 32 + g * 8) * 2) : OOB_OFF;
+            }
+        const unsigned b3_off = (unsigned)((wc * 32 + g * 8) * 4);
+        FU rr[3][TM][2];
+        c64_u32x4 rb[3][2];
+#define C64_CH_ISSUE(s_)                                                                                                             \
+        {                                                                                                                            \
+            _Pragma("unroll") for (int j_ = 0; j_ < CH_PW; ++j_) {                                                                   \
+                const unsigned vo_ = w3_off[j_];                                                                                     \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w3, (lds_void_t*)(lds + CH_W + ((s_) % 3) * CH_STG + (wid * CH_PW + j_) * 1024), 16, vo_, \
+                                                         (s_) * 64 * 128 * 2, 0, 0);                                                  \
+            }                                                                                                                        \
+            __builtin_amdgcn_sched_barrier(0); /* the counted waits below rely on this issue order */                                \
+        }
+#define C64_CH_FETCH(s_)                                                                                                             \
+        {                                                                                                                            \
+            _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_)                                                                        \
+                _Pragma("unroll") for (int si_ = 0; si_ < 2; ++si_) {                                                                \
+                    rr[(s_) % 3][i_][si_].u = __builtin_amdgcn_raw_buffer_load_b128(rs_res, o_off[i_][si_], (s_) * 128, 0);           \
+                }                                                                                                                    \
+            rb[(s_) % 3][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_b3, b3_off, (s_) * 256, 0);                                    \
+            rb[(s_) % 3][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_b3, b3_off, (s_) * 256 + 16, 0);                               \
+            __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        }
+        __syncthreads();  // the parked image is complete; the staging buffers of the K loop are free
+        C64_CH_ISSUE(0);
+        C64_CH_FETCH(0);
+        C64_CH_ISSUE(1);
+        C64_CH_FETCH(1);
+        frag_t fp[TM][2][4];  // this wave's 64 pixels x 128 channels: B operand of every stage
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int si = 0; si < 2; ++si)
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const int rr_ = si * 16 + l15;
+                    fp[i][si][k4] = *reinterpret_cast<const frag_t*>(lds + CH_A + (k4 >> 1) * CH_SL + ((wr * TM + i) * 32 + rr_) * 128 +
+                                                                     ((((k4 & 1) * 4 + g) ^ ((rr_ >> 1) & 7)) << 4));
+                }
+        const int wrow_ = wc * 32 + l15;
+        // One stage. The counted waits are exact: vector-memory operations issued behind the one waited for, per stage P = CH_PW
+        // LDS-DMA pieces, R = CH_NR residual / bias loads, 4 stores -- nothing is issued for stages past the last one (a dummy load
+        // whose result is unused would be removed by the compiler and the counts with it).
+#define C64_CH_HAS(t_) ((t_) >= 0 && (t_) < CH_NS)
+#define C64_CH_STAGE(S)                                                                                                              \
+        {                                                                                                                            \
+            constexpr int s = (S);                                                                                                   \
+            constexpr int PR1 = C64_CH_HAS(s + 1) ? CH_PW + CH_NR : 0, PR2 = C64_CH_HAS(s + 2) ? CH_PW + CH_NR : 0;                  \
+            constexpr int ST1 = s >= 1 ? 4 : 0, ST2 = s >= 2 ? 4 : 0;                                                                \
+            /* stage s has landed for this wave: younger = R(s), stores(s-2), P(s+1), R(s+1), stores(s-1) */                         \
+            c64_wait_vm_lgkm_barrier<CH_NR + ST2 + PR1 + ST1>();                                                                     \
+            if constexpr (C64_CH_HAS(s + 2)) {                                                                                       \
+                C64_CH_ISSUE(s + 2);                                                                                                 \
+                C64_CH_FETCH(s + 2);                                                                                                 \
+            }                                                                                                                        \
+            const unsigned char* sb = lds + CH_W + (s % 3) * CH_STG;                                                                 \
+            f32x4 a3[TM][2][2];                                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                           \
+                _Pragma("unroll") for (int si = 0; si < 2; ++si)                                                                     \
+                    _Pragma("unroll") for (int sj = 0; sj < 2; ++sj) a3[i][si][sj] = f32x4{0.f, 0.f, 0.f, 0.f};                      \
+            _Pragma("unroll") for (int k4 = 0; k4 < 4; ++k4) {                                                                       \
+                frag_t fw[2];                                                                                                        \
+                _Pragma("unroll") for (int sj = 0; sj < 2; ++sj) {                                                                   \
+                    const int rw_ = wrow_ + sj * 16;                                                                                 \
+                    fw[sj] = *reinterpret_cast<const frag_t*>(sb + (k4 >> 1) * 8192 + rw_ * 128 + ((((k4 & 1) * 4 + g) ^ ((rw_ >> 1) & 7)) << 4)); \
+                }                                                                                                                    \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                       \
+                    _Pragma("unroll") for (int si = 0; si < 2; ++si)                                                                 \
+                        _Pragma("unroll") for (int sj = 0; sj < 2; ++sj)                                                             \
+                            a3[i][si][sj] = Frag64<TI>::mfma16(fw[sj], fp[i][si][k4], a3[i][si][sj]);                                \
+            }                                                                                                                        \
+            /* the stage's residual and bias (requested two stages ago): younger = stores(s-2), P+R(s+1), stores(s-1), P+R(s+2) */   \
+            c64_wait_vm<ST2 + PR1 + ST1 + PR2>();                                                                                    \
+            union { c64_u32x4 u; float f[4]; } b0, b1;                                                                               \
+            b0.u = rb[s % 3][0]; b1.u = rb[s % 3][1];                                                                                \
+            FU o[TM][2];                                                                                                             \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                           \
+                _Pragma("unroll") for (int si = 0; si < 2; ++si) {                                                                   \
+                    const frag_t rv = rr[s % 3][i][si].f;                                                                            \
+                    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                                  \
+                        float v = (e < 4 ? a3[i][si][0][e & 3] : a3[i][si][1][e & 3]) + (e < 4 ? b0.f[e & 3] : b1.f[e & 3]);         \
+                        v += (float)rv[e];                                                                                           \
+                        o[i][si].f[e] = (TI)fmaxf(v, 0.f);                                                                           \
+                    }                                                                                                                \
+                }                                                                                                                    \
+            /* The four stores go out together at the end of the stage, fenced on both sides, and nothing may write their data       \
+               registers for the next instructions: a 16-byte buffer store reads its data after it has issued, and with a register   \
+               in the soffset field the compiler assumes it may overwrite them at once (measured: under load from a second stream   \
+               lanes 12-15 of every row of 16 stored the NEXT value of the first data register). */                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                                       \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                           \
+                _Pragma("unroll") for (int si = 0; si < 2; ++si) /* (a row beyond M: offset outside the buffer, store dropped) */    \
+                    __builtin_amdgcn_raw_buffer_store_b128(o[i][si].u, rs_out, o_off[i][si], s * 128, 0);                            \
+            asm volatile("s_nop 3" ::: "memory");                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        }
+        static_assert(CH_NS == 8, "eight stages written out");
+        C64_CH_STAGE(0) C64_CH_STAGE(1) C64_CH_STAGE(2) C64_CH_STAGE(3) C64_CH_STAGE(4) C64_CH_STAGE(5) C64_CH_STAGE(6) C64_CH_STAGE(7)
+#undef C64_CH_STAGE
+#undef C64_CH_HAS
+#undef C64_CH_ISSUE
+#undef C64_CH_FETCH
+        C64_STAMP(3);
+        return;
+    }
 
     if constexpr (EPI == 1) {
         // ---- fused CF-RPN tail (classification_free_rpn.py:159-161): t = relu(conv + bias) is parked in LDS in the
@@ -860,6 +1042,7 @@ osr_status osr_conv64_run(const osr_conv_params* p, const void* in, const void* 
     a.tap_minor = (!a.stem && p->kh * p->kw > 1) ? tap_minor_default() : 0;
     a.tiles_m = a.tiles_n = 0;
     a.tail_w = a.tail_b = nullptr; a.tail_deltas = a.tail_ctr = nullptr;
+    a.w3 = nullptr; a.bias3 = nullptr; a.cout3 = 0; a.w3_bytes = a.out_bytes = 0;
 #ifdef C64_STAMPS
     a.dbg = g_c64_stamps;
 #endif
@@ -911,9 +1094,69 @@ extern "C" osr_status osr_cfrpn_head_fwd_ex(const osr_conv_params* p, const void
     a.stem = 0;
     a.tap_minor = p->kh * p->kw > 1 ? tap_minor_default() : 0;
     a.tail_w = w_tail; a.tail_b = b_tail; a.tail_deltas = deltas; a.tail_ctr = ctr;
+    a.w3 = nullptr; a.bias3 = nullptr; a.cout3 = 0; a.w3_bytes = a.out_bytes = 0;
 #ifdef C64_STAMPS
     a.dbg = nullptr;
 #endif
     hipStream_t st = (hipStream_t)stream;
     return p->in_dtype == OSR_F16 ? cfrpn_fused_launch<f16_t>(a, st) : cfrpn_fused_launch<bf16_t>(a, st);
+}
+
+// A bottleneck's conv2 -> conv3 in one launch (include/osr.h: osr_conv2d_chain_fwd):
+//     out = relu(conv1x1(act(conv(in, w) + bias), w3) + bias3 + residual),   act = ReLU when p->relu.
+// p describes the FIRST convolution (cout == 128; its output never reaches HBM); out and residual are dense (rows, cout3) tensors.
+template <class TI, int BM>
+static osr_status conv_chain_launch(Conv64Args& a, hipStream_t st) {
+    constexpr int WM = BM / 64;
+    a.two_stage = 1;
+    a.tiles_n = 1;
+    a.tiles_m = (int)((a.M + BM - 1) / BM);
+    a.tile0 = 0; a.ntile = a.tiles_m; a.ksplit = 1; a.split_stride = 0;
+    // parked tile + three weight stages; the K loop's two staging buffers alias the front
+    const size_t park = (size_t)2 * BM * 128 + 3 * 16384, stg = (size_t)2 * (BM + 128) * 128, lds = park > stg ? park : stg;
+    static osr_dev_mask attr{0};
+    osr_once_per_device(attr, [] { allow_big_lds(conv_igemm64_kernel<TI, TI, BM, 128, WM, 2, 2, 1>); });
+    hipLaunchKernelGGL((conv_igemm64_kernel<TI, TI, BM, 128, WM, 2, 2, 1>), dim3((unsigned)a.tiles_m), dim3(WM * 2 * 64), lds, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { osr_set_error("osr_conv2d_chain_fwd: launch failed: %s", hipGetErrorString(e)); return OSR_ERR_LAUNCH; }
+    return OSR_OK;
+}
+
+extern "C" osr_status osr_conv2d_chain_fwd(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* w3,
+                                           const float* bias3, int32_t cout3, const void* residual, void* out, void* stream) {
+    OSR_REQUIRE(p && in && weight && bias && w3 && bias3 && residual && out, OSR_ERR_INVALID_ARG, "osr_conv2d_chain_fwd: null pointer");
+    OSR_REQUIRE(p->in_dtype == OSR_F16 || p->in_dtype == OSR_BF16, OSR_ERR_UNSUPPORTED, "osr_conv2d_chain_fwd: in_dtype must be f16/bf16");
+    OSR_REQUIRE(p->out_dtype == p->in_dtype, OSR_ERR_UNSUPPORTED, "osr_conv2d_chain_fwd: out_dtype must equal in_dtype");
+    OSR_REQUIRE(p->cout == 128 && cout3 == 512 && p->cin % 64 == 0 && p->pad_mode == 0, OSR_ERR_UNSUPPORTED,
+                "osr_conv2d_chain_fwd: needs cout == 128, cout3 == 512, cin %% 64 == 0 (got %d, %d, %d)", p->cout, cout3, p->cin);
+    OSR_REQUIRE(p->n >= 1 && p->hi >= 1 && p->wi >= 1 && p->kh >= 1 && p->kw >= 1 && p->kh <= 16 && p->kw <= 16 && p->stride_h >= 1 && p->stride_w >= 1 &&
+                    p->pad_h >= 0 && p->pad_w >= 0, OSR_ERR_INVALID_ARG, "osr_conv2d_chain_fwd: bad geometry");
+    OSR_REQUIRE((p->hi + 2 * p->pad_h - p->kh) / p->stride_h + 1 == p->ho && (p->wi + 2 * p->pad_w - p->kw) / p->stride_w + 1 == p->wo,
+                OSR_ERR_INVALID_ARG, "osr_conv2d_chain_fwd: ho/wo inconsistent with hi/wi/kernel/stride/pad");
+    OSR_REQUIRE(p->in_stride_w % 8 == 0 && p->in_stride_h % 8 == 0 && p->in_stride_n % 8 == 0 && p->in_stride_n > 0, OSR_ERR_INVALID_ARG,
+                "osr_conv2d_chain_fwd: input strides must be multiples of 8 elements");
+    OSR_REQUIRE((((uintptr_t)in | (uintptr_t)weight | (uintptr_t)bias | (uintptr_t)w3 | (uintptr_t)bias3 | (uintptr_t)residual | (uintptr_t)out) & 15) == 0,
+                OSR_ERR_INVALID_ARG, "osr_conv2d_chain_fwd: pointers must be 16-byte aligned");
+    const long long in_bytes = (long long)p->n * p->in_stride_n * 2, w_bytes = (long long)p->cout * p->kh * p->kw * p->cin * 2;
+    const long long M = (long long)p->n * p->ho * p->wo, out_bytes = M * cout3 * 2;
+    OSR_REQUIRE(osr_conv64_eligible(p, in_bytes, w_bytes) && out_bytes < (1ll << 31) - 4096, OSR_ERR_UNSUPPORTED,
+                "osr_conv2d_chain_fwd: tensor too large for 32-bit buffer offsets");
+    Conv64Args a;
+    a.p = *p; a.in = in; a.w = weight; a.bias = bias; a.res = residual; a.mask = nullptr; a.out = out;
+    a.p.row_seg_counts = nullptr;
+    a.M = M;
+    a.K = p->kh * p->kw * p->cin;
+    a.div_howo = fastdiv_make((unsigned)(p->ho * p->wo));
+    a.div_wo = fastdiv_make((unsigned)p->wo);
+    a.in_bytes = (unsigned)in_bytes; a.w_bytes = (unsigned)w_bytes;
+    a.stem = 0;
+    a.tap_minor = p->kh * p->kw > 1 ? tap_minor_default() : 0;
+    a.tail_w = a.tail_b = nullptr; a.tail_deltas = a.tail_ctr = nullptr; a.tail_lds_off = 0;
+    a.w3 = w3; a.bias3 = bias3; a.cout3 = cout3;
+    a.w3_bytes = (unsigned)((long long)cout3 * p->cout * 2); a.out_bytes = (unsigned)out_bytes;
+#ifdef C64_STAMPS
+    a.dbg = g_c64_stamps;
+#endif
+    hipStream_t st = (hipStream_t)stream;
+    return p->in_dtype == OSR_F16 ? conv_chain_launch<f16_t, 128>(a, st) : conv_chain_launch<bf16_t, 128>(a, st);
 }

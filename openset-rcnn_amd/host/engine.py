@@ -113,6 +113,8 @@ class OpensetRCNNEngine:
         self.skip_padding_tiles = dtype != torch.float32
         # the three (four) convolutions of a res2 block run as ONE launch (osr_bottleneck_fwd): fp16 / bf16 storage only
         self.fuse_res2 = dtype != torch.float32
+        # conv2 -> conv3 + shortcut of a res3 block run as ONE launch (osr_conv2d_chain_fwd: conv2's output stays in LDS)
+        self.chain_res3 = dtype != torch.float32
         self._init_rpn(params)
         self._init_roi_heads(params)
 
@@ -205,6 +207,19 @@ class OpensetRCNNEngine:
                 return y
         sc = self._conv(x, pre + ".shortcut", stride) if first else x
         o = self._conv(x, pre + ".conv1", stride, relu=True)
+        if self.chain_res3 and w[pre + ".conv2.w"].shape[0] == 128 and w[pre + ".conv3.w"].shape[0] == 512:
+            if self.profile is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            y = ops.conv2d_chain(o, w[pre + ".conv2.w"], w[pre + ".conv2.b"], w[pre + ".conv3.w"], w[pre + ".conv3.b"], sc, 1, 1)
+            if y is not None:
+                if self.profile is not None:
+                    e1.record()
+                    px, es = y.numel() // y.shape[-1], y.element_size()
+                    flops = 2.0 * px * (w[pre + ".conv2.w"].numel() + w[pre + ".conv3.w"].numel())
+                    nbytes = (o.numel() + sc.numel() + y.numel() + w[pre + ".conv2.w"].numel() + w[pre + ".conv3.w"].numel()) * es
+                    self.profile.append((pre + ".conv2+conv3 (chained)", flops, e0, e1, nbytes, flops))
+                return y
         o = self._conv(o, pre + ".conv2", 1, 1, relu=True)
         return self._conv(o, pre + ".conv3", relu=True, residual=sc, res_mode=1)
 

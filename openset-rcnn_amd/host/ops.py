@@ -189,6 +189,43 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, relu: bool
     return y.view(m, weight.shape[0])
 
 
+def conv2d_chain(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, w3: torch.Tensor, b3: torch.Tensor, residual: torch.Tensor,
+                 stride: int = 1, pad: int = 0) -> Optional[torch.Tensor]:
+    """A bottleneck's conv2 -> conv3 in one launch (osr_conv2d_chain_fwd): relu(conv1x1(relu(conv(x, weight) + bias), w3) + b3 +
+    residual). x (n,h,w,cin) f16/bf16, weight (cmid,kh,kw,cin), w3 (cout3,1,1,cmid), residual (n,ho,wo,cout3). Returns None when the
+    shape is outside the fused kernel's envelope (the caller then runs conv2d twice)."""
+    lib = _lib.load()
+    _need(x, name="x")
+    if x.dtype not in (torch.float16, torch.bfloat16):
+        return None
+    _need(weight, x.dtype, "weight"); _need(w3, x.dtype, "w3"); _need(residual, x.dtype, "residual")
+    _need(bias, torch.float32, "bias"); _need(b3, torch.float32, "b3")
+    n, hi, wi, cin = x.shape
+    cmid, kh, kw, cin2 = weight.shape
+    cout3 = w3.shape[0]
+    if cin2 != cin or tuple(w3.shape) != (cout3, 1, 1, cmid) or bias.numel() != cmid or b3.numel() != cout3:
+        raise OsrError("conv2d_chain: weight shapes do not form conv -> 1x1 conv")
+    ho = (hi + 2 * pad - kh) // stride + 1
+    wo = (wi + 2 * pad - kw) // stride + 1
+    if tuple(residual.shape) != (n, ho, wo, cout3):
+        raise OsrError(f"conv2d_chain: residual shape {tuple(residual.shape)} != {(n, ho, wo, cout3)}")
+    p = _new_conv_params()
+    p.n, p.hi, p.wi, p.cin, p.ho, p.wo, p.cout = n, hi, wi, cin, ho, wo, cmid
+    p.kh, p.kw, p.stride_h, p.stride_w, p.pad_h, p.pad_w = kh, kw, stride, stride, pad, pad
+    p.in_stride_n, p.in_stride_h, p.in_stride_w = hi * wi * cin, wi * cin, cin
+    p.out_stride_n, p.out_stride_h, p.out_stride_w = ho * wo * cmid, wo * cmid, cmid
+    p.relu, p.res_mode, p.pad_mode = 1, 0, 0
+    p.in_dtype = p.out_dtype = _DT[x.dtype]
+    out = torch.empty((n, ho, wo, cout3), dtype=x.dtype, device=x.device)
+    st = lib.osr_conv2d_chain_fwd(C.byref(p), _p(x), _p(weight), _p(bias), _p(w3), _p(b3), cout3, _p(residual), _p(out), _stream())
+    if st == _lib.ERR_UNSUPPORTED:
+        return None
+    check(st, "osr_conv2d_chain_fwd")
+    if FLOP_COUNT is not None:
+        FLOP_COUNT["conv"] += 2.0 * n * ho * wo * (cmid * kh * kw * cin + cout3 * cmid)
+    return out
+
+
 def bottleneck(x: torch.Tensor, w1, b1, w2, b2, w3, b3, wsc=None, bsc=None) -> Optional[torch.Tensor]:
     """One whole bottleneck block in one launch (osr_bottleneck_fwd): x (n,h,w,cin) f16/bf16, weights packed (cout,kh,kw,cin) in
     x's dtype, biases fp32; wsc / bsc = the projection shortcut (None: identity). Returns y (n,h,w,cout), or None when the shape
