@@ -65,8 +65,11 @@ struct WgradArgs {
 
 // Tile TCO (output channels) x TCI (input channels) of one tap, WM x WN waves. Per step of 64 pixel rows the dy tile
 // [64][TCO] and the x tile [64][TCI] are staged row-major (LDS-DMA pieces of 1 KiB = 512/T rows); the 16-byte chunk c of row r
-// lands in slot c ^ sw(r), sw(r) = (r & 3) | ((r >> 3) & 1) << 2: the eight rows one half-wave touches in a transposing read
-// (r = 8g + 4h + q, g in {0,1} or {2,3}) get eight different swizzles, so the reads are bank-conflict free.
+// lands in slot c ^ sw(r), sw(r) = 2 ((r & 3) | ((r >> 3) & 1) << 2): the eight rows one half-wave touches in a transposing read
+// (r = 8g + 4h + q, g in {0,1} or {2,3}) get eight different EVEN swizzles. Even, because the lanes of a read differ in the low chunk
+// bit as well (pp >> 1: the two 16-byte chunks of a 16-channel sub-tile): with the odd values of round 1's sw(r) = (r & 3) | ... lane
+// (row s, chunk bit 0) and lane (row s ^ 1, chunk bit 1) met in the same banks -- rocprofv3: SQ_LDS_BANK_CONFLICT = half of
+// SQ_LDS_IDX_ACTIVE in both instantiations. Now the 32 lanes of a half-wave cover all 64 banks once.
 // The pieces of step s+1 are issued between the MFMAs of step s (as in the forward kernel).
 template <class TI, int TCO, int TCI, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(WgradArgs a) {
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(WgradArgs a
                        p.in_stride_h == (long long)p.wi * p.in_stride_w && p.in_stride_n == (long long)p.hi * p.in_stride_h;  // x rows are linear in m
 
     // one staging piece: q < YPW -> dy rows, else x rows (gathered through the conv geometry)
-#define WG_SW(r) (((r) & 3) | ((((r) >> 3) & 1) << 2))
+#define WG_SW(r) ((((r) & 3) | ((((r) >> 3) & 1) << 2)) << 1)
 #define WG_PIECE(stage, step, q)                                                                                                \
     {                                                                                                                           \
         unsigned char* sy_ = lds + (stage) * STAGE;                                                                             \
