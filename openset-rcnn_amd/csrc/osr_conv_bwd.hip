@@ -235,13 +235,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     *reinterpret_cast<float4*>(dw + i4) = s;
 }
 
+#ifdef OSR_EXPERIMENT
+#include <stdlib.h>
+static int wg_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#define WG_KNOB(name, dflt) ([] { static const int v = wg_env_int(name, dflt); return v; }())
+#else
+#define WG_KNOB(name, dflt) (dflt)
+#endif
 static bool wgrad_big(const osr_conv_params* p) { return p->cout % 256 == 0 && p->cin % 256 == 0; }
 
 static int wgrad_splits(const osr_conv_params* p) {
     const long long M = (long long)p->n * p->ho * p->wo;
     const int tt = wgrad_big(p) ? 256 : 128;
     const long long ntiles = (long long)((p->cout + tt - 1) / tt) * ((p->cin + tt - 1) / tt) * p->kh * p->kw;
-    const long long target = wgrad_big(p) ? 512 : 1024;  // workgroups wanted: 256 CUs x 2 (x 2 for the 4-wave tiles)
+    // Workgroups wanted. Every split writes a full fp32 copy of the tile's weights and the reduction reads it back: for the layers
+    // with few tiles (the 1x1 layers of res3 / res4: 4 tiles of 256 x 256, K loop of 67 200 rows) that traffic outweighs the operands
+    // (128 splits x 1 MB written and re-read against 170 MB of x + dy), and the 256 x 256 tile holds one workgroup per CU anyway, so
+    // fewer, longer splits cost no occupancy. Swept inside the training step, where the launches share the GPU with the data-gradient
+    // stream (same box, ms per iteration): 512 / 1024 (rounds 1-2) 32.2; 256 / 1024 31.4-31.6; 192 / 1024 30.8; 160 / 1024 30.7;
+    // 128 / 1024 31.6; 192 / 384 30.6.
+    const long long target = wgrad_big(p) ? WG_KNOB("OSR_WGRAD_TARGET_BIG", 192) : WG_KNOB("OSR_WGRAD_TARGET_SMALL", 384);
     long long splits = (target + ntiles - 1) / ntiles;
     const long long max_splits = (M + 255) / 256;     // at least 256 rows per split
     if (splits > max_splits) splits = max_splits;
