@@ -584,6 +584,16 @@ osr_status osr_roi_align_bwd(const osr_pyramid* dfeat, int32_t n, const float* b
                              int32_t pooled, int32_t canonical_level, int32_t canonical_size, int32_t min_level,
                              const void* dout, int32_t dout_dtype, void* stream);
 
+/* The same gradient in pixel-centric form: one workgroup per 8 x 8 pixel tile of a level GATHERS the contributions of the image's RoIs
+ * -- no atomics, no zero-initialised output (every element of dfeat is written exactly once, zeros where no RoI reaches), bitwise
+ * reproducible (fixed summation order: list order, bin row, bin column). The RoI list must be image-major with a fixed stride:
+ * rows [b * rois_per_image, (b + 1) * rois_per_image) belong to image b (batch_idx == b) or are padding (batch_idx < 0);
+ * m == n * rois_per_image, rois_per_image <= 1024, c <= 256. Otherwise OSR_ERR_UNSUPPORTED with nothing launched: zero dfeat and
+ * call osr_roi_align_bwd. Same reference lines as osr_roi_align_bwd. */
+osr_status osr_roi_align_bwd_dense(const osr_pyramid* dfeat, int32_t n, const float* boxes, const int32_t* batch_idx, int64_t m,
+                                   int32_t rois_per_image, int32_t pooled, int32_t canonical_level, int32_t canonical_size, int32_t min_level,
+                                   const void* dout, int32_t dout_dtype, void* stream);
+
 /* g[i] = act[i] > 0 ? g[i] : 0, in place (gradient through a ReLU whose output is act). */
 osr_status osr_relu_mask(void* g, int32_t g_dtype, const void* act, int32_t act_dtype, int64_t n, void* stream);
 /* out[i] = (T)(a_f32[i] + b[i]); either addend may be null. */

@@ -985,16 +985,27 @@ def pln_loss_bwd(emb, protos_raw, gt_classes, ious, iou_thr: float, alpha: float
 
 
 def roi_align_bwd(dout: torch.Tensor, shapes: Sequence[Tuple[int, int]], n: int, scales: Sequence[float], boxes, batch_idx,
-                  canonical_level: int = 4, canonical_size: int = 224, min_level: int = 2) -> List[torch.Tensor]:
-    """dout (m,P,P,c) -> list of fp32 (n,h,w,c) feature gradients, one per level."""
+                  canonical_level: int = 4, canonical_size: int = 224, min_level: int = 2, rois_per_image: Optional[int] = None) -> List[torch.Tensor]:
+    """dout (m,P,P,c) -> list of fp32 (n,h,w,c) feature gradients, one per level. rois_per_image: the list is image-major with this
+    fixed stride (rows [b*S, (b+1)*S) are image b's or padding) -- the pixel-centric kernel then gathers (osr_roi_align_bwd_dense: no
+    atomics, no zero fill, reproducible bit for bit); otherwise the scatter kernel adds into a zeroed pyramid with fp32 atomics."""
     lib = _lib.load()
     _need(dout, name="dout"); _need(boxes, torch.float32, "boxes"); _need(batch_idx, torch.int32, "batch_idx")
     m, pooled, _, c = dout.shape
-    outs = [torch.zeros((n, h, w, c), dtype=torch.float32, device=dout.device) for h, w in shapes]
+    dense = rois_per_image is not None and m == n * rois_per_image and rois_per_image <= 1024 and c <= 256
+    outs = [(torch.empty if dense else torch.zeros)((n, h, w, c), dtype=torch.float32, device=dout.device) for h, w in shapes]
     py = Pyramid()
     py.num_levels, py.c = len(outs), c
     for i, (f, s) in enumerate(zip(outs, scales)):
         py.h[i], py.w[i], py.scale[i], py.data[i] = f.shape[1], f.shape[2], float(s), f.data_ptr()
+    if dense:
+        st = lib.osr_roi_align_bwd_dense(C.byref(py), n, _p(boxes), _p(batch_idx), m, int(rois_per_image), pooled, canonical_level, canonical_size,
+                                         min_level, _p(dout), _DT[dout.dtype], _stream())
+        if st != _lib.ERR_UNSUPPORTED:
+            check(st, "osr_roi_align_bwd_dense")
+            return outs
+        for f in outs:
+            f.zero_()
     check(lib.osr_roi_align_bwd(C.byref(py), n, _p(boxes), _p(batch_idx), m, pooled, canonical_level, canonical_size, min_level, _p(dout),
                                 _DT[dout.dtype], _stream()), "osr_roi_align_bwd")
     return outs

@@ -432,7 +432,7 @@ class OpensetRCNNTrainer:
         P = c["pooler_resolution"]
         shapes = [(p[k].shape[1], p[k].shape[2]) for k in ("p2", "p3", "p4", "p5")]
         d_feat = ops.roi_align_bwd(d_pooled.view(m, P, P, -1), shapes, n, c["pooler_scales"], s["boxes"], s["smp"]["batch_idx"], c["canonical_level"],
-                                   c["canonical_size"], 2)
+                                   c["canonical_size"], 2, rois_per_image=m // n if m % n == 0 else None)  # (the sampled list is (n, S))
         # --- CF-RPN 3x3 conv: data gradient per level, joined with the RoI heads' feature gradient (the chain above it ran on the
         #     second stream, see the top of this function) ---
         if self.side_wgrad:

@@ -171,6 +171,73 @@ def test_roi_align_backward_extreme_aspect_footprints(ops):
     assert rel(got.permute(0, 3, 1, 2), feat.grad) < 1e-4
 
 
+def _image_major(boxes, bidx, dout, n):
+    """Reorder a RoI list into the (n, S) image-major layout the pixel-centric backward wants (padding rows: batch_idx -1)."""
+    per = [torch.nonzero(bidx == b).squeeze(1) for b in range(n)]
+    S = max(len(p) for p in per) + 2  # at least two padding rows per image
+    bx = torch.zeros(n * S, 4)
+    bi = torch.full((n * S,), -1, dtype=torch.int32)
+    do = torch.zeros((n * S,) + tuple(dout.shape[1:]))
+    for b, ids in enumerate(per):
+        bx[b * S:b * S + len(ids)] = boxes[ids]
+        bi[b * S:b * S + len(ids)] = b
+        do[b * S:b * S + len(ids)] = dout[ids]
+    do[bi < 0] = 7.0  # (garbage behind padding rows must not matter)
+    return bx, bi, do, S
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+def test_roi_align_backward_dense_matches_autograd_and_the_scatter_kernel(ops, dt):
+    """osr_roi_align_bwd_dense (pixel-centric gather, no atomics) on the lists of the two tests above, reordered image-major:
+    against autograd through the torch restatement of the forward, against the scatter kernel, and bit-reproducible."""
+    gg = g(83)
+    n, c = 2, 32
+    shapes = [(32, 48), (16, 24), (8, 12), (4, 6)]
+    m = 60
+    ctr = torch.rand(m, 2, generator=gg) * torch.tensor([192.0, 128.0])
+    size = torch.exp(torch.rand(m, 2, generator=gg) * 5.0 + 0.5)
+    boxes = torch.cat((ctr - size / 2, ctr + size / 2), dim=1)
+    boxes[0] = torch.tensor([-20.0, -10.0, 40.0, 30.0])
+    boxes[1] = torch.tensor([0.0, 0.0, 192.0, 128.0])
+    boxes[2] = torch.tensor([50.3, 60.2, 51.1, 61.0])    # sub-pixel
+    boxes[3] = torch.tensor([4.0, 100.0, 190.0, 104.0])  # wide and thin
+    bidx = torch.randint(0, n, (m,), generator=gg, dtype=torch.int32)
+    dout = torch.randn(m, 7, 7, c, generator=gg).to(dt).float()
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+    bx, bi, do, S = _image_major(boxes, bidx, dout, n)
+    got = ops.roi_align_bwd(do.to(dt).to(DEV), shapes, n, scales, bx.to(DEV), bi.to(DEV), rois_per_image=S)
+    again = ops.roi_align_bwd(do.to(dt).to(DEV), shapes, n, scales, bx.to(DEV), bi.to(DEV), rois_per_image=S)
+    scat = ops.roi_align_bwd(do.to(dt).to(DEV), shapes, n, scales, bx.to(DEV), bi.to(DEV))
+    lv = O.assign_levels(boxes)
+    for l, (h, w) in enumerate(shapes):
+        assert torch.equal(got[l], again[l]), "the gather has a fixed summation order"
+        assert rel(got[l], scat[l]) < 1e-5, f"level {l}: gather vs scatter"
+        feat = torch.zeros(n, c, h, w, requires_grad=True)
+        ids = torch.nonzero(lv == l).squeeze(1)
+        if len(ids) == 0:
+            assert float(got[l].abs().max()) == 0.0
+            continue
+        rois = torch.cat((bidx[ids].float().unsqueeze(1), boxes[ids]), dim=1)
+        O.roi_align_torch(feat, rois, scales[l]).backward(dout[ids].permute(0, 3, 1, 2))
+        assert rel(got[l].permute(0, 3, 1, 2), feat.grad) < 1e-4, f"level {l}"
+
+
+def test_roi_align_backward_dense_extreme_footprints_and_ragged_tiles(ops):
+    gg = g(84)
+    n, c, h, w = 2, 8, 117, 339  # not multiples of the 8 x 8 tile
+    boxes = torch.tensor([
+        [4.0, 100.0, 1300.0, 112.0], [300.0, 2.0, 330.0, 465.0], [10.0, 10.0, 700.0, 400.0], [50.3, 60.2, 51.1, 61.0],
+        [-40.0, -30.0, 90.0, 50.0], [1200.0, 400.0, 1400.0, 520.0], [0.0, 0.0, 1356.0, 468.0], [600.0, 200.0, 640.0, 203.0],
+    ])
+    bidx = torch.tensor([0, 1, 0, 1, 0, 1, 1, 0], dtype=torch.int32)
+    dout = torch.randn(len(boxes), 7, 7, c, generator=gg)
+    bx, bi, do, S = _image_major(boxes, bidx, dout, n)
+    got = ops.roi_align_bwd(do.to(DEV), [(h, w)], n, (0.25,), bx.to(DEV), bi.to(DEV), min_level=2, rois_per_image=S)[0].cpu()
+    feat = torch.zeros(n, c, h, w, requires_grad=True)
+    O.roi_align_torch(feat, torch.cat((bidx.float().unsqueeze(1), boxes), dim=1), 0.25).backward(dout.permute(0, 3, 1, 2))
+    assert rel(got.permute(0, 3, 1, 2), feat.grad) < 1e-4
+
+
 def test_elementwise_and_sgd(ops):
     gg = g(91)
     a = torch.randn(2, 9, 7, 16, generator=gg)
