@@ -61,7 +61,9 @@ struct WgradArgs {
 };
 
 #define WG_OOB 0x80000000u
+#ifndef WG_BM
 #define WG_BM 64  // rows (m) per pipeline step
+#endif
 
 // Tile TCO (output channels) x TCI (input channels) of one tap, WM x WN waves. Per step of 64 pixel rows the dy tile
 // [64][TCO] and the x tile [64][TCI] are staged row-major (LDS-DMA pieces of 1 KiB = 512/T rows); the 16-byte chunk c of row r
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(WgradArgs a
     // transposing fragment read: lane (g, q, pp) of a 16-lane group supplies the address of row 8g+4h+q, 4 elements at
     // column 16*sub + 4*pp of the wave's channels; it receives column (lane & 15) of the four rows.
     const int g = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
-    constexpr int NMF = 2 * SA * SB, PSTEP = (NMF / 2) / PPW > 0 ? (NMF / 2) / PPW : 1;  // pieces go out during the first half of a step
+    constexpr int NMF = (WG_BM / 32) * SA * SB, PSTEP = (NMF / 2) / PPW > 0 ? (NMF / 2) / PPW : 1;  // pieces go out during the first half of a step
     if (nsteps > 0) {
 #pragma unroll
         for (int q = 0; q < PPW; ++q) WG_PIECE(0, 0, q);
