@@ -589,10 +589,11 @@ osr_status osr_roi_align_bwd(const osr_pyramid* dfeat, int32_t n, const float* b
  * reproducible (fixed summation order: list order, bin row, bin column). The RoI list must be image-major with a fixed stride:
  * rows [b * rois_per_image, (b + 1) * rois_per_image) belong to image b (batch_idx == b) or are padding (batch_idx < 0);
  * m == n * rois_per_image, rois_per_image <= 1024, c <= 256. Otherwise OSR_ERR_UNSUPPORTED with nothing launched: zero dfeat and
- * call osr_roi_align_bwd. Same reference lines as osr_roi_align_bwd. */
+ * call osr_roi_align_bwd. out_dtype: OSR_F32, or dout's dtype -- the fp32 sums are then rounded once on the way out (what a separate
+ * cast of the fp32 pyramid would give), dfeat->data pointing at tensors of that type. Same reference lines as osr_roi_align_bwd. */
 osr_status osr_roi_align_bwd_dense(const osr_pyramid* dfeat, int32_t n, const float* boxes, const int32_t* batch_idx, int64_t m,
                                    int32_t rois_per_image, int32_t pooled, int32_t canonical_level, int32_t canonical_size, int32_t min_level,
-                                   const void* dout, int32_t dout_dtype, void* stream);
+                                   const void* dout, int32_t dout_dtype, int32_t out_dtype, void* stream);
 
 /* g[i] = act[i] > 0 ? g[i] : 0, in place (gradient through a ReLU whose output is act). */
 osr_status osr_relu_mask(void* g, int32_t g_dtype, const void* act, int32_t act_dtype, int64_t n, void* stream);

@@ -1166,7 +1166,7 @@ extern "C" osr_status osr_roi_align_bwd(const osr_pyramid* dfeat, int32_t n, con
 // ------------------------------------------------------------------------------------------------------
 #define RD_T 8
 struct RoiBwdDenseArgs {
-    float* data[4];
+    void* data[4];
     int h[4], w[4];
     float scale[4];
     int tiles_x[4], tiles_y[4], tile_off[5];  // tile grid of one image per level; first workgroup of each level
@@ -1177,7 +1177,7 @@ struct RoiBwdDenseArgs {
     const void* dout;
 };
 
-template <class TG>
+template <class TG, class TO>
 __global__ __launch_bounds__(256) void roi_align_bwd_dense_kernel(RoiBwdDenseArgs a) {
     __shared__ float s_w[2][2][RD_T][8];  // [buffer][axis: 0 = y, 1 = x][pixel row / column of the tile][bin] (axis 0 already / count)
     __shared__ unsigned short s_hits[1024];
@@ -1287,19 +1287,20 @@ __global__ __launch_bounds__(256) void roi_align_bwd_dense_kernel(RoiBwdDenseArg
     }
     // ---- 3. the tile, once ----
     if (chok) {
-        float* out = a.data[lv] + (size_t)b * H * W * C + ch;
+        TO* out = reinterpret_cast<TO*>(a.data[lv]) + (size_t)b * H * W * C + ch;
 #pragma unroll
         for (int y = 0; y < RD_T; ++y)
 #pragma unroll
             for (int x = 0; x < RD_T; ++x)
-                if (ty0 + y < H && tx0 + x < W) out[((size_t)(ty0 + y) * W + tx0 + x) * C] = acc[y * RD_T + x];
+                if (ty0 + y < H && tx0 + x < W) out[((size_t)(ty0 + y) * W + tx0 + x) * C] = osr_from_float<TO>(acc[y * RD_T + x]);
     }
 }
 
 extern "C" osr_status osr_roi_align_bwd_dense(const osr_pyramid* dfeat, int32_t n, const float* boxes, const int32_t* batch_idx, int64_t m,
                                               int32_t rois_per_image, int32_t pooled, int32_t canonical_level, int32_t canonical_size,
-                                              int32_t min_level, const void* dout, int32_t dout_dtype, void* stream) {
+                                              int32_t min_level, const void* dout, int32_t dout_dtype, int32_t out_dtype, void* stream) {
     OSR_REQUIRE(dfeat && boxes && batch_idx && dout, OSR_ERR_INVALID_ARG, "osr_roi_align_bwd_dense: null pointer");
+    OSR_REQUIRE(out_dtype == OSR_F32 || out_dtype == dout_dtype, OSR_ERR_UNSUPPORTED, "osr_roi_align_bwd_dense: out_dtype must be f32 or dout's dtype");
     OSR_REQUIRE(dfeat->num_levels >= 1 && dfeat->num_levels <= 4, OSR_ERR_INVALID_ARG, "osr_roi_align_bwd_dense: 1..4 levels, got %d", dfeat->num_levels);
     OSR_REQUIRE(pooled >= 1 && pooled <= 7, OSR_ERR_UNSUPPORTED, "osr_roi_align_bwd_dense: pooled size 1..7, got %d", pooled);
     OSR_REQUIRE(dfeat->c > 0 && dfeat->c <= 256, OSR_ERR_UNSUPPORTED, "osr_roi_align_bwd_dense: at most 256 channels, got %d", dfeat->c);
@@ -1312,7 +1313,7 @@ extern "C" osr_status osr_roi_align_bwd_dense(const osr_pyramid* dfeat, int32_t 
     for (int l = 0; l < 4; ++l) {
         const int s = l < dfeat->num_levels ? l : 0;
         OSR_REQUIRE(dfeat->data[s] && dfeat->h[s] > 0 && dfeat->w[s] > 0, OSR_ERR_INVALID_ARG, "osr_roi_align_bwd_dense: bad level %d", s);
-        a.data[l] = (float*)dfeat->data[s]; a.h[l] = dfeat->h[s]; a.w[l] = dfeat->w[s]; a.scale[l] = dfeat->scale[s];
+        a.data[l] = (void*)dfeat->data[s]; a.h[l] = dfeat->h[s]; a.w[l] = dfeat->w[s]; a.scale[l] = dfeat->scale[s];
         a.tiles_x[l] = (a.w[l] + RD_T - 1) / RD_T; a.tiles_y[l] = (a.h[l] + RD_T - 1) / RD_T;
         a.tile_off[l] = (int)off;
         if (l < dfeat->num_levels) off += (long long)n * a.tiles_x[l] * a.tiles_y[l];
@@ -1325,10 +1326,17 @@ extern "C" osr_status osr_roi_align_bwd_dense(const osr_pyramid* dfeat, int32_t 
     a.dout = dout;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)off), block(256);
+    const bool lowp_out = out_dtype != OSR_F32;
     switch (dout_dtype) {
-        case OSR_F32: hipLaunchKernelGGL(roi_align_bwd_dense_kernel<float>, grid, block, 0, st, a); break;
-        case OSR_F16: hipLaunchKernelGGL(roi_align_bwd_dense_kernel<f16_t>, grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL(roi_align_bwd_dense_kernel<bf16_t>, grid, block, 0, st, a); break;
+        case OSR_F32: hipLaunchKernelGGL((roi_align_bwd_dense_kernel<float, float>), grid, block, 0, st, a); break;
+        case OSR_F16:
+            if (lowp_out) hipLaunchKernelGGL((roi_align_bwd_dense_kernel<f16_t, f16_t>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((roi_align_bwd_dense_kernel<f16_t, float>), grid, block, 0, st, a);
+            break;
+        default:
+            if (lowp_out) hipLaunchKernelGGL((roi_align_bwd_dense_kernel<bf16_t, bf16_t>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((roi_align_bwd_dense_kernel<bf16_t, float>), grid, block, 0, st, a);
+            break;
     }
     OSR_CHECK_LAUNCH("osr_roi_align_bwd_dense");
     return OSR_OK;

@@ -139,7 +139,7 @@ PROTOTYPES = {
     "osr_pln_loss_bwd": (I32, [P, I64, I32, P, I32, P, P, F32, F32, F32, F32, F32, P, P, I32, P, I64, P]),
     "osr_pln_loss_bwd_ex": (I32, [P, I64, I32, P, I32, I32, I32, P, P, F32, F32, F32, F32, F32, P, P, I32, P, I64, P]),
     "osr_roi_align_bwd": (I32, [P, I32, P, P, I64, I32, I32, I32, I32, P, I32, P]),
-    "osr_roi_align_bwd_dense": (I32, [P, I32, P, P, I64, I32, I32, I32, I32, I32, P, I32, P]),
+    "osr_roi_align_bwd_dense": (I32, [P, I32, P, P, I64, I32, I32, I32, I32, I32, P, I32, I32, P]),
     "osr_relu_mask": (I32, [P, I32, P, I32, I64, P]),
     "osr_add_cast": (I32, [P, P, P, I32, I64, P]),
     "osr_pool_bwd": (I32, [P, I32, I32, P, P, I32, I32, I32, I32, I32, I32, P]),

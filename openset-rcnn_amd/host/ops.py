@@ -985,30 +985,37 @@ def pln_loss_bwd(emb, protos_raw, gt_classes, ious, iou_thr: float, alpha: float
 
 
 def roi_align_bwd(dout: torch.Tensor, shapes: Sequence[Tuple[int, int]], n: int, scales: Sequence[float], boxes, batch_idx,
-                  canonical_level: int = 4, canonical_size: int = 224, min_level: int = 2, rois_per_image: Optional[int] = None) -> List[torch.Tensor]:
-    """dout (m,P,P,c) -> list of fp32 (n,h,w,c) feature gradients, one per level. rois_per_image: the list is image-major with this
+                  canonical_level: int = 4, canonical_size: int = 224, min_level: int = 2, rois_per_image: Optional[int] = None,
+                  out_dtype: Optional[torch.dtype] = None) -> List[torch.Tensor]:
+    """dout (m,P,P,c) -> list of (n,h,w,c) feature gradients, one per level: fp32, or out_dtype (= dout's dtype: the fp32 sums rounded
+    once; the scatter path casts afterwards). rois_per_image: the list is image-major with this
     fixed stride (rows [b*S, (b+1)*S) are image b's or padding) -- the pixel-centric kernel then gathers (osr_roi_align_bwd_dense: no
     atomics, no zero fill, reproducible bit for bit); otherwise the scatter kernel adds into a zeroed pyramid with fp32 atomics."""
     lib = _lib.load()
     _need(dout, name="dout"); _need(boxes, torch.float32, "boxes"); _need(batch_idx, torch.int32, "batch_idx")
     m, pooled, _, c = dout.shape
     dense = rois_per_image is not None and m == n * rois_per_image and rois_per_image <= 1024 and c <= 256
-    outs = [(torch.empty if dense else torch.zeros)((n, h, w, c), dtype=torch.float32, device=dout.device) for h, w in shapes]
+    if out_dtype not in (None, torch.float32, dout.dtype):
+        raise OsrError("roi_align_bwd: out_dtype must be float32 or dout's dtype")
+    odt = out_dtype or torch.float32
+    outs = [torch.empty((n, h, w, c), dtype=odt, device=dout.device) if dense else torch.zeros((n, h, w, c), dtype=torch.float32, device=dout.device)
+            for h, w in shapes]
     py = Pyramid()
     py.num_levels, py.c = len(outs), c
     for i, (f, s) in enumerate(zip(outs, scales)):
         py.h[i], py.w[i], py.scale[i], py.data[i] = f.shape[1], f.shape[2], float(s), f.data_ptr()
     if dense:
         st = lib.osr_roi_align_bwd_dense(C.byref(py), n, _p(boxes), _p(batch_idx), m, int(rois_per_image), pooled, canonical_level, canonical_size,
-                                         min_level, _p(dout), _DT[dout.dtype], _stream())
+                                         min_level, _p(dout), _DT[dout.dtype], _DT[odt], _stream())
         if st != _lib.ERR_UNSUPPORTED:
             check(st, "osr_roi_align_bwd_dense")
             return outs
-        for f in outs:
-            f.zero_()
+        outs = [torch.zeros((n, h, w, c), dtype=torch.float32, device=dout.device) for h, w in shapes]
+        for i, f in enumerate(outs):
+            py.data[i] = f.data_ptr()
     check(lib.osr_roi_align_bwd(C.byref(py), n, _p(boxes), _p(batch_idx), m, pooled, canonical_level, canonical_size, min_level, _p(dout),
                                 _DT[dout.dtype], _stream()), "osr_roi_align_bwd")
-    return outs
+    return outs if odt == torch.float32 else [add_cast(f, None, odt) for f in outs]
 
 
 def relu_mask_(g: torch.Tensor, act: torch.Tensor) -> torch.Tensor:

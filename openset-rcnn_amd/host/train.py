@@ -432,7 +432,8 @@ class OpensetRCNNTrainer:
         P = c["pooler_resolution"]
         shapes = [(p[k].shape[1], p[k].shape[2]) for k in ("p2", "p3", "p4", "p5")]
         d_feat = ops.roi_align_bwd(d_pooled.view(m, P, P, -1), shapes, n, c["pooler_scales"], s["boxes"], s["smp"]["batch_idx"], c["canonical_level"],
-                                   c["canonical_size"], 2, rois_per_image=m // n if m % n == 0 else None)  # (the sampled list is (n, S))
+                                   c["canonical_size"], 2, rois_per_image=m // n if m % n == 0 else None,  # (the sampled list is (n, S))
+                                   out_dtype=dt if d_pooled.dtype == dt else None)
         # --- CF-RPN 3x3 conv: data gradient per level, joined with the RoI heads' feature gradient (the chain above it ran on the
         #     second stream, see the top of this function) ---
         if self.side_wgrad:
@@ -445,7 +446,7 @@ class OpensetRCNNTrainer:
             rows = n * h * w
             dtl = dt_all[off:off + rows].view(n, h, w, 256)
             off += rows
-            roi_part = ops.add_cast(d_feat[li], None, dt) if li < 4 else None
+            roi_part = (d_feat[li] if d_feat[li].dtype == dt else ops.add_cast(d_feat[li], None, dt)) if li < 4 else None
             dP[k] = ops.conv2d_dgrad(dtl, self.wd[rn], (h, w), 1, 1, add=roi_part)
         h5, w5 = p["p5"].shape[1], p["p5"].shape[2]
         dP["p5"] = ops.pool_bwd(dP["p6"], (h5, w5), dP["p5"], 1)  # p6 = p5[::2, ::2]

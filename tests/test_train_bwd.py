@@ -208,6 +208,10 @@ def test_roi_align_backward_dense_matches_autograd_and_the_scatter_kernel(ops, d
     got = ops.roi_align_bwd(do.to(dt).to(DEV), shapes, n, scales, bx.to(DEV), bi.to(DEV), rois_per_image=S)
     again = ops.roi_align_bwd(do.to(dt).to(DEV), shapes, n, scales, bx.to(DEV), bi.to(DEV), rois_per_image=S)
     scat = ops.roi_align_bwd(do.to(dt).to(DEV), shapes, n, scales, bx.to(DEV), bi.to(DEV))
+    if dt != torch.float32:  # the storage dtype straight from the kernel = the fp32 sums rounded once
+        low = ops.roi_align_bwd(do.to(dt).to(DEV), shapes, n, scales, bx.to(DEV), bi.to(DEV), rois_per_image=S, out_dtype=dt)
+        for l in range(len(shapes)):
+            assert low[l].dtype == dt and torch.equal(low[l], got[l].to(dt))
     lv = O.assign_levels(boxes)
     for l, (h, w) in enumerate(shapes):
         assert torch.equal(got[l], again[l]), "the gather has a fixed summation order"
