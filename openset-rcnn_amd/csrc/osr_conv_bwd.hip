@@ -106,43 +106,68 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(WgradArgs a
 
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, a.dy_bytes, 0x00020000);
-    const bool plain = p.kh == 1 && p.kw == 1 && p.stride_h == 1 && p.stride_w == 1 && p.pad_h == 0 && p.pad_w == 0 &&
-                       p.in_stride_h == (long long)p.wi * p.in_stride_w && p.in_stride_n == (long long)p.hi * p.in_stride_h;  // x rows are linear in m
+
+    // ---- staging addresses, kept INCREMENTALLY. A lane serves the same row-in-step and chunk of every step; from one step to the next
+    // its pixel row advances by WG_BM. Round 1-2 recomputed (n, oh, ow) of every piece with two magic-number divisions and three
+    // 64-bit multiplies per piece and step, inside the MFMA loop: 163 quarter-rate v_mul_lo_u32 and ~150 exec-masked branches in the
+    // loop body, 3.1 other vector instructions per MFMA (rocprofv3 SQ_INSTS_VALU / SQ_INSTS_MFMA). Now: the lane's FIRST piece keeps
+    // (ih, iw, byte offset of its tap pixel) and advances them by WG_BM rows per step with adds and wraps; the wave's other pieces
+    // sit a fixed number of rows further on and are derived with adds and one wrap. No division, no 32-bit multiply in the loop. ----
+#define WG_SW(r) ((((r) & 3) | ((((r) >> 3) & 1) << 2)) << 1)
+    constexpr int CPRY = YB / 16, RPPY = 1024 / YB, CPRX = XB / 16, RPPX = 1024 / XB;
+    const int rowy0 = wid * YPW * RPPY + lane / CPRY, rowx0 = wid * XPW * RPPX + lane / CPRX;  // piece q: + q * RPP rows
+    // dy: offset of (row m, co0) grows by cout elements per row
+    unsigned ybase = (unsigned)(((m_begin + rowy0) * p.cout + co0) * 2);
+    const unsigned ystep = (unsigned)((long long)WG_BM * p.cout * 2), yrow = (unsigned)(p.cout * 2);
+    long long my = m_begin + rowy0, mx = m_begin + rowx0;  // pixel rows of the first pieces at the current step
+    // x: input coordinates (ih, iw) of pixel mx's tap (kh, kw) and their byte offset at channel ci0 (wraps below zero in the padding).
+    // Output column + 1 = iw + stride_w; past the last output column (iw >= iw_lim) the next output row starts: iw -= wo * stride_w,
+    // ih += stride_h; past the last output row the next image.
+    int xih, xiw;
+    unsigned xbase;
+    {
+        const long long mm = mx < a.M ? mx : 0;
+        const unsigned mu = (unsigned)mm, ni = wdiv(mu, a.div_howo), rem = mu - ni * a.div_howo.d;
+        const int oh0 = (int)wdiv(rem, a.div_wo), ow0 = (int)(rem - (unsigned)oh0 * a.div_wo.d);
+        xih = oh0 * p.stride_h - p.pad_h + kh; xiw = ow0 * p.stride_w - p.pad_w + kw;
+        xbase = (unsigned)(((long long)ni * p.in_stride_n + (long long)xih * p.in_stride_h + (long long)xiw * p.in_stride_w + ci0) * 2);
+    }
+    const unsigned x_dw = (unsigned)(p.stride_w * p.in_stride_w * 2);                                     // ow + 1
+    const unsigned x_wrap_w = (unsigned)((p.stride_h * p.in_stride_h - (long long)p.wo * p.stride_w * p.in_stride_w) * 2);  // ow -= wo, oh + 1
+    const unsigned x_wrap_h = (unsigned)((p.in_stride_n - (long long)p.ho * p.stride_h * p.in_stride_h) * 2);              // oh -= ho, image + 1
+    const int iw_lim = p.wo * p.stride_w - p.pad_w + kw, ih_lim = p.ho * p.stride_h - p.pad_h + kh;
+    const int iw_span = p.wo * p.stride_w, ih_span = p.ho * p.stride_h;
 
     // one staging piece: q < YPW -> dy rows, else x rows (gathered through the conv geometry)
-#define WG_SW(r) ((((r) & 3) | ((((r) >> 3) & 1) << 2)) << 1)
 #define WG_PIECE(stage, step, q)                                                                                                \
     {                                                                                                                           \
         unsigned char* sy_ = lds + (stage) * STAGE;                                                                             \
         if ((q) < YPW) {                                                                                                        \
-            constexpr int CPR = YB / 16, RPP = 1024 / YB; /* chunks per row, rows per piece */                                  \
-            const int pc_ = wid * YPW + ((q) < YPW ? (q) : 0);                                                                  \
-            const int row_ = pc_ * RPP + lane / CPR;                                                                            \
-            const long long m_ = m_begin + (long long)(step) * WG_BM + row_;                                                    \
-            const int chunk_ = (lane % CPR) ^ WG_SW(row_);                                                                      \
-            const unsigned yoff_ = (m_ < m_end && co0 + chunk_ * 8 < p.cout) ? (unsigned)((m_ * p.cout + co0 + chunk_ * 8) * 2) : WG_OOB; \
+            const int qq_ = (q) < YPW ? (q) : 0;                                                                                \
+            const int pc_ = wid * YPW + qq_;                                                                                    \
+            const int row_ = rowy0 + qq_ * RPPY;                                                                                \
+            const int chunk_ = (lane % CPRY) ^ WG_SW(row_);                                                                     \
+            const unsigned yoff_ = (my + qq_ * RPPY < m_end && co0 + chunk_ * 8 < p.cout) ? ybase + (unsigned)qq_ * RPPY * yrow + (unsigned)chunk_ * 16u : WG_OOB; \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_t*)(sy_ + pc_ * 1024), 16, yoff_, 0, 0, 0);                  \
         } else {                                                                                                                \
-            constexpr int CPR = XB / 16, RPP = 1024 / XB;                                                                       \
-            const int pc_ = wid * XPW + ((q) >= YPW ? (q) - YPW : 0);                                                           \
-            const int row_ = pc_ * RPP + lane / CPR;                                                                            \
-            const long long m_ = m_begin + (long long)(step) * WG_BM + row_;                                                    \
-            const int chunk_ = (lane % CPR) ^ WG_SW(row_);                                                                      \
-            unsigned xoff_ = WG_OOB;                                                                                            \
-            if (m_ < m_end && ci0 + chunk_ * 8 < p.cin) {                                                                       \
-                if (plain) {                                                                                                    \
-                    xoff_ = (unsigned)((m_ * p.in_stride_w + ci0 + chunk_ * 8) * 2);                                             \
-                } else {                                                                                                        \
-                    const unsigned mu_ = (unsigned)m_;                                                                          \
-                    const unsigned ni_ = wdiv(mu_, a.div_howo), rem_ = mu_ - ni_ * a.div_howo.d;                                 \
-                    const unsigned oh_ = wdiv(rem_, a.div_wo), ow_ = rem_ - oh_ * a.div_wo.d;                                    \
-                    const int ih_ = (int)oh_ * p.stride_h - p.pad_h + kh, iw_ = (int)ow_ * p.stride_w - p.pad_w + kw;            \
-                    if ((unsigned)ih_ < (unsigned)p.hi && (unsigned)iw_ < (unsigned)p.wi)                                        \
-                        xoff_ = (unsigned)(((long long)ni_ * p.in_stride_n + (long long)ih_ * p.in_stride_h + (long long)iw_ * p.in_stride_w + ci0 + chunk_ * 8) * 2); \
-                }                                                                                                               \
-            }                                                                                                                   \
+            const int qq_ = (q) >= YPW ? (q) - YPW : 0;                                                                         \
+            const int pc_ = wid * XPW + qq_;                                                                                    \
+            const int row_ = rowx0 + qq_ * RPPX;                                                                                \
+            const int chunk_ = (lane % CPRX) ^ WG_SW(row_);                                                                     \
+            int iw_ = xiw + qq_ * RPPX * p.stride_w, ih_ = xih;                                                                 \
+            unsigned off_ = xbase + (unsigned)(qq_ * RPPX) * x_dw;                                                              \
+            while (iw_ >= iw_lim) { iw_ -= iw_span; ih_ += p.stride_h; off_ += x_wrap_w; if (ih_ >= ih_lim) { ih_ -= ih_span; off_ += x_wrap_h; } } \
+            const bool ok_ = mx + qq_ * RPPX < m_end && ci0 + chunk_ * 8 < p.cin && (unsigned)ih_ < (unsigned)p.hi && (unsigned)iw_ < (unsigned)p.wi; \
+            const unsigned xoff_ = ok_ ? off_ + (unsigned)chunk_ * 16u : WG_OOB;                                                 \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(sy_ + WG_BM * YB + pc_ * 1024), 16, xoff_, 0, 0, 0);    \
         }                                                                                                                       \
+    }
+    // the state moves on by one step (WG_BM rows): called once all pieces of a step have been issued
+#define WG_ADVANCE()                                                                                                            \
+    {                                                                                                                           \
+        my += WG_BM; mx += WG_BM; ybase += ystep;                                                                               \
+        xiw += WG_BM * p.stride_w; xbase += (unsigned)WG_BM * x_dw;                                                             \
+        while (xiw >= iw_lim) { xiw -= iw_span; xih += p.stride_h; xbase += x_wrap_w; if (xih >= ih_lim) { xih -= ih_span; xbase += x_wrap_h; } } \
     }
 
     f32x4 acc[SA][SB];  // [co sub-tile][ci sub-tile]: rows = output channels, columns = input channels
@@ -158,6 +183,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(WgradArgs a
     if (nsteps > 0) {
 #pragma unroll
         for (int q = 0; q < PPW; ++q) WG_PIECE(0, 0, q);
+        WG_ADVANCE();
     }
     for (int s = 0; s < nsteps; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -202,7 +228,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(WgradArgs a
                     acc[i][j] = FragW<TI>::mfma(fa[i], fb[j], acc[i][j]);
                     const int done = (kk * SA + i) * SB + j + 1;
                     if (done % PSTEP == 0 && done / PSTEP <= PPW) {
-                        if (more) WG_PIECE(nst, s + 1, done / PSTEP - 1);
+                        if (more) {
+                            WG_PIECE(nst, s + 1, done / PSTEP - 1);
+                            if (done / PSTEP == PPW) { WG_ADVANCE(); }
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
