@@ -237,17 +237,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(WgradArgs a
                 }
         }
     }
-    // partial[split][co][tap][ci]: C/D layout col = lane&15 (ci), row = (lane>>4)*4 + r (co)
+    // partial[split][co][tap][ci]: C/D layout col = lane&15 (ci), row = (lane>>4)*4 + r (co). (Offsets by additions: the 128 stores of
+    // the big tile used to cost two 32-bit multiplies each.)
     float* out = a.partial + (long long)split * p.cout * a.taps * p.cin;
+    const long long rstride = (long long)a.taps * p.cin;  // one output channel further
+    const int co_b = co0 + wr * SA * 16 + (lane >> 4) * 4, ci_b = ci0 + wc * SB * 16 + (lane & 15);
+    const long long obase = ((long long)co_b * a.taps + tap) * p.cin + ci_b;
 #pragma unroll
     for (int i = 0; i < SA; ++i)
 #pragma unroll
         for (int j = 0; j < SB; ++j) {
-            const int ci = ci0 + (wc * SB + j) * 16 + (lane & 15);
+            const int ci = ci_b + j * 16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = co0 + (wr * SA + i) * 16 + (lane >> 4) * 4 + r;
-                if (co < p.cout && ci < p.cin) out[((long long)co * a.taps + tap) * p.cin + ci] = acc[i][j][r];
+                const int co = co_b + i * 16 + r;
+                if (co < p.cout && ci < p.cin) out[obase + (i * 16 + r) * rstride + j * 16] = acc[i][j][r];
             }
         }
 }
