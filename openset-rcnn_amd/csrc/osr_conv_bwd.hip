@@ -64,6 +64,9 @@ struct WgradArgs {
 #ifndef WG_BM
 #define WG_BM 64  // rows (m) per pipeline step
 #endif
+#ifndef WG_NST
+#define WG_NST 2  // staging buffers: the pieces of step s + WG_NST - 1 are in flight under step s
+#endif
 
 // Tile TCO (output channels) x TCI (input channels) of one tap, WM x WN waves. Per step of 64 pixel rows the dy tile
 // [64][TCO] and the x tile [64][TCI] are staged row-major (LDS-DMA pieces of 1 KiB = 512/T rows); the 16-byte chunk c of row r
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(WgradArgs a
     constexpr int PPW = (YP + XP) / NW;                         // pieces per wave and step
     static_assert((YP + XP) % NW == 0 && YP % NW == 0, "pieces must divide over the waves, dy pieces first");
     constexpr int YPW = YP / NW, XPW = XP / NW;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // 2 stages
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // WG_NST stages
     typedef typename FragW<TI>::type frag_t;
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     const osr_conv_params& p = a.p;
@@ -180,18 +183,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(WgradArgs a
     // column 16*sub + 4*pp of the wave's channels; it receives column (lane & 15) of the four rows.
     const int g = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
     constexpr int NMF = (WG_BM / 32) * SA * SB, PSTEP = (NMF / 2) / PPW > 0 ? (NMF / 2) / PPW : 1;  // pieces go out during the first half of a step
+    // (pieces are issued for every step up to nsteps + WG_NST - 2: rows past m_end are zero fills into buffers nothing reads, and the
+    // counted wait below stays exact)
     if (nsteps > 0) {
 #pragma unroll
-        for (int q = 0; q < PPW; ++q) WG_PIECE(0, 0, q);
-        WG_ADVANCE();
+        for (int ps = 0; ps < WG_NST - 1; ++ps) {
+#pragma unroll
+            for (int q = 0; q < PPW; ++q) WG_PIECE(ps, ps, q);
+            WG_ADVANCE();
+        }
     }
     for (int s = 0; s < nsteps; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WG_NST - 2) * PPW) : "memory");
         __syncthreads();
-        const bool more = s + 1 < nsteps;
-        const unsigned char* sy = lds + (s & 1) * STAGE;
+        const bool more = true;
+        const unsigned char* sy = lds + (s % WG_NST) * STAGE;
         const unsigned char* sx = sy + WG_BM * YB;
-        const int nst = (s + 1) & 1;
+        const int nst = (s + WG_NST - 1) % WG_NST;
 #pragma unroll
         for (int kk = 0; kk < WG_BM / 32; ++kk) {
             s16x4 va[2][SA], vb[2][SB];
@@ -237,6 +245,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(WgradArgs a
                 }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the tail's zero-fill pieces)
     // partial[split][co][tap][ci]: C/D layout col = lane&15 (ci), row = (lane>>4)*4 + r (co). (Offsets by additions: the 128 stores of
     // the big tile used to cost two 32-bit multiplies each.)
     float* out = a.partial + (long long)split * p.cout * a.taps * p.cin;
@@ -343,7 +352,7 @@ extern "C" osr_status osr_conv2d_wgrad(const osr_conv_params* p, const void* x, 
     OSR_REQUIRE(grid < (1ll << 31), OSR_ERR_UNSUPPORTED, "osr_conv2d_wgrad: grid too large");
     hipStream_t st = (hipStream_t)stream;
     if (big) {
-        const size_t ldsb = 2 * WG_BM * (256 + 256) * 2;  // 128 KiB
+        const size_t ldsb = (size_t)WG_NST * WG_BM * (256 + 256) * 2;  // 128 KiB
         static osr_dev_mask attr{0};
         osr_once_per_device(attr, [] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<f16_t, 256, 256, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -352,7 +361,7 @@ extern "C" osr_status osr_conv2d_wgrad(const osr_conv_params* p, const void* x, 
         if (p->in_dtype == OSR_F16) hipLaunchKernelGGL((conv_wgrad_kernel<f16_t, 256, 256, 2, 4>), dim3((unsigned)grid), dim3(512), ldsb, st, a);
         else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 256, 256, 2, 4>), dim3((unsigned)grid), dim3(512), ldsb, st, a);
     } else {
-        const size_t ldsb = 2 * WG_BM * (128 + 128) * 2;  // 64 KiB
+        const size_t ldsb = (size_t)WG_NST * WG_BM * (128 + 128) * 2;  // 64 KiB
         if (p->in_dtype == OSR_F16) hipLaunchKernelGGL((conv_wgrad_kernel<f16_t, 128, 128, 2, 2>), dim3((unsigned)grid), dim3(256), ldsb, st, a);
         else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 128, 128, 2, 2>), dim3((unsigned)grid), dim3(256), ldsb, st, a);
     }
