@@ -27,6 +27,7 @@ SOURCES = {
     "osr_bottleneck.hip": [],
     "osr_rpn.hip": ["-ffp-contract=off"],
     "osr_roi_align.hip": ["-ffp-contract=off"],
+    "osr_roi_tiled.hip": ["-ffp-contract=off"],
     "osr_det_tail.hip": ["-ffp-contract=off"],
     "osr_train_fwd.hip": ["-ffp-contract=off"],
     "osr_conv_bwd.hip": [],

@@ -48,6 +48,8 @@ struct RoiAlignArgs {
     void* out;
     const int* order;  // processing order of the RoIs (a permutation of 0..m-1) or null: the result does not depend on it
     const int* order_nvalid;  // (with order) how many leading entries of it are real RoIs, the rest padding rows; null: unknown
+    const int* skip;   // optional (osr_roi_align_fwd_masked): RoI r is left alone when skip[r] >= 0 (the tiled kernel has pooled it)
+    int slice_major;   // 0: out[r][ph][pw][c]; 1: out[r][c / 16][ph][pw][c % 16] (the tiled kernel's row layout, osr_roi_tiled.hip)
 };
 
 template <class T> struct Vec4;
@@ -472,8 +474,13 @@ __global__ __launch_bounds__(RA_THREADS, RA_MINW) void roi_align_kernel(RoiAlign
     }
     if (r >= a.m) return;
     if (a.order) r = a.order[r];
+    if (a.skip && a.skip[r] >= 0) return;
     RaWaveLds& S = s_all[grp];
     const int P = a.pooled, C = a.c;
+    // element stride between two bins of a row and the offset of channel c0 inside the row (c0 is a multiple of 4 or 8: it never
+    // straddles a 16-channel slice)
+    const int CE = a.slice_major ? 16 : C;
+#define RA_CBASE(c0) (a.slice_major ? (size_t)((c0) >> 4) * P * P * 16 + ((c0) & 15) : (size_t)(c0))
     TO* out = reinterpret_cast<TO*>(a.out) + (size_t)r * P * P * C;
 
     const int b = a.batch_idx[r];
@@ -591,7 +598,7 @@ __global__ __launch_bounds__(RA_THREADS, RA_MINW) void roi_align_kernel(RoiAlign
         // byte strides of one step along the inner / outer axis, and the element stride between two consecutive output bins of the outer axis
         const int rowstride_b = W * C * (int)sizeof(TI), pix_b = C * (int)sizeof(TI);
         const int istride_b = ia == 0 ? rowstride_b : pix_b, sstride_b = ia == 0 ? pix_b : rowstride_b;
-        const size_t ostride = oa == 1 ? (size_t)C : (size_t)P * C;
+        const size_t ostride = oa == 1 ? (size_t)CE : (size_t)P * CE;
         for (int pb = sub; pb < P; pb += RA_WPR) {  // bins along the inner axis
             const int i0 = __builtin_amdgcn_readfirstlane(S.lo[ia][pb]), ni = __builtin_amdgcn_readfirstlane(S.n[ia][pb]);
             float wi[6];  // wave-uniform inner weights (live in scalar registers)
@@ -604,7 +611,7 @@ __global__ __launch_bounds__(RA_THREADS, RA_MINW) void roi_align_kernel(RoiAlign
                     const int c0 = cb0 + (lane & 31) * 8;
                     const bool cok = c0 < C;
                     const int voff = (cok ? c0 : 0) * (int)sizeof(TI) + half * sstride_b;
-                    TO* outrow = out + (size_t)pb * (oa == 1 ? (size_t)P * C : (size_t)C) + c0;
+                    TO* outrow = out + (size_t)pb * (oa == 1 ? (size_t)P * CE : (size_t)CE) + RA_CBASE(c0);
                     switch (ni) {
                         case 1: ra_bin_row_pair<1, TI, TO>(rs, voff, base, istride_b, sstride_b, nstep, S, half, wi, inv_count, outrow, ostride, cok, P); break;
                         case 2: ra_bin_row_pair<2, TI, TO>(rs, voff, base, istride_b, sstride_b, nstep, S, half, wi, inv_count, outrow, ostride, cok, P); break;
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(RA_THREADS, RA_MINW) void roi_align_kernel(RoiAlign
                 const int c0 = cb0 + lane * 4;
                 const bool cok = c0 < C;
                 const int voff = (cok ? c0 : 0) * (int)sizeof(TI);
-                TO* outrow = out + (size_t)pb * (oa == 1 ? (size_t)P * C : (size_t)C) + c0;
+                TO* outrow = out + (size_t)pb * (oa == 1 ? (size_t)P * CE : (size_t)CE) + RA_CBASE(c0);
                 switch (nstep > 0 ? (ni > 6 ? 7 : ni) : 0) {  // (no step: the pipelined loop would have nothing valid to prefetch)
                     case 1: ra_bin_row<1, TI, TO>(rs, voff, base, istride_b, sstride_b, nstep, S, wi, inv_count, outrow, ostride, cok, P); break;
                     case 2: ra_bin_row<2, TI, TO>(rs, voff, base, istride_b, sstride_b, nstep, S, wi, inv_count, outrow, ostride, cok, P); break;
@@ -674,7 +681,7 @@ __global__ __launch_bounds__(RA_THREADS, RA_MINW) void roi_align_kernel(RoiAlign
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) acc[k] = acc[k] / count;
-                store4<TO>(out + (size_t)(ph * P + pw) * C + c0, acc);
+                store4<TO>(out + (size_t)(ph * P + pw) * CE + RA_CBASE(c0), acc);
             }
         }
     }
@@ -692,10 +699,10 @@ static osr_status launch_out(const RoiAlignArgs& a, int out_dtype, hipStream_t s
     return OSR_OK;
 }
 
-extern "C" osr_status osr_roi_align_fwd_ordered(const osr_pyramid* f, int32_t feat_dtype, int32_t n, const float* boxes,
-                                                const int32_t* batch_idx, int64_t m, int32_t pooled, int32_t canonical_level,
-                                                int32_t canonical_size, int32_t min_level, const int32_t* order,
-                                                const int32_t* order_nvalid, void* out, int32_t out_dtype, void* stream) {
+static osr_status roi_align_fwd_impl(const osr_pyramid* f, int32_t feat_dtype, int32_t n, const float* boxes,
+                                     const int32_t* batch_idx, int64_t m, int32_t pooled, int32_t canonical_level,
+                                     int32_t canonical_size, int32_t min_level, const int32_t* order,
+                                     const int32_t* order_nvalid, const int32_t* skip, int32_t slice_major, void* out, int32_t out_dtype, void* stream) {
     OSR_REQUIRE(f && boxes && batch_idx && out, OSR_ERR_INVALID_ARG, "osr_roi_align_fwd: null pointer");
     OSR_REQUIRE(f->num_levels >= 1 && f->num_levels <= 4, OSR_ERR_INVALID_ARG, "osr_roi_align_fwd: 1..4 levels, got %d", f->num_levels);
     OSR_REQUIRE(pooled >= 1 && pooled <= 7, OSR_ERR_UNSUPPORTED, "osr_roi_align_fwd: pooled size 1..7, got %d", pooled);
@@ -713,12 +720,33 @@ extern "C" osr_status osr_roi_align_fwd_ordered(const osr_pyramid* f, int32_t fe
     a.num_levels = f->num_levels; a.c = f->c; a.boxes = boxes; a.batch_idx = batch_idx; a.m = m;
     a.pooled = pooled; a.canonical_level = canonical_level; a.canonical_size = canonical_size; a.min_level = min_level;
     a.out = out; a.order = order; a.order_nvalid = order ? order_nvalid : nullptr;
+    a.skip = skip; a.slice_major = slice_major;
+    OSR_REQUIRE(!slice_major || f->c % 16 == 0, OSR_ERR_UNSUPPORTED, "osr_roi_align_fwd: the slice-major row layout needs channels % 16 == 0, got %d", f->c);
     hipStream_t st = (hipStream_t)stream;
     switch (feat_dtype) {
         case OSR_F32: return launch_out<float>(a, out_dtype, st);
         case OSR_F16: return launch_out<f16_t>(a, out_dtype, st);
         default: return launch_out<bf16_t>(a, out_dtype, st);
     }
+}
+
+extern "C" osr_status osr_roi_align_fwd_ordered(const osr_pyramid* f, int32_t feat_dtype, int32_t n, const float* boxes,
+                                                const int32_t* batch_idx, int64_t m, int32_t pooled, int32_t canonical_level,
+                                                int32_t canonical_size, int32_t min_level, const int32_t* order,
+                                                const int32_t* order_nvalid, void* out, int32_t out_dtype, void* stream) {
+    return roi_align_fwd_impl(f, feat_dtype, n, boxes, batch_idx, m, pooled, canonical_level, canonical_size, min_level, order, order_nvalid,
+                              nullptr, 0, out, out_dtype, stream);
+}
+
+// The wave-per-RoI kernel for the RoIs the tiled kernel left (skip[r] < 0: -1 = not on its path, -2 = padding row, zero-filled
+// here), writing the tiled kernel's slice-major rows into the same buffer.
+extern "C" osr_status osr_roi_align_fwd_masked(const osr_pyramid* f, int32_t feat_dtype, int32_t n, const float* boxes,
+                                               const int32_t* batch_idx, int64_t m, int32_t pooled, int32_t canonical_level,
+                                               int32_t canonical_size, int32_t min_level, const int32_t* skip, int32_t slice_major,
+                                               void* out, int32_t out_dtype, void* stream) {
+    OSR_REQUIRE(skip, OSR_ERR_INVALID_ARG, "osr_roi_align_fwd_masked: null pointer");
+    return roi_align_fwd_impl(f, feat_dtype, n, boxes, batch_idx, m, pooled, canonical_level, canonical_size, min_level, nullptr, nullptr,
+                              skip, slice_major, out, out_dtype, stream);
 }
 
 extern "C" osr_status osr_roi_align_fwd(const osr_pyramid* f, int32_t feat_dtype, int32_t n, const float* boxes,

@@ -41,7 +41,13 @@ class DynamicLossScale:
     sync). `record(flag)` queues that flag's copy into a slot of its own right after an update; `poll(wait)` applies the verdicts
     of the updates that have finished -- an overflow halves the scale (floor 1.0), `growth_interval` consecutive clean updates
     double it again, never past the configured scale (what torch's GradScaler does) -- so no verdict is ever overwritten however
-    far the host runs ahead of the GPU, and the scale is not a one-way ratchet."""
+    far the host runs ahead of the GPU, and the scale is not a one-way ratchet.
+
+    The same slot carries the iteration's PROPOSAL STATUS word (osr_rpn_select's status_flags: non-zero when a predicted box or
+    score was Inf / NaN). The reference raises FloatingPointError for that in training (find_top_proposals.py:96-101); here the
+    word rides with the overflow verdict -- no extra host sync -- and `poll` raises the same exception when it drains the slot."""
+
+    DIVERGED = "Predicted boxes or scores contain Inf/NaN. Training has diverged."  # find_top_proposals.py:99-101
 
     def __init__(self, scale: float, growth_interval: int = 2000, device: Optional[torch.device] = None):
         self.scale, self.scale_max, self.growth_interval = float(scale), float(scale), int(growth_interval)
@@ -51,15 +57,20 @@ class DynamicLossScale:
         self.overflow_steps = 0
         self.clean_steps = 0  # consecutive clean updates since the last overflow / growth
 
-    def record(self, ok_flag: torch.Tensor) -> None:
-        """ok_flag: (1,) int32 on the trainer's device, 1 = the update just enqueued was applied, 0 = skipped."""
+    def record(self, ok_flag: torch.Tensor, proposal_status: Optional[torch.Tensor] = None) -> None:
+        """ok_flag: (1,) int32 on the trainer's device, 1 = the update just enqueued was applied, 0 = skipped.
+        proposal_status: (1,) int32, osr_rpn_select's status word of the same iteration (0 = every prediction finite)."""
         if self.free:
             slot = self.free.pop()
         else:
-            slot = torch.ones((1,), dtype=torch.int32)
+            slot = torch.ones((2,), dtype=torch.int32)
             if self.cuda:
                 slot = slot.pin_memory()
-        slot.copy_(ok_flag, non_blocking=True)
+        slot[0:1].copy_(ok_flag, non_blocking=True)
+        if proposal_status is not None:
+            slot[1:2].copy_(proposal_status, non_blocking=True)
+        else:
+            slot[1] = 0
         ev = None
         if self.cuda:
             ev = torch.cuda.Event()
@@ -77,8 +88,10 @@ class DynamicLossScale:
                 elif not ev.query():
                     break
             self.queue.popleft()
-            ok = int(slot[0]) == 1
+            ok, diverged = int(slot[0]) == 1, int(slot[1]) != 0
             self.free.append(slot)
+            if diverged:
+                raise FloatingPointError(self.DIVERGED)
             if ok:
                 self.clean_steps += 1
                 if self.growth_interval > 0 and self.clean_steps >= self.growth_interval and self.scale < self.scale_max:
@@ -102,7 +115,7 @@ class OpensetRCNNTrainer:
         is the un-folded weight (weight decay acts on it, the chain rule multiplies the kernel's gradient by the scale)."""
         self.frozen_bn = frozen_bn or {}
         self.row_scale: Dict[str, torch.Tensor] = {}
-        self.eng = OpensetRCNNEngine(params, cfg, dtype, device, class_map)
+        self.eng = OpensetRCNNEngine(params, cfg, dtype, device, class_map, tiled_roi=False)  # (the backward reads (ph, pw, c) rows)
         self.eng.rpn_keep_hidden = True  # the hidden state of the head is needed by its backward: the fused head kernel also writes it
         self.dtype, self.device = dtype, self.eng.device
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
@@ -288,6 +301,7 @@ class OpensetRCNNTrainer:
         keep: dict = {}
         sel = e._rpn(out, image_hw, keep, topk=c["pre_nms_topk_train"])
         s["rpn_t"], s["rpn_shapes"], s["sel"] = keep["rpn_t"], keep["rpn_shapes"], sel
+        self._proposal_status = sel["status_flags"]  # read with this iteration's overflow verdict (DynamicLossScale.record)
         assert list(keep["rpn_shapes"]) == list(shapes), "pyramid_shapes disagrees with the backbone"
         if self.overlap_targets:
             cur.wait_event(targets_ready)
@@ -524,7 +538,8 @@ class OpensetRCNNTrainer:
         self._fan([lambda k=k, pm=pm: ops.sgd_step_(pm, self.grad[k], self.mom[k], self.lr, self.momentum, self.weight_decay, gs, self.row_scale.get(k),
                                                    self.lowp.get(k), self._ok) for k, pm in self.master.items()])
         self._refresh_derived()
-        self.scaler.record(self._ok)
+        self.scaler.record(self._ok, getattr(self, "_proposal_status", None))
+        self._proposal_status = None
 
     def poll_overflow(self, wait: bool = False) -> bool:
         """Drain, IN ORDER, the verdicts of the updates that have finished (wait=True: of every update issued so far). True when
