@@ -134,6 +134,25 @@ def launch_ranks(n: int, argv) -> int:
     return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
 
 
+def rank_identity(dist, rank: int, world: int, local_elapsed: float, steps: int, batch: int, gpu_uuid: str, device_name: str) -> dict:
+    """What proves the N-rank line came from N ranks on N GPUs (the reference launches one process per GPU, train.py:287-294):
+    the world size the process group reports, every rank's GPU uuid (must be N distinct ones on a real node; a rehearsal that
+    shares one card shows one) and every rank's own images/s over the timed region. One all_gather_object of small tuples,
+    outside the timed region."""
+    mine = (int(rank), str(gpu_uuid), str(device_name), float(local_elapsed))
+    rows = [None] * world
+    if dist is not None and world > 1:
+        dist.all_gather_object(rows, mine)
+    else:
+        rows = [mine]
+    rows = sorted(rows)
+    uuids = [r[1] for r in rows]
+    return dict(ranks=int(dist.get_world_size()) if dist is not None and world > 1 else 1, gpu_uuids=uuids, distinct_gpus=len(set(uuids)),
+                device_names=sorted(set(r[2] for r in rows)),
+                per_rank_images_per_sec=[round(batch * steps / r[3], 2) if r[3] > 0 else None for r in rows],
+                per_rank_ms_per_step=[round(r[3] / steps * 1e3, 3) for r in rows])
+
+
 def measure_traffic(timeout_s: int = 150):
     """HBM-side traffic of the two kernel groups, measured in this run: two child passes of this very script under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (counters only, separate passes, as MI355X_MICROARCH.md prescribes; FETCH_SIZE
@@ -315,11 +334,34 @@ def pcie_leg(lanes, dev, batch: int, steps: int, warm: int = 2):
                 note="single host thread fills the pinned buffers (a memcpy per frame); image decode (JPEG) is not included")
 
 
-def parity_leg(tdt, dev, images, image_hw, steps: int = 2):
+F32_MATRIX_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def graph_rate(eng, images, image_hw, steps: int, warm: int = 2):
+    """images/s of one engine over `steps` replays of its captured pass (one lane, one stream): how the headline's single_pass
+    figure is measured."""
+    graph, out = eng.capture(images, image_hw, 800, 1344, 1)
+    for _ in range(warm):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    del graph, out
+    return images.shape[0] / dt, dt
+
+
+def parity_leg(tdt, dev, images, image_hw, flops_per_step: float, steps: int = 10):
     """What the benchmarked fp16 path gives up against fp32, and what fp32 costs. (1) agreement of the fast path's final
     detections with the engine's fp32 PARITY MODE (every tensor and product in fp32; tests/test_e2e_parity.py pins that mode to
     the fp32 oracle at 400 / 400) on the tests' 4 seeded 256x384 images: same class, IoU >= 0.99, |score difference| <= 1e-2,
-    matched one to one. (2) images/s of the parity mode at the benchmark batch (eager, one stream)."""
+    matched one to one. (2) images/s of the parity mode at the benchmark batch, measured like the headline's single_pass figure:
+    the captured pass replayed `steps` times, with its roofline against the 157.3 TFLOP/s fp32 matrix peak. (3) `config5_mode`:
+    BASELINE.json config 5 / SURVEY.md section 7 taken literally -- fp16 MFMA operands in the backbone, FPN and CF-RPN head, fp32
+    storage AND fp32 products from the RoIAlign output on (the box head's FC layers on the exact-f32 matrix instruction) -- its
+    agreement with the parity mode and its images/s: the price of staying inside what north_star sanctions, as a number."""
     from openset_rcnn_amd.host.agreement import detection_agreement
     from openset_rcnn_amd.host.engine import OpensetRCNNEngine
     from openset_rcnn_amd.host.weights import random_params, with_known_unknown_mix
@@ -336,8 +378,8 @@ def parity_leg(tdt, dev, images, image_hw, steps: int = 2):
     params = with_known_unknown_mix(base, emb)
     del e32, keep
 
-    def dets(dtype):
-        eng = OpensetRCNNEngine(params, dtype=dtype, device=dev)
+    def dets(dtype, **kw):
+        eng = OpensetRCNNEngine(params, dtype=dtype, device=dev, **kw)
         out = eng.forward(small, sizes)
         torch.cuda.synchronize()
         return eng, [(d["pred_boxes"], d["scores"], d["pred_classes"]) for d in eng.to_instances(out, n)]
@@ -346,23 +388,74 @@ def parity_leg(tdt, dev, images, image_hw, steps: int = 2):
     _, got = dets(tdt)
     agree = detection_agreement(got, ref)
     loose = detection_agreement(got, ref, iou_thr=0.9, score_tol=5e-2)
-    # parity-mode throughput at the benchmark batch
-    e32.forward_device(images, image_hw, 800, 1344)
+    # parity-mode throughput at the benchmark batch: captured pass, `steps` replays
+    rate32, dt32 = graph_rate(e32, images, image_hw, steps)
+    del e32
+    torch.cuda.empty_cache()
+    tf32 = flops_per_step / dt32 / 1e12
+    out = dict(fast_mode_agreement=round(agree["fraction"], 4), matched=agree["matched"], reference_detections=agree["reference_detections"],
+               returned_detections=agree["returned_detections"], same_class_on_matches=agree["same_class"],
+               agreement_at_iou_0p9_dscore_5e_2=round(loose["fraction"], 4),
+               criterion="same class, IoU >= 0.99, |score difference| <= 1e-2, one-to-one; reference = this engine's fp32 parity mode "
+                         "(fp32 storage and products in every layer), which tests/test_e2e_parity.py holds to the fp32 oracle",
+               images="4 seeded 256x384 uint8 images (seed 2024), random-init weights with a calibrated known / unknown mix",
+               fast_mode_storage="fp16 activations from the stem to h1 (RoIAlign output and FC1 output included), fp32 accumulation; fp32 from the box features on",
+               parity_mode_images_per_sec=round(rate32, 2), parity_mode_ms_per_step=round(dt32 * 1e3, 2), parity_mode_steps=steps,
+               parity_mode_roofline=dict(bound="mfma", achieved=round(tf32, 2), peak=F32_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
+                                         frac=round(tf32 / F32_MATRIX_PEAK_TFLOPS, 4), flops_per_step=flops_per_step,
+                                         note="algorithmic FLOPs of the MFMA launches (real proposal rows) over the whole captured pass's time"),
+               parity_mode_note=f"fp32 engine (osr_conv_f32.hip, exact-f32 MFMA), batch {images.shape[0]} at 800x1333, captured pass (hipGraph) replayed "
+                                f"{steps} times on one stream after 2 warm-up replays")
+    try:
+        e5, got5 = dets(tdt, fp32_points=("pooled", "h1"))
+        a5 = detection_agreement(got5, ref)
+        rate5, dt5 = graph_rate(e5, images, image_hw, steps)
+        del e5
+        out["config5_mode"] = dict(images_per_sec=round(rate5, 2), ms_per_step=round(dt5 * 1e3, 3), steps=steps,
+                                   agreement_with_fp32=round(a5["fraction"], 4), matched=a5["matched"], reference_detections=a5["reference_detections"],
+                                   storage="fp16 MFMA operands and storage in the backbone, FPN and CF-RPN head; fp32 storage and exact-fp32 products from the RoIAlign "
+                                           "output on (pooled rows, FC1, FC2, predictor, PLN, classifier) -- BASELINE.json config 5 / SURVEY.md section 7",
+                                   note="captured pass, one lane; FC1 / FC2 run on v_mfma_f32_32x32x2_f32 at 1/16 of the fp16 matrix rate")
+    except Exception as e:  # noqa: BLE001
+        out["config5_mode"] = {"error": repr(e)[:300]}
+    torch.cuda.empty_cache()
+    return out
+
+
+def make_lanes(eng, lane_images, image_hw, streams_per_pass: int = 1, concurrency_hint: int = 1):
+    """The headline's schedule: one captured pass (hipGraph) per lane, each lane with its own batch of images, its own activation /
+    output buffers (the capture's private pool) and its own HIP stream. Returns ([(graph, outputs, stream, images)], GB of one lane).
+    The tile model's concurrency hint = how many launch streams share the GPU (lanes x micro-batch streams)."""
+    from openset_rcnn_amd.host import ops as _ops
+    dev = eng.device
+    lanes, lane_gb = [], None
+    with _ops.concurrent_streams(concurrency_hint):
+        for li, imgs in enumerate(lane_images):
+            torch.cuda.synchronize()
+            mem0 = torch.cuda.memory_reserved(dev)
+            g_, o_ = eng.capture(imgs, image_hw, 800, 1344, streams_per_pass)
+            torch.cuda.synchronize()
+            if li == 0:
+                lane_gb = (torch.cuda.memory_reserved(dev) - mem0 + imgs.numel()) / 1e9  # one lane: its graph's private pool + its images
+            lanes.append((g_, o_, torch.cuda.Stream(device=dev), imgs))
+    for g_, _, st_, _ in lanes:  # first replay of every lane's graph (one-time upload of the executable graph), untimed and outside the W warm-up steps
+        with torch.cuda.stream(st_):
+            g_.replay()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        e32.forward_device(images, image_hw, 800, 1344)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    return dict(fast_mode_agreement=round(agree["fraction"], 4), matched=agree["matched"], reference_detections=agree["reference_detections"],
-                returned_detections=agree["returned_detections"], same_class_on_matches=agree["same_class"],
-                agreement_at_iou_0p9_dscore_5e_2=round(loose["fraction"], 4),
-                criterion="same class, IoU >= 0.99, |score difference| <= 1e-2, one-to-one; reference = this engine's fp32 parity mode "
-                          "(fp32 storage and products in every layer), which tests/test_e2e_parity.py holds to the fp32 oracle",
-                images="4 seeded 256x384 uint8 images (seed 2024), random-init weights with a calibrated known / unknown mix",
-                fast_mode_storage="fp16 activations from the stem to h1 (RoIAlign output and FC1 output included), fp32 accumulation; fp32 from the box features on",
-                parity_mode_images_per_sec=round(images.shape[0] / dt, 2), parity_mode_ms_per_step=round(dt * 1e3, 2),
-                parity_mode_note=f"fp32 engine (osr_conv_f32.hip, exact-f32 MFMA), batch {images.shape[0]} at 800x1333, eager single stream, {steps} steps")
+    return lanes, lane_gb
+
+
+def step_lanes(lanes, turn):
+    """One step of the headline loop: pass i is launched on lane i % P without waiting for pass i - 1 (its own buffers, its own
+    stream); a lane's next pass queues behind its previous one. The caller ends the timed region with a device-wide synchronize."""
+    if len(lanes) == 1:
+        lanes[0][0].replay()
+        return lanes[0][1]
+    g_, o_, st_, _ = lanes[turn[0] % len(lanes)]
+    turn[0] += 1
+    with torch.cuda.stream(st_):
+        g_.replay()
+    return o_
 
 
 def main(argv=None) -> int:
@@ -456,39 +549,17 @@ def main(argv=None) -> int:
 
     lanes, lane_gb = [], None
     if args.graph:
-        from openset_rcnn_amd.host import ops as _ops
         npass = max(1, args.passes_in_flight)
-        # (the tile model's concurrency hint: how many launch streams share the GPU -- lanes x micro-batch streams)
-        with _ops.concurrent_streams(npass if args.lane_hint else 1):
-            torch.cuda.synchronize()
-            mem0 = torch.cuda.memory_reserved(dev)
-            graph, gout = eng.capture(images, image_hw, 800, 1344, args.streams)
-            torch.cuda.synchronize()
-            lane_gb = (torch.cuda.memory_reserved(dev) - mem0 + images.numel()) / 1e9  # one lane: its graph's private pool + its images
-            lanes = [(graph, gout, torch.cuda.Stream(device=dev), images)]
-            lane_images = [images]
-            for li in range(1, npass):  # every lane has its own batch of images (and, through its capture, its own activations and outputs)
-                gi = torch.Generator().manual_seed(1234 + rank + 1000 * li)
-                lane_images.append(torch.randint(0, 256, (args.batch, 3, 800, 1333), generator=gi, dtype=torch.uint8).to(dev))
-                g2, o2 = eng.capture(lane_images[li], image_hw, 800, 1344, args.streams)
-                lanes.append((g2, o2, torch.cuda.Stream(device=dev), lane_images[li]))
-        for g_, _, st_, _ in lanes:  # first replay of every lane's graph (one-time upload of the executable graph), untimed and outside the W warm-up steps
-            with torch.cuda.stream(st_):
-                g_.replay()
-        torch.cuda.synchronize()
+        lane_images = [images]
+        for li in range(1, npass):  # every lane has its own batch of images (and, through its capture, its own activations and outputs)
+            gi = torch.Generator().manual_seed(1234 + rank + 1000 * li)
+            lane_images.append(torch.randint(0, 256, (args.batch, 3, 800, 1333), generator=gi, dtype=torch.uint8).to(dev))
+        lanes, lane_gb = make_lanes(eng, lane_images, image_hw, args.streams, npass if args.lane_hint else 1)
+        graph, gout = lanes[0][0], lanes[0][1]
         turn = [0]
 
         def step():  # noqa: F811  one hipGraph launch replays the whole pass
-            if len(lanes) == 1:
-                graph.replay()
-                return gout
-            # several passes in flight: pass i is launched on lane i % P without waiting for pass i - 1 (its own buffers, its own
-            # stream); a lane's next pass queues behind its previous one. The timed region ends with a device-wide synchronize.
-            g_, o_, st_, _ = lanes[turn[0] % len(lanes)]
-            turn[0] += 1
-            with torch.cuda.stream(st_):
-                g_.replay()
-            return o_
+            return step_lanes(lanes, turn)
 
     def timed(fn, warm, steps):
         """The contract's timed region: W untimed steps, then exactly K steps between barrier + synchronize, MAX over the ranks."""
@@ -506,6 +577,7 @@ def main(argv=None) -> int:
             dist.barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        timed.local = el  # this rank's own time (the returned value is the maximum over the ranks)
         if dist is not None:
             t = torch.tensor([el], dtype=torch.float64, device=eng.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -513,6 +585,8 @@ def main(argv=None) -> int:
         return el, o
 
     elapsed, out = timed(step, args.warmup, args.steps)
+    props = torch.cuda.get_device_properties(local_rank)
+    identity = rank_identity(dist, rank, world, timed.local, args.steps, args.batch, str(getattr(props, "uuid", "unknown")), props.name)
     n_det = int(out[3].sum().item())
     n_unknown = int((out[2] == eng.cfg["unknown_id"]).logical_and(torch.arange(out[2].shape[1], device=out[2].device)[None, :] < out[3][:, None]).sum().item())
 
@@ -559,8 +633,9 @@ def main(argv=None) -> int:
     # one collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x2 per the gfx950 guide) on this
     # very command by scripts/profile_round.sh and committed under profiles/ (newest round first); null when absent.
     traffic, traffic_source, hbm_traffic = None, None, None
-    for tag in ("r03_c", "r03_b", "r03_a", "r02_f", "r02_d", "r02_b", "r02_a", "r01_j"):
-        tfile = os.path.join(ROOT, "profiles", f"{tag}_kernel_times_and_traffic.json")
+    import glob
+    for tfile in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_times_and_traffic.json")), reverse=True):  # newest round / letter first
+        tag = os.path.basename(tfile)[: -len("_kernel_times_and_traffic.json")]
         if os.path.exists(tfile):
             with open(tfile) as fh:
                 blob = json.load(fh)
@@ -587,6 +662,16 @@ def main(argv=None) -> int:
                                "proposals that exist, not for the padding rows of the fixed-capacity lists",
                     flops_per_step_nominal=mfma_flops_nominal, frac_nominal=round(mfma_flops_nominal / (mfma_ms * 1e-3) / 1e12 / peak, 4) if mfma_ms > 0 else 0.0,
                     real_proposals=real_rois, proposal_list_rows=list_rows)
+    # the two figures north_star's targets are worded in: (1) the R50 + FPN backbone alone (its MFMA launches' FLOPs over their
+    # own time); (2) SURVEY.md 8d's dense-conv group formula, 392.9 GFLOP (ResNet-50 + FPN + CF-RPN head at 800 x 1344) x img/s
+    bb = [(f, e0.elapsed_time(e1)) for name, f, e0, e1, _, _ in prof if name.startswith("backbone.")]
+    bb_flops, bb_ms = sum(f for f, _ in bb), sum(t for _, t in bb)
+    roofline["backbone_frac"] = round(bb_flops / (bb_ms * 1e-3) / 1e12 / peak, 4) if bb_ms > 0 else 0.0
+    roofline["backbone"] = dict(flops_per_step=bb_flops, kernel_ms_per_step=round(bb_ms, 3), launches=len(bb),
+                                scope="ResNet-50 (stem .. res5) + FPN laterals / output convolutions: north_star's '>= 40 % of MFMA peak on the R50 backbone'")
+    per_gpu_rate = args.batch * args.steps / elapsed
+    roofline["survey_8d_frac"] = round(392.9e9 * per_gpu_rate / 1e12 / peak, 4)
+    roofline["survey_8d_note"] = "SURVEY.md 8d: 392.9 GFLOP of dense convolutions per image (ResNet-50 + FPN + CF-RPN head) x images/s per GPU / peak; target 0.40 = 2545 img/s"
     # HBM group: RoIAlign + proposal selection + the three NMS passes. NMS is not HBM-bound (n <= a few thousand
     # boxes per segment, a serial greedy scan): its bytes are folded in, so the aggregate is dominated by RoIAlign, and its time
     # and upper bound of IoU pairs (sum over segments of n^2 / 2) are reported per pass.
@@ -640,6 +725,9 @@ def main(argv=None) -> int:
                        "weights": "random-init (seed 0), FrozenBN folded; PLN encoder bias calibrated for a known/unknown mix at UNK_THR 0.23",
                        "detections_last_step": n_det, "unknown_detections_last_step": n_unknown, "known_detections_last_step": n_det - n_unknown,
                        "micro_batch_streams": args.streams, "hipgraph": bool(args.graph),
+                       "ranks": identity["ranks"], "gpu_uuids": identity["gpu_uuids"], "distinct_gpus": identity["distinct_gpus"],
+                       "device_names": identity["device_names"], "per_rank_images_per_sec": identity["per_rank_images_per_sec"],
+                       "per_rank_ms_per_step": identity["per_rank_ms_per_step"],
                        "passes_in_flight": max(1, len(lanes)),
                        "images_in_flight": args.batch * max(1, len(lanes)),
                        "lane_memory_GB": round(lane_gb, 2) if lane_gb is not None else None,
@@ -661,7 +749,7 @@ def main(argv=None) -> int:
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_parity:
         try:
-            line["parity"] = parity_leg(tdt, dev, images, image_hw)
+            line["parity"] = parity_leg(tdt, dev, images, image_hw, mfma_flops)
         except Exception as e:  # noqa: BLE001  (reported in the line; the headline stands)
             line["parity"] = {"error": repr(e)[:400]}
         torch.cuda.empty_cache()
@@ -690,8 +778,8 @@ def main(argv=None) -> int:
         if rank == 0:
             line["train_step"] = ts
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(params, args.cpu_batch, one_thread=True)
+        if not args.no_cpu_baseline:  # host-only: rank 0 times it whatever N is (the other ranks wait at the closing barrier)
+            line["cpu_baseline"] = cpu_baseline(params, args.cpu_batch, one_thread=world == 1)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -606,15 +606,16 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
                         o[i][si].f[e] = (TI)fmaxf(v, 0.f);                                                                           \
                     }                                                                                                                \
                 }                                                                                                                    \
-            /* The four stores go out together at the end of the stage, fenced on both sides, and nothing may write their data       \
-               registers for the next instructions: a 16-byte buffer store reads its data after it has issued, and with a register   \
-               in the soffset field the compiler assumes it may overwrite them at once (measured: under load from a second stream   \
-               lanes 12-15 of every row of 16 stored the NEXT value of the first data register). */                                  \
+            /* The four stores go out together at the end of the stage. A 16-byte buffer store reads its data after it has issued;   \
+               with a REGISTER in the soffset field LLVM's hazard rule inserts no wait state and the next instruction may overwrite   \
+               the data (round 3, measured: under load from a second stream lanes 12-15 of every row of 16 stored the NEXT value of   \
+               the first data register). The stage's channel offset therefore rides in the instruction's immediate offset field      \
+               (s * 128 <= 896 < 4096, folded from the voffset sum) and soffset is the constant 0: the compiler's own wait state      \
+               applies -- the hazard class is gone, not padded (tests/test_conv_chain.py keeps the two-stream scenario as a gate). */  \
             __builtin_amdgcn_sched_barrier(0);                                                                                       \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                           \
                 _Pragma("unroll") for (int si = 0; si < 2; ++si) /* (a row beyond M: offset outside the buffer, store dropped) */    \
-                    __builtin_amdgcn_raw_buffer_store_b128(o[i][si].u, rs_out, o_off[i][si], s * 128, 0);                            \
-            asm volatile("s_nop 3" ::: "memory");                                                                                    \
+                    __builtin_amdgcn_raw_buffer_store_b128(o[i][si].u, rs_out, o_off[i][si] + s * 128, 0, 0);                        \
             __builtin_amdgcn_sched_barrier(0);                                                                                       \
         }
         static_assert(CH_NS == 8, "eight stages written out");

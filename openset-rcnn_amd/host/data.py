@@ -10,6 +10,8 @@ from __future__ import annotations
 
 from typing import Callable, Iterator, List, Optional, Sequence, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -123,6 +125,8 @@ class DeviceResizer:
         self.staging = []  # ring of pinned host buffers: one frame is being copied while the next is filled
         self.turn = 0
         self.max_bytes = max_pixels * 3
+        self.done = torch.cuda.Event()  # recorded after every resize; unrecorded until the first call (waiting on it is a no-op)
+        self._pid = os.getpid()         # a forked DataLoader worker must not touch the parent's GPU context (use num_workers=0)
 
     def _axis(self, n_in: int, n_out: int):
         key = (n_in, n_out)
@@ -135,6 +139,12 @@ class DeviceResizer:
         """out: a (3, nh, nw) uint8 CUDA tensor to write into (a slice of a batch buffer). wait=False: the caller's stream is NOT made
         to wait here -- it waits once for `self.done` after a whole batch (one event per batch instead of one per frame)."""
         from . import ops
+        if os.getpid() != self._pid:
+            raise RuntimeError("DeviceResizer used in a forked worker process: resize on the device runs in the process that owns the GPU "
+                               "context (DataLoader num_workers=0 with DatasetMapper(device_resize=...))")
+        if not wait and out is None:
+            raise ValueError("DeviceResizer(wait=False) needs out=: a result allocated on the copy stream could be reused by the caching "
+                             "allocator before the consumer stream has read it")
         h, w = img.shape[:2]
         nh, nw = int(new_hw[0]), int(new_hw[1])
         nbytes = h * w * 3
@@ -158,7 +168,7 @@ class DeviceResizer:
             self.done = self.stream.record_event()
         if wait:
             cur.wait_event(self.done)
-            out.record_stream(cur)
+        out.record_stream(cur)  # always: the consumer is the caller's stream (with wait=False it waits for self.done once per batch)
         return out
 
 

@@ -332,7 +332,15 @@ class ClsFreeRPN(nn.Module):
             with torch.no_grad():
                 rpn, _ = self.rpn_head.engine().rpn_losses_forward(sel, n, gt.to(dev), gcnt.to(dev), keys)
             losses = {"loss_rpn_loc": rpn[0], "loss_rpn_ctr": rpn[1]}
-        counts = sel["counts"].cpu().tolist()  # the list-of-Instances API needs the lengths on the host
+        # the list-of-Instances API needs the lengths on the host: one D2H copy brings the selection's status word with them
+        host = torch.cat((sel["counts"], sel["status_flags"])).cpu().tolist()
+        counts = host[:-1]
+        if self.training and host[-1] != 0:  # find_top_proposals.py:96-101 (at test time the rows are dropped silently: the kernel did)
+            raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")
+        if self.training:  # the scalars classification_free_rpn.py:459-463,553-554 puts into EventStorage
+            pos_reg, neg_reg, pos_obj, neg_obj = [float(v) for v in rpn[2:6].tolist()]
+            self.storage = {"rpn/num_pos_anchors": pos_reg / n, "rpn/num_neg_anchors": neg_reg / n, "rpn/obj_num_pos_anchors": pos_obj / n,
+                            "rpn/obj_num_neg_anchors": neg_obj / n, "rpn/num_proposals": sum(counts) / max(n, 1)}
         out = []
         for i, size in enumerate(images.image_sizes):
             r = Instances(size)
@@ -698,7 +706,8 @@ class GeneralizedRCNN(_EngineOwner):
         trainer = self.trainer()
         tensors = self._train_tensors(batched_inputs, self.sampler_generator)
         with torch.no_grad():
-            trainer.poll_overflow(wait=parallel.is_dist())  # (several ranks: all apply the same verdicts at the same iteration)
+            # (several ranks: all apply the same verdicts -- those of the updates up to two iterations back -- at the same iteration)
+            trainer.poll_overflow(wait=parallel.is_dist(), lag=trainer.MULTI_RANK_LAG if parallel.is_dist() else 0)
             losses, saved = trainer._forward(*tensors)
         names = list(losses)
         outs = _ExplicitBackward.apply(self._grad_hook(), trainer, saved, tensors[0].shape[0], *[losses[k] for k in names])

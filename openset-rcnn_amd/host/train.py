@@ -77,10 +77,12 @@ class DynamicLossScale:
             ev.record()
         self.queue.append((ev, slot))
 
-    def poll(self, wait: bool = False) -> bool:
-        """True when at least one of the drained updates had been skipped."""
+    def poll(self, wait: bool = False, lag: int = 0) -> bool:
+        """True when at least one of the drained updates had been skipped. lag: leave the newest `lag` updates in the queue
+        whatever their state -- with wait=True the call then applies EXACTLY the verdicts of all updates but the newest `lag`,
+        a deterministic set (the same on every rank of a data-parallel job), while the host keeps `lag` iterations of run-ahead."""
         any_overflow = False
-        while self.queue:
+        while len(self.queue) > lag:
             ev, slot = self.queue[0]
             if ev is not None:
                 if wait:
@@ -183,7 +185,7 @@ class OpensetRCNNTrainer:
         return self.scaler.scale
 
     @loss_scale.setter
-    def loss_scale(self, v: float) -> None:  # (a resumed checkpoint restores the scale it was written with)
+    def loss_scale(self, v: float) -> None:  # (load_optimizer_state restores the scale a checkpoint was written with)
         self.scaler.scale = float(v)
 
     @property
@@ -541,22 +543,28 @@ class OpensetRCNNTrainer:
         self.scaler.record(self._ok, getattr(self, "_proposal_status", None))
         self._proposal_status = None
 
-    def poll_overflow(self, wait: bool = False) -> bool:
+    # several ranks: step k applies the verdicts of the updates up to k - 1 - MULTI_RANK_LAG, waited for -- the same set on every rank
+    # (they are functions of the all-reduced gradient), so the scales cannot drift apart, and the host still runs two iterations ahead
+    # of the GPU (waiting for update k - 1 at the top of step k exposed the ~150 small update launches and the next forward's launch
+    # latency on every iteration)
+    MULTI_RANK_LAG = 2
+
+    def poll_overflow(self, wait: bool = False, lag: int = 0) -> bool:
         """Drain, IN ORDER, the verdicts of the updates that have finished (wait=True: of every update issued so far). True when
         at least one of them was skipped because of non-finite gradients. Dynamic loss scaling as GradScaler does it: an
         overflow halves the scale (floor 1.0) and counts in `overflow_steps`; `scale_growth_interval` consecutive clean updates
         double it again, never past the configured scale. Every update has a pinned slot of its own, so a verdict is never lost
-        however far the host runs ahead. With several ranks step() calls this with wait=True: every rank then applies the same
+        however far the host runs ahead. With several ranks step() calls this with wait=True and lag=MULTI_RANK_LAG: every rank then applies the same
         verdicts (they are functions of the all-reduced gradient) at the same iteration, and the scales cannot drift apart.
         (`wait=True` is also what the checkpoint writer uses, so that no skipped or half-applied state is written blind.)"""
-        return self.scaler.poll(wait)
+        return self.scaler.poll(wait, lag)
 
     def step(self, images, image_hw, hp, wp, gt_boxes, gt_classes, gt_count, keys, update: bool = True) -> Dict[str, torch.Tensor]:
         """One iteration: returns the loss dict (GPU scalars). update=False leaves the parameters untouched (gradients stay in
         self.grad, scaled by loss_scale)."""
         # earlier iterations' verdicts adjust the loss scale here, at one deterministic point of the iteration; with several ranks
         # the call waits for them, so that all ranks change the scale at the same iteration (see poll_overflow)
-        self.poll_overflow(wait=parallel.is_dist())
+        self.poll_overflow(wait=parallel.is_dist(), lag=self.MULTI_RANK_LAG if parallel.is_dist() else 0)
         losses, saved = self._forward(images, image_hw, hp, wp, gt_boxes, gt_classes, gt_count, keys)
         self._backward(saved, images.shape[0], overlap=update)
         if update:
@@ -565,9 +573,19 @@ class OpensetRCNNTrainer:
 
     def export_optimizer_state(self) -> Dict[str, torch.Tensor]:
         """Momentum buffers (CPU copies) for a checkpoint that is resumed exactly ([d2] checkpoints carry the optimizer state)."""
-        return {k: v.detach().cpu().clone() for k, v in self.mom.items()}
+        out = {k: v.detach().cpu().clone() for k, v in self.mom.items()}
+        self.poll_overflow(wait=True)  # every issued update's verdict is in the scale that is written
+        out[self.SCALE_KEY] = torch.tensor([self.scaler.scale, float(self.scaler.clean_steps), float(self.scaler.overflow_steps), self.scaler.scale_max],
+                                           dtype=torch.float64)
+        return out
+
+    SCALE_KEY = "__dynamic_loss_scale__"  # (scale, consecutive clean updates, skipped updates so far, configured scale)
 
     def load_optimizer_state(self, state: Dict[str, torch.Tensor]) -> None:
+        state = dict(state)
+        sc = state.pop(self.SCALE_KEY, None)
+        if sc is not None:  # a run that had backed off resumes at the scale it was written with, not at the configured one
+            self.scaler.scale, self.scaler.clean_steps, self.scaler.overflow_steps = float(sc[0]), int(sc[1]), int(sc[2])
         for k, v in state.items():
             if k not in self.mom or tuple(self.mom[k].shape) != tuple(v.shape):
                 raise KeyError(f"optimizer state {k}: not a momentum buffer of this trainer")

@@ -52,3 +52,36 @@ def test_single_gpu_run_does_not_relaunch(monkeypatch):
 def test_bf16_is_not_offered_as_a_benchmark_dtype():
     with pytest.raises(SystemExit):
         bench.main(["--dtype", "bf16"])
+
+
+def _identity_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = bench.rank_identity(dist, rank, world, local_elapsed=0.5 + 0.25 * rank, steps=10, batch=16, gpu_uuid=f"GPU-{rank:04d}", device_name="AMD Instinct MI355X")
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_n_rank_line_names_its_ranks_and_devices():
+    """the N > 1 line carries what proves N ranks on N devices -- the process group's world size, every
+    rank's GPU uuid (N distinct on a real node) and every rank's own rate. Two gloo ranks on CPU with stand-in uuids."""
+    import socket
+    import torch.multiprocessing as mp
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_identity_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out["ranks"] == 2 and out["gpu_uuids"] == ["GPU-0000", "GPU-0001"] and out["distinct_gpus"] == 2
+    assert out["per_rank_images_per_sec"] == [320.0, 213.33] and out["per_rank_ms_per_step"] == [50.0, 75.0]
+    assert out["device_names"] == ["AMD Instinct MI355X"]
+    one = bench.rank_identity(None, 0, 1, 0.2, 4, 16, "GPU-x", "dev")
+    assert one["ranks"] == 1 and one["distinct_gpus"] == 1 and one["per_rank_images_per_sec"] == [320.0]

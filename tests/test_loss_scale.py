@@ -57,3 +57,35 @@ def test_floor_of_the_scale(osr):
         sc.record(_flag(False))
     sc.poll()
     assert sc.scale == 1.0 and sc.overflow_steps == 3
+
+
+def test_non_finite_proposals_raise_when_the_iteration_is_drained(osr):
+    """find_top_proposals.py:96-101: `FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")` in
+    training. The selection kernel's status word rides in the overflow verdict's slot and raises when the host drains it."""
+    import pytest
+    from openset_rcnn_amd.host.train import DynamicLossScale
+    sc = DynamicLossScale(1024.0, growth_interval=0)
+    sc.record(_flag(True), torch.tensor([0], dtype=torch.int32))
+    assert sc.poll() is False
+    sc.record(_flag(True), torch.tensor([1], dtype=torch.int32))
+    sc.record(_flag(True))
+    with pytest.raises(FloatingPointError, match="Predicted boxes or scores contain Inf/NaN. Training has diverged."):
+        sc.poll()
+    assert sc.poll() is False and not sc.queue  # the iteration behind the diverged one is drained normally; slots are recycled clean
+    sc.record(_flag(True))
+    assert sc.poll() is False
+
+
+def test_lagged_poll_applies_a_deterministic_set_of_verdicts(osr):
+    """with several ranks the step waits for the verdicts up to two updates back (not for the newest one): the
+    applied set is the same on every rank and the host keeps two iterations of run-ahead."""
+    from openset_rcnn_amd.host.train import DynamicLossScale
+    sc = DynamicLossScale(1024.0, growth_interval=0)
+    for ok in (False, True, False, True):
+        sc.record(_flag(ok))
+    assert sc.poll(wait=True, lag=2) is True          # updates 0 and 1 only
+    assert sc.scale == 512.0 and sc.overflow_steps == 1 and len(sc.queue) == 2
+    assert sc.poll(wait=True, lag=2) is False         # nothing older than the newest two
+    sc.record(_flag(True))
+    assert sc.poll(wait=True, lag=2) is True and sc.scale == 256.0 and len(sc.queue) == 2  # update 2 (overflowed) is now old enough
+    assert sc.poll(wait=True) is False and not sc.queue

@@ -227,3 +227,60 @@ def test_back_to_back_steps_keep_every_overflow_verdict(osr):
     assert tr.poll_overflow(wait=True) in (True, False)
     assert tr.overflow_steps == 2 and tr.loss_scale == float(2 ** 38)
     assert all(torch.equal(v, before[k]) for k, v in tr.master.items())
+
+
+def test_non_finite_proposals_raise_floating_point_error_in_training(osr):
+    """find_top_proposals.py:96-101 raises FloatingPointError when predicted boxes / scores are not finite in training and drops
+    the rows silently at test time. Stand-alone ClsFreeRPN.forward raises at once (it reads the proposal counts on the host
+    anyway); the model-level training path raises when the iteration's verdict is drained (no extra host sync)."""
+    from openset_rcnn_amd.host import modeling as M
+    cfg = _cfg(osr)
+    torch.manual_seed(0)
+    model = M.build_model(cfg)
+    data = _data(list(range(20)))
+    model.train()
+    images = model.preprocess_image(data)
+    gt = [d["instances"] for d in data]
+    features = model.backbone(images.tensor)
+    props, _ = model.proposal_generator(images, features, gt)
+    st = model.proposal_generator.storage  # classification_free_rpn.py:459-463,553-554
+    assert set(st) == {"rpn/num_pos_anchors", "rpn/num_neg_anchors", "rpn/obj_num_pos_anchors", "rpn/obj_num_neg_anchors", "rpn/num_proposals"}
+    assert 0 < st["rpn/num_pos_anchors"] <= 128 and st["rpn/num_pos_anchors"] + st["rpn/num_neg_anchors"] == 256
+    assert st["rpn/num_proposals"] == sum(len(p) for p in props) / 2
+    with torch.no_grad():
+        model.proposal_generator.rpn_head.anchor_deltas.bias[1] = float("nan")
+    model.refresh()
+    with pytest.raises(FloatingPointError, match="Training has diverged"):
+        model.proposal_generator(images, features, gt)
+    model.eval()
+    props, _ = model.proposal_generator(images, features)  # test time: silently filtered (every anchor of every level is dropped)
+    assert all(len(p) == 0 for p in props)
+    # model level: the trainer's forward queues the status word behind the update's overflow verdict
+    model.train()
+    tr = model.make_trainer(lr=1e-4, loss_scale=1024.0)
+    tensors = model._train_tensors(data, torch.Generator().manual_seed(1))
+    tr.step(*tensors)
+    with pytest.raises(FloatingPointError, match="Predicted boxes or scores contain Inf/NaN"):
+        tr.poll_overflow(wait=True)
+
+
+def test_resumed_optimizer_state_carries_the_loss_scale(osr):
+    """the dynamic loss scale (scale, clean-update count, skipped updates) is part of the optimizer state; a run
+    that had backed off resumes at the scale it was written with."""
+    from openset_rcnn_amd.host import modeling as M
+    cfg = _cfg(osr)
+    torch.manual_seed(0)
+    model = M.build_model(cfg)
+    tr = model.make_trainer(lr=1e-4, loss_scale=1024.0)
+    data = _data(list(range(20)))
+    tensors = model._train_tensors(data, torch.Generator().manual_seed(1))
+    tr.step(*tensors, update=False)
+    tr.grad_flat[3] = float("inf")
+    tr._update(1)
+    state = tr.export_optimizer_state()  # (drains the verdicts first)
+    assert tr.loss_scale == 512.0 and float(state[tr.SCALE_KEY][0]) == 512.0 and int(state[tr.SCALE_KEY][2]) == 1
+    tr2 = model.make_trainer(lr=1e-4, loss_scale=1024.0)
+    assert tr2.loss_scale == 1024.0
+    tr2.load_optimizer_state(state)
+    assert tr2.loss_scale == 512.0 and tr2.overflow_steps == 1 and tr2.scaler.scale_max == 1024.0
+    assert all(torch.equal(tr2.mom[k].cpu(), state[k]) for k in tr2.mom)
