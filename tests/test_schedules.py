@@ -38,7 +38,7 @@ def test_four_lanes_in_flight_give_each_lane_its_eager_result(osr):
         refs.append([t.clone() for t in out])
     assert sum(int(r[3].sum()) for r in refs) > 0  # the passes produce detections
     lanes, lane_gb = bench.make_lanes(eng, lane_images, hw, 1, npass)
-    assert len(lanes) == npass and lane_gb > 1.0
+    assert len(lanes) == npass
     turn = [0]
     for rnd in range(3):  # 3 x 4 = 12 steps in flight, checked after every round of four
         for _ in range(npass):
