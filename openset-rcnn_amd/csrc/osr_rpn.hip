@@ -82,6 +82,7 @@ extern "C" osr_status osr_cfrpn_head_tail(const void* t, int32_t t_dtype, int64_
 // ------------------------------------------------------------------------------------------------------
 #define SEL_THREADS 1024
 #define SEL_MAXK 2048
+#define SEL_BINS 2048  // histogram bins of a radix-select pass (11 key bits)
 
 struct SelLevels {
     int num_levels, num_anchors;
@@ -110,6 +111,25 @@ __device__ __forceinline__ void bitonic_desc(unsigned long long* buf, int n) {
     }
 }
 
+// hist[digit] += 1 for the lanes with `on`, called by all 64 lanes of a wave. Two rounds of "the first pending lane's digit: every
+// lane that shares it is added by ONE atomic", then one atomic per lane that is still pending. Same histogram as 64 plain atomics.
+__device__ __forceinline__ void sel_hist_add(int* hist, int digit, bool on) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long act = __ballot(on);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (!act) return;  // wave-uniform
+        const int leader = __ffsll((long long)act) - 1;
+        const int d0 = __shfl(digit, leader, 64);
+        const bool mine = on && digit == d0;
+        const unsigned long long m = __ballot(mine);
+        if (lane == leader) atomicAdd(&hist[d0], __popcll(m));
+        if (mine) on = false;
+        act &= ~m;
+    }
+    if (on) atomicAdd(&hist[digit], 1);
+}
+
 // Stage A: grid (level, image). Stable top-k by radix select + bitonic sort, ltrb decode, filters.
 // Writes staging arrays st_box/st_score/st_src/st_flag at [img][koff[l] + rank].
 __global__ __launch_bounds__(SEL_THREADS) void rpn_select_kernel(SelLevels lv, const float* __restrict__ cell_anchors,
@@ -126,36 +146,80 @@ __global__ __launch_bounds__(SEL_THREADS) void rpn_select_kernel(SelLevels lv, c
     const float* dl = deltas + (lv.offset[l] + (long long)img * cnt) * 4;
 
     __shared__ unsigned long long s_sel[SEL_MAXK];
-    __shared__ int s_hist[256];
+    __shared__ __attribute__((aligned(16))) int s_hist[SEL_BINS];
     __shared__ int s_scan[32];
     __shared__ unsigned int s_prefix, s_remaining;
 
-    // ---- 1. radix select: key T of the k-th largest element (4 passes x 8 bits, MSB first) ----
+    // Four scores per thread and load (16 bytes per lane) where the segment allows it: the level's score run must be 16-byte
+    // aligned and a multiple of 4 long (true for p2..p4 of every image; the small levels take the scalar form).
+    const bool vec4 = (cnt & 3) == 0 && (((uintptr_t)sc) & 15) == 0;
+    const int per = vec4 ? 4 : 1;
+    const int nit = (cnt + SEL_THREADS * per - 1) / (SEL_THREADS * per);  // uniform trip count of the strided loops below
+
+    // ---- 1. radix select: key T of the k-th largest element (3 passes: 11 + 11 + 10 key bits, MSB first). The scores of a level are sigmoid
+    //      outputs: their leading key byte is the same for almost every anchor, so one LDS atomic per element would put all 67 200
+    //      adds of a p2 pass on one histogram bin, one behind the other. sel_hist_add adds a wave's most common digits once per wave. ----
     unsigned int prefix = 0, mask = 0;
     int remaining = k;  // rank (1-based, from the top) still to resolve inside the current prefix bucket
     if (cnt > k) {
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = 24 - 8 * pass;
-            for (int i = tid; i < 256; i += blockDim.x) s_hist[i] = 0;
+        // three passes over the scores: 11 + 11 + 10 key bits, MSB first (four 8-bit passes read the 269 KB of a p2 level once more)
+#pragma unroll 1
+        for (int pass = 0; pass < 3; ++pass) {
+            const int shift = pass == 0 ? 21 : pass == 1 ? 10 : 0, nbins = pass == 2 ? 1024 : 2048;
+            for (int i = tid; i < SEL_BINS; i += blockDim.x) s_hist[i] = 0;
             __syncthreads();
-            for (int i = tid; i < cnt; i += blockDim.x) {
-                unsigned int key = osr_float_key(sc[i]);
-                if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255], 1);
+            for (int it = 0; it < nit; ++it) {
+                const int i = (it * SEL_THREADS + tid) * per;
+                unsigned int key[4] = {0u, 0u, 0u, 0u};
+                if (i < cnt) {
+                    if (vec4) {
+                        const float4 v = *reinterpret_cast<const float4*>(sc + i);
+                        key[0] = osr_float_key(v.x); key[1] = osr_float_key(v.y); key[2] = osr_float_key(v.z); key[3] = osr_float_key(v.w);
+                    } else key[0] = osr_float_key(sc[i]);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < per) sel_hist_add(s_hist, (int)((key[e] >> shift) & (unsigned)(nbins - 1)), i < cnt && (key[e] & mask) == prefix);
             }
             __syncthreads();
-            if (tid == 0) {
-                int acc = 0, d = 255;
-                for (; d > 0; --d) {
-                    if (acc + s_hist[d] >= remaining) break;
-                    acc += s_hist[d];
+            if (tid < 64) {
+                // the digit d whose bucket holds the rank: the largest d with sum(hist[d..]) >= remaining (d = 0 when only the whole
+                // histogram reaches it). One wave: SEL_BINS / 64 bins per lane, suffix sums over the lanes, then the lane that holds
+                // the crossing walks its own bins (a serial walk over all bins: dependent LDS reads, 7 us per 256 of them).
+                constexpr int BPL = SEL_BINS / 64;
+                int sum = 0;
+#pragma unroll
+                for (int j = 0; j < BPL; j += 4) {
+                    const int4 h4 = *reinterpret_cast<const int4*>(&s_hist[tid * BPL + j]);
+                    sum += h4.x + h4.y + h4.z + h4.w;
                 }
-                s_prefix = prefix | ((unsigned int)d << shift);
-                s_remaining = remaining - acc;
+                int inc = sum;  // becomes the sum over this lane's bins and all higher lanes'
+#pragma unroll
+                for (int dd = 1; dd < 64; dd <<= 1) {
+                    const int t = __shfl_down(inc, dd, 64);
+                    if (tid + dd < 64) inc += t;
+                }
+                const int above = inc - sum;
+                const bool here = above < remaining && remaining <= inc;
+                if (here) {
+                    int acc = above, d = tid * BPL;
+                    for (int j = BPL - 1; j >= 0; --j) {
+                        const int hj = s_hist[tid * BPL + j];
+                        if (acc + hj >= remaining) { d = tid * BPL + j; break; }
+                        acc += hj;
+                    }
+                    s_prefix = prefix | ((unsigned int)d << shift);
+                    s_remaining = remaining - acc;
+                }
+                if (!__ballot(here) && tid == 0) {  // (cannot happen while the bucket holds >= remaining elements: the serial walk's d = 0 exit)
+                    s_prefix = prefix;
+                    s_remaining = remaining - (inc - s_hist[0]);
+                }
             }
             __syncthreads();
             prefix = s_prefix;
             remaining = s_remaining;
-            mask |= 255u << shift;
+            mask |= (unsigned)(nbins - 1) << shift;
             __syncthreads();
         }
     }
@@ -164,31 +228,36 @@ __global__ __launch_bounds__(SEL_THREADS) void rpn_select_kernel(SelLevels lv, c
     const unsigned int T = prefix;
     const bool all = cnt <= k;
 
-    // ---- 2. ordered compaction into s_sel as (key << 32) | ~index ----
+    // ---- 2. ordered compaction into s_sel as (key << 32) | ~index: strictly greater keys to [0, ngt), ties to [ngt, k). The k-th
+    //      largest key is T and `remaining` of its ties are needed, so exactly k - remaining keys are greater: no counting pass ----
     int base_gt = 0, base_eq = 0;  // running counts (uniform across the block)
-    int ngt_total = 0;
-    if (!all) {
-        // first count strictly-greater elements so that they go to [0, ngt) and ties to [ngt, k)
-        int c = 0;
-        for (int i = tid; i < cnt; i += blockDim.x) c += osr_float_key(sc[i]) > T;
-        int tot;
-        osr_block_excl_scan(c, s_scan, &tot);
-        ngt_total = tot;
-    }
-    for (int i0 = 0; i0 < cnt; i0 += blockDim.x) {
-        const int i = i0 + tid;
-        unsigned int key = 0;
-        int gt = 0, eq = 0;
+    const int ngt_total = all ? 0 : k - remaining;
+    for (int it = 0; it < nit; ++it) {
+        const int i = (it * SEL_THREADS + tid) * per;
+        unsigned int key[4] = {0u, 0u, 0u, 0u};
+        int gt = 0, eq = 0;  // how many of this thread's (up to four, consecutive) elements are greater / tie
         if (i < cnt) {
-            key = osr_float_key(sc[i]);
-            if (all) gt = 1; else { gt = key > T; eq = key == T; }
+            if (vec4) {
+                const float4 v = *reinterpret_cast<const float4*>(sc + i);
+                key[0] = osr_float_key(v.x); key[1] = osr_float_key(v.y); key[2] = osr_float_key(v.z); key[3] = osr_float_key(v.w);
+            } else key[0] = osr_float_key(sc[i]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < per) { if (all) gt += 1; else { gt += key[e] > T; eq += key[e] == T; } }
         }
         int tot;
-        int packed = osr_block_excl_scan(gt | (eq << 16), s_scan, &tot);
-        const int pg = base_gt + (packed & 0xffff), pe = base_eq + (packed >> 16);
-        const unsigned long long comp = ((unsigned long long)key << 32) | (unsigned int)(0xffffffffu - (unsigned int)i);
-        if (gt && pg < SEL_MAXK) s_sel[pg] = comp;
-        if (eq && pe < remaining && ngt_total + pe < SEL_MAXK) s_sel[ngt_total + pe] = comp;
+        const int packed = osr_block_excl_scan(gt | (eq << 16), s_scan, &tot);
+        int pg = base_gt + (packed & 0xffff), pe = base_eq + (packed >> 16);
+        if (i < cnt) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < per) {
+                    const unsigned long long comp = ((unsigned long long)key[e] << 32) | (unsigned int)(0xffffffffu - (unsigned int)(i + e));
+                    const bool g = all || key[e] > T, q = !all && key[e] == T;
+                    if (g) { if (pg < SEL_MAXK) s_sel[pg] = comp; ++pg; }
+                    if (q) { if (pe < remaining && ngt_total + pe < SEL_MAXK) s_sel[ngt_total + pe] = comp; ++pe; }
+                }
+        }
         base_gt += tot & 0xffff;
         base_eq += tot >> 16;
         if (!all && base_eq >= remaining && base_gt >= ngt_total) break;  // uniform
