@@ -24,6 +24,27 @@ __device__ __forceinline__ float osr_pln_distance(F ehat, const float* __restric
     return sqrtf(osr_wave_sum(acc));
 }
 
+// The same with the first vector held in registers: lane l keeps components l, l + 64, ... of it (OSR_PLN_REG * 64 components at
+// most), loaded ONCE per row -- the class loop of the PLN kernels then reads only LDS (re-reading the row from global memory
+// inside that loop put a memory round trip in front of every one of its K * R distances: 0.2-0.35 ms for a few hundred rows).
+#define OSR_PLN_REG 16
+__device__ __forceinline__ float osr_pln_distance_reg(const float (&eh)[OSR_PLN_REG], const float* __restrict__ p, int d, int lane, int type) {
+    float acc = 0.f;
+    if (type == OSR_DIST_COS) {
+#pragma unroll
+        for (int j = 0; j < OSR_PLN_REG; ++j) { const int i = lane + 64 * j; if (i < d) acc += eh[j] * p[i]; }
+        return 1.0f - osr_wave_sum(acc);
+    }
+    if (type == OSR_DIST_L1) {
+#pragma unroll
+        for (int j = 0; j < OSR_PLN_REG; ++j) { const int i = lane + 64 * j; if (i < d) acc += fabsf(eh[j] - p[i]); }
+        return osr_wave_sum(acc);
+    }
+#pragma unroll
+    for (int j = 0; j < OSR_PLN_REG; ++j) { const int i = lane + 64 * j; if (i < d) { const float df = eh[j] - p[i]; acc += df * df; } }
+    return sqrtf(osr_wave_sum(acc));
+}
+
 // d distance(a, b) / d a_i, given the two components and the distance itself (L2 only). d / d b_i: COS -a_i, L1 / L2 the negative.
 __device__ __forceinline__ float osr_pln_ddist_da(float a, float b, float dist, int type) {
     if (type == OSR_DIST_COS) return -b;

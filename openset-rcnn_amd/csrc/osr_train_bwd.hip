@@ -388,11 +388,17 @@ __global__ __launch_bounds__(256) void pln_bwd_rows_kernel(const float* __restri
             // own class: its nearest prototype (i0, intra); other classes: the nearest prototype of the nearest class (i1, inter)
             float intra = 0.f, inter = 1000.f;
             int pstar = -1, ystar = -1;
+            const bool in_regs = d <= OSR_PLN_REG * 64;  // (wave-uniform) the normalised row lives in registers for the class loop
+            float ehr[OSR_PLN_REG];
+#pragma unroll
+            for (int j = 0; j < OSR_PLN_REG; ++j) { const int i = lane + 64 * j; ehr[j] = (in_regs && i < d) ? e[i] * inv : 0.f; }
             for (int c = 0; c < K; ++c) {
                 float dist = 0.f;
                 int arg = c * R;
                 for (int q = 0; q < R; ++q) {
-                    const float dq = osr_pln_distance([&](int i) { return e[i] * inv; }, s_p + (size_t)(c * R + q) * d, d, lane, dist_type);
+                    const float* pq = s_p + (size_t)(c * R + q) * d;
+                    const float dq = in_regs ? osr_pln_distance_reg(ehr, pq, d, lane, dist_type)
+                                             : osr_pln_distance([&](int i) { return e[i] * inv; }, pq, d, lane, dist_type);
                     if (q == 0 || dq < dist) { dist = dq; arg = c * R + q; }
                 }
                 if (c == (int)y) { intra = dist; ystar = arg; }

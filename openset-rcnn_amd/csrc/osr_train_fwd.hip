@@ -633,10 +633,16 @@ __global__ __launch_bounds__(256) void pln_loss_kernel(const float* __restrict__
         ss = osr_wave_sum(ss);
         const float den = fmaxf(sqrtf(ss), 1e-12f);
         float intra = 0.f, inter = 1000.f;  // the reference overwrites the own-class column with 1000 before the min
+        const bool in_regs = d <= OSR_PLN_REG * 64;  // (wave-uniform) the normalised row lives in registers for the class loop
+        float eh[OSR_PLN_REG];
+#pragma unroll
+        for (int j = 0; j < OSR_PLN_REG; ++j) { const int i = lane + 64 * j; eh[j] = (in_regs && i < d) ? e[i] / den : 0.f; }
         for (int c = 0; c < K; ++c) {
             float dist = 0.f;  // min over the class's prototypes (prototype_learning_network.py:163)
             for (int q = 0; q < R; ++q) {
-                const float dq = osr_pln_distance([&](int i) { return e[i] / den; }, s_p + (size_t)(c * R + q) * d, d, lane, dist_type);
+                const float* pq = s_p + (size_t)(c * R + q) * d;
+                const float dq = in_regs ? osr_pln_distance_reg(eh, pq, d, lane, dist_type)
+                                         : osr_pln_distance([&](int i) { return e[i] / den; }, pq, d, lane, dist_type);
                 dist = (q == 0 || dq < dist) ? dq : dist;
             }
             if (c == (int)y) intra = dist; else inter = fminf(inter, dist);
