@@ -287,9 +287,13 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
 #define C64_COL(r) ((((r) >> 2) & 1) * 16 + (lane & 15))
 
     int nk = a.K / 64;
-    if constexpr (SPLIT) {  // this workgroup's share of the K slices (1x1 / FC layers only: the slice index is the channel block)
+    if constexpr (SPLIT) {  // this workgroup's share of the K slices: the K state of slice k_lo in the launch's K order
         const int k_lo = (int)((long long)ksp * nk / a.ksplit), k_hi = (int)((long long)(ksp + 1) * nk / a.ksplit);
-        c0 = k_lo * 64; kbyte = k_lo * 128; tap_off = (unsigned)(c0 * 2);
+        const int taps = p.kh * p.kw, spt = p.cin / 64;  // taps; channel slices per tap
+        const int tp = a.tap_minor ? k_lo % taps : k_lo / spt, cs = a.tap_minor ? k_lo / taps : k_lo % spt;
+        kh = tp / p.kw; kw = tp - kh * p.kw; c0 = cs * 64; tap = tp;
+        tap_off = (unsigned)((kh * p.in_stride_h + kw * p.in_stride_w + c0) * 2);
+        kbyte = (tap * p.cin + c0) * 2;
         nk = k_hi - k_lo;
     }
     C64_ISSUE(0);
@@ -861,10 +865,12 @@ struct SplitPlan { int tile_id, tail_mtiles, ksplit; long long m_tail0, ws_bytes
 
 static bool conv64_plan_split(const Conv64Args& a, SplitPlan* sp) {
     const osr_conv_params& p = a.p;
-    if (a.stem || p.kh * p.kw != 1 || p.res_mode != 0 || a.mask || p.stride_h != 1 || p.stride_w != 1 || p.pad_h != 0 || p.pad_w != 0) return false;
+    if (a.stem || p.res_mode != 0 || a.mask || p.stride_h != 1 || p.stride_w != 1 || p.cin % 64 != 0) return false;
     if (p.out_stride_w != p.cout || p.out_stride_h != (long long)p.wo * p.cout || p.out_stride_n != (long long)p.ho * p.wo * p.cout) return false;  // dense output rows
     const int nk = a.K / 64;
-    if (nk < 48) return false;  // the partial sums (tail rows x cout x 4 B x ksplit, written and read once) must be small beside the K loop
+    // the partial sums (tail rows x cout x 4 B x ksplit, written and read once) must be small beside the K loop: 48 slices for a 1 x 1 /
+    // FC layer, 32 for a KH x KW convolution (round 4: the 3 x 3 layers of res4 / FPN p4, 1050 tiles of 128 x 128 on 768 slots)
+    if (nk < (p.kh * p.kw > 1 ? 32 : 48)) return false;
     const int id = conv64_pick_tile(a);
     if (id != T256x256_2 && id != T128x128_1 && id != T128x256_1) return false;  // the tile shapes with a split-K tail instantiation
     const TileCfg* c = nullptr;
@@ -873,6 +879,10 @@ static bool conv64_plan_split(const Conv64Args& a, SplitPlan* sp) {
     const long long tiles_m = (a.M + c->bm - 1) / c->bm, tiles_n = (p.cout + c->bn - 1) / c->bn, tiles = tiles_m * tiles_n, slots = 256ll * c->occ;
     const long long full = tiles / slots, rem = tiles % slots;
     if (full < 1 || rem == 0 || rem * 2 > slots) return false;
+    // a K x K convolution needs at least two full rounds in front of the tail: with one (res4's 3 x 3 layers at batch 16, 1050 tiles on
+    // 768 slots) the two extra launches and the partial sums cost more than the half-empty round (measured 100 -> 115 us), with four
+    // (fpn_output3 on 256 x 256 tiles) the split takes 380 -> 321 us (scripts/exp_split3x3.py)
+    if (p.kh * p.kw > 1 && full < 2) return false;
     const long long tail_mt = (rem + tiles_n - 1) / tiles_n;  // whole rows of M tiles
     long long ks = slots / (tail_mt * tiles_n);
     if (ks > 8) ks = 8;

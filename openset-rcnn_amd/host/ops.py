@@ -150,7 +150,7 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, stride: in
             raise OsrError(f"planes_out: expected shape {(n, cout // 16, ho, wo, 16)}, no post_mask")
         p.out2_planar16 = planes_out.data_ptr()
     ws = None
-    if SPLIT_K_TAIL and post_mask is None and res_mode == 0 and kh == 1 and kw == 1 and planes_out is None:
+    if SPLIT_K_TAIL and post_mask is None and res_mode == 0 and stride == 1 and planes_out is None:
         wsb = int(lib.osr_conv2d_fwd_workspace_bytes(C.byref(p)))  # > 0: a deep-K 1x1 / FC layer whose last dispatch round is mostly empty
         if wsb > 0:
             ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)

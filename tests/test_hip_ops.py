@@ -425,6 +425,46 @@ def test_linear_split_k_tail_round(ops, osr):
     assert torch.equal(split[: 8192], single[: 8192])  # rows of the full rounds are untouched by the split
 
 
+def test_conv3x3_split_k_tail_round(ops, osr):
+    """Round 4: the split-K tail also takes K x K convolutions behind at least two full dispatch rounds (fpn_output3 at batch 16:
+    1050 tiles of 256 x 256 on 256 slots; 380 -> 321 us). The tail workgroups start in the middle of the launch's K order
+    (channel-slice-major, tap-minor), padding included. Reference: torch-CPU convolution of the first and of the last image (the
+    tail rows are the last 6656 of the last image)."""
+    gg = g(42)
+    n, h, w, c = 16, 100, 168, 256
+    x = (torch.randn(n, h, w, c, generator=gg) * 0.5).half().to(DEV)
+    wt = (torch.randn(c, 3, 3, c, generator=gg) / math.sqrt(9 * c)).half().to(DEV)
+    b = torch.randn(c, generator=gg).to(DEV)
+    L = osr._lib
+    import ctypes
+    p = L.ConvParams()
+    p.n, p.hi, p.wi, p.cin, p.ho, p.wo, p.cout = n, h, w, c, h, w, c
+    p.kh = p.kw = 3
+    p.stride_h = p.stride_w = p.pad_h = p.pad_w = 1
+    p.in_stride_n, p.in_stride_h, p.in_stride_w = h * w * c, w * c, c
+    p.out_stride_n, p.out_stride_h, p.out_stride_w = h * w * c, w * c, c
+    p.in_dtype, p.out_dtype = L.OSR_F16, L.OSR_F32
+    assert L.load().osr_conv2d_fwd_workspace_bytes(ctypes.byref(p)) > 0, "this shape must qualify for the split (otherwise the test tests nothing)"
+    buf = ctypes.create_string_buffer(256)
+    L.load().osr_conv2d_fwd_describe(ctypes.byref(p), 1, buf, 256)
+    assert "split-K" in buf.value.decode(), buf.value
+    try:
+        ops.SPLIT_K_TAIL = False
+        single = ops.conv2d(x, wt, b, 1, 1, relu=True, out_dtype=torch.float32)
+        ops.SPLIT_K_TAIL = True
+        split = ops.conv2d(x, wt, b, 1, 1, relu=True, out_dtype=torch.float32)
+        split2 = ops.conv2d(x, wt, b, 1, 1, relu=True, out_dtype=torch.float32)
+    finally:
+        ops.SPLIT_K_TAIL = True
+    assert torch.equal(split, split2)
+    assert torch.equal(split[:15], single[:15])  # rows of the full rounds are untouched by the split
+    assert not torch.equal(split[15], single[15]) or True  # (the tail rows are summed in another order: equality allowed, not required)
+    for img in (0, n - 1):
+        ref = torch.relu(F.conv2d(x[img:img + 1].cpu().float().permute(0, 3, 1, 2), wt.cpu().float().permute(0, 3, 1, 2), b.cpu(), padding=1)).permute(0, 2, 3, 1)
+        assert_close(split[img:img + 1], ref, rtol=1e-4, name=f"split-K 3x3 conv, image {img}")
+        assert_close(single[img:img + 1], ref, rtol=1e-4, name=f"single-launch 3x3 conv, image {img}")
+
+
 # ------------------------------------------------------------------------------------------------------
 def test_box_predictor_tail(ops):
     gg = g(31)
