@@ -163,6 +163,14 @@ osr_status osr_resize_bilinear_u8(const uint8_t* in, int32_t h, int32_t w, int64
                                   int32_t ky, int32_t y_first, int32_t y_rows, int32_t nh, int32_t nw, uint8_t* tmp,
                                   int64_t tmp_bytes, uint8_t* out, void* stream);
 
+/* The whole ResNet stem in ONE launch (csrc/osr_stem_pool.hip): [d2] BasicStem.forward = conv1 (7x7, stride 2, pad 3, 3 -> 64,
+ * FrozenBN folded) -> ReLU -> F.max_pool2d(3, 2, 1), built by build_resnet_fpn_backbone (/root/reference/configs/Base-RCNN-FPN.yaml:3-8).
+ * xpad: osr_preprocess' (n, hp + 6, osr_stem_padded_width(wp), 4) image; w_view: the stem view (64, w_rows, 1, 32) of
+ * osr_conv2d_fwd's stem path (w_rows 7 or 8; row ky holds 8 taps x 4 channels, the 8th tap and the 4th channel zero); out:
+ * (n, hp / 4, wp / 4, 64) (odd halves round up as the two layers do). The 64-channel stem output never reaches HBM. Same K order and
+ * rounding points as osr_conv2d_fwd(stem view) followed by osr_maxpool3x3s2. dtype f16 / bf16 (hp, wp even). */
+osr_status osr_stem_maxpool_fwd(const void* xpad, int32_t n, int32_t hp, int32_t wp, const void* w_view, int32_t w_rows, const float* bias,
+                                void* out, int32_t dtype, void* stream);
 /* [d2] F.max_pool2d(k=3,s=2,p=1) of the ResNet stem, NHWC contiguous. */
 osr_status osr_maxpool3x3s2(const void* in, int32_t n, int32_t hi, int32_t wi, int32_t c, void* out, int32_t dtype,
                             void* stream);

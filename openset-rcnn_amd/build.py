@@ -25,6 +25,7 @@ SOURCES = {
     "osr_conv_gemm64.hip": [],
     "osr_conv_f32.hip": [],
     "osr_bottleneck.hip": [],
+    "osr_stem_pool.hip": [],
     "osr_rpn.hip": ["-ffp-contract=off"],
     "osr_roi_align.hip": ["-ffp-contract=off"],
     "osr_roi_tiled.hip": ["-ffp-contract=off"],

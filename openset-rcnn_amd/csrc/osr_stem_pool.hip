@@ -1,0 +1,181 @@
+// ResNet stem in ONE launch for gfx950 (include/osr.h: osr_stem_maxpool_fwd): 7x7 / stride 2 / pad 3 convolution (3 -> 64, FrozenBN
+// folded) + ReLU + 3x3 / stride 2 / pad 1 max pool.
+//
+// Replaces [d2] BasicStem.forward (conv1 -> relu_ -> F.max_pool2d(kernel_size=3, stride=2, padding=1)) of build_resnet_fpn_backbone,
+// selected by /root/reference/configs/Base-RCNN-FPN.yaml:3-8 -- until round 4 two launches: the stem as a (kh = 8, kw = 1, cin = 32)
+// "view" convolution on the generic implicit-GEMM kernel (K padded 147 -> 256, 0.29 ms) and osr_maxpool3x3s2 (0.16 ms), with the
+// 550 MB stem output written to HBM and read back in between.
+//
+// Design (MI355X): one workgroup (4 waves, 51 KB of LDS: three per CU) = a 4 x 16 tile of POOLED pixels = a 9 x 33 region of stem
+// pixels (the pool's halo is recomputed: 297 / 256 = 1.16x) = a 23 x 72-pixel patch of the pre-padded NHWC4 image, staged in LDS
+// once (every input pixel feeds up to 16 stem pixels).
+//  * conv: v_mfma_f32_16x16x32 with the WEIGHTS as the A operand (m = 16 output channels: wave w owns channels 16 w .. 16 w + 15 and
+//    keeps its seven fragments -- one per kernel row -- in registers for the whole tile) and the PIXELS as the B operand (n = 16 stem
+//    pixels of the flattened 9 x 33 region, k = one kernel row: 8 pixels x 4 channels = 64 contiguous bytes of the patch, one
+//    ds_read_b128 per lane; the 8th pixel and the 4th channel meet zero weights). Seven K steps per 16 x 16 tile instead of the
+//    eight of the padded view, no tile tails (19 groups of 16 for 297 pixels).
+//  * D = W X^T hands a lane four consecutive channels of one pixel: bias, ReLU, round to the storage dtype (the same rounding point
+//    as the separate launches), 8-byte write into the LDS image of the stem region; pixels outside the stem map are written as 0
+//    (post-ReLU values are >= 0, so a zero stands in for the pool's padding).
+//  * pool: thread = (pooled pixel, 16 channels): nine 32-byte LDS reads (pieces XOR-swizzled by the column so that neighbouring
+//    pooled pixels, two columns apart, do not share banks), fp32 max, two 16-byte stores; the tile's output rows are 2 KB runs.
+// Same K order (kernel rows ascending, fp32 accumulation) and rounding points as osr_conv2d_fwd(stem view) + osr_maxpool3x3s2.
+#include "osr_common.h"
+
+typedef f16_t sp_h8 __attribute__((ext_vector_type(8)));
+typedef bf16_t sp_b8 __attribute__((ext_vector_type(8)));
+typedef float sp_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned sp_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned sp_u32x2 __attribute__((ext_vector_type(2)));
+
+template <class T> struct SpFrag;
+template <> struct SpFrag<f16_t> {
+    typedef sp_h8 type;
+    static __device__ __forceinline__ sp_f32x4 mfma(sp_h8 a, sp_h8 b, sp_f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct SpFrag<bf16_t> {
+    typedef sp_b8 type;
+    static __device__ __forceinline__ sp_f32x4 mfma(sp_b8 a, sp_b8 b, sp_f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
+#define SP_PH 4                     // pooled rows of a tile
+#define SP_PW 16                    // pooled columns
+#define SP_SH (2 * SP_PH + 1)       // 9 stem rows
+#define SP_SW (2 * SP_PW + 1)       // 33 stem columns
+#define SP_NPIX (SP_SH * SP_SW)     // 297
+#define SP_NGRP ((SP_NPIX + 15) / 16)  // 19 groups of 16 stem pixels
+#define SP_IR (2 * (SP_SH - 1) + 7)    // 23 patch rows
+#define SP_IC (2 * (SP_SW - 1) + 8)    // 72 patch pixels per row
+#define SP_IPITCH (SP_IC * 8)          // 576 bytes
+#define SP_PATCH_BYTES (SP_IR * SP_IPITCH)                 // 13 248
+#define SP_TILE_OFF ((SP_PATCH_BYTES + 255) / 256 * 256)   // 13 312
+#define SP_LDS (SP_TILE_OFF + SP_NGRP * 16 * 128)          // + 38 912 = 52 224
+
+struct StemPoolArgs {
+    const void* x;       // (n, hd, wd, 4)
+    const void* w;       // (64, >= 7, 1, 32): stem view, row stride wrow elements
+    const float* bias;   // (64)
+    void* out;           // (n, hq, wq, 64)
+    int n, hd, wd, hs, ws, hq, wq, tiles_x, tiles_y, wrow;
+};
+
+template <class T>
+__global__ __launch_bounds__(256, 3) void stem_pool_kernel(StemPoolArgs a) {
+    typedef typename SpFrag<T>::type frag_t;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[SP_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware walk: an XCD takes a contiguous run of tiles (row-major inside an image): the patch rows neighbouring tiles share hit one L2
+    int t;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, img = t / (a.tiles_x * a.tiles_y);
+    const int py0 = ty * SP_PH, px0 = tx * SP_PW;
+    const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;   // first stem row / column of the region (-1 on the top / left tiles: the pool's padding)
+    const int iy0 = 2 * sy0, ix0 = 2 * sx0;           // first patch row / column in the pre-padded image (stem pixel (y, x) reads rows 2y .. 2y + 6)
+
+    // ---- this wave's weight fragments (A operand: lane (m = lane & 15, kg = lane >> 4) holds w[16 wid + m][ky][8 kg .. 8 kg + 7]) and biases ----
+    const int m16 = lane & 15, kg = lane >> 4;
+    frag_t wf[7];
+    {
+        const T* wp = reinterpret_cast<const T*>(a.w) + (size_t)(16 * wid + m16) * a.wrow * 32 + 8 * kg;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) wf[ky] = *reinterpret_cast<const frag_t*>(wp + ky * 32);
+    }
+    const float4 b4 = *reinterpret_cast<const float4*>(a.bias + 16 * wid + 4 * kg);  // the lane's D rows are channels 16 wid + 4 kg + 0..3
+
+    // ---- stage the patch: 23 rows x 36 chunks of 16 bytes, zero outside the pre-padded image ----
+    {
+        const char* xi = reinterpret_cast<const char*>(a.x) + (size_t)img * a.hd * a.wd * 8;
+        for (int i = tid; i < SP_IR * (SP_IC / 2); i += 256) {
+            const int r = i / (SP_IC / 2), ch = i - r * (SP_IC / 2);
+            const int y = iy0 + r, x = ix0 + 2 * ch;  // (two pixels per chunk; ix0 is even, wd is a multiple of 8: a chunk is inside or outside as a whole)
+            sp_u32x4 v = {0u, 0u, 0u, 0u};
+            if (y >= 0 && y < a.hd && x >= 0 && x + 1 < a.wd) v = *reinterpret_cast<const sp_u32x4*>(xi + ((size_t)y * a.wd + x) * 8);
+            *reinterpret_cast<sp_u32x4*>(lds + r * SP_IPITCH + ch * 16) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- conv + bias + ReLU -> LDS image of the stem region: pixel q = 33 row + column, 128 bytes, piece j (8 channels) at slot j ^ ((column >> 1) & 7) ----
+    unsigned char* tile = lds + SP_TILE_OFF;
+#pragma unroll 1
+    for (int grp = 0; grp < SP_NGRP; ++grp) {  // (two groups per turn -- two independent accumulator chains -- measured slower: 305 against 250 us)
+        const int q = 16 * grp + m16, qc = q < SP_NPIX ? q : SP_NPIX - 1;
+        const int r = (qc * 1986) >> 16;  // qc / 33 for qc < 2048 (1986 = ceil(65536 / 33))
+        const int c = qc - r * 33;
+        // B operand: lane (n = lane & 15 -> pixel q, kg) reads patch row 2 r + ky, pixels 2 c + 2 kg, 2 c + 2 kg + 1 (16 bytes)
+        const unsigned char* pb = lds + (2 * r) * SP_IPITCH + (2 * c + 2 * kg) * 8;
+        frag_t xb[7];
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) xb[ky] = *reinterpret_cast<const frag_t*>(pb + ky * SP_IPITCH);
+        sp_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) acc = SpFrag<T>::mfma(wf[ky], xb[ky], acc);
+        const int sy = sy0 + r, sx = sx0 + c;
+        const bool in = q < SP_NPIX && sy >= 0 && sy < a.hs && sx >= 0 && sx < a.ws;
+        typedef T t4 __attribute__((ext_vector_type(4)));
+        t4 o;
+        o[0] = (T)(in ? fmaxf(acc[0] + b4.x, 0.f) : 0.f);
+        o[1] = (T)(in ? fmaxf(acc[1] + b4.y, 0.f) : 0.f);
+        o[2] = (T)(in ? fmaxf(acc[2] + b4.z, 0.f) : 0.f);
+        o[3] = (T)(in ? fmaxf(acc[3] + b4.w, 0.f) : 0.f);
+        const int piece = 2 * wid + (kg >> 1);
+        *reinterpret_cast<t4*>(tile + q * 128 + ((piece ^ ((c >> 1) & 7)) << 4) + (kg & 1) * 8) = o;
+    }
+    __syncthreads();
+
+    // ---- 3x3 / s2 max pool out of the LDS image: thread = (pooled pixel, 16 channels) ----
+    {
+        const int pix = tid >> 2, cq = tid & 3;
+        const int py = pix >> 4, px = pix & 15;
+        float mx[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mx[k] = 0.f;
+        typedef T t8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int c = 2 * px + dx, q = (2 * py + dy) * 33 + c, f = (c >> 1) & 7;
+                const t8 v0 = *reinterpret_cast<const t8*>(tile + q * 128 + (((2 * cq) ^ f) << 4));
+                const t8 v1 = *reinterpret_cast<const t8*>(tile + q * 128 + (((2 * cq + 1) ^ f) << 4));
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { mx[k] = fmaxf(mx[k], (float)v0[k]); mx[8 + k] = fmaxf(mx[8 + k], (float)v1[k]); }
+            }
+        const int oy = py0 + py, ox = px0 + px;
+        if (oy < a.hq && ox < a.wq) {
+            t8 o0, o1;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { o0[k] = (T)mx[k]; o1[k] = (T)mx[8 + k]; }
+            T* op = reinterpret_cast<T*>(a.out) + (((size_t)img * a.hq + oy) * a.wq + ox) * 64 + 16 * cq;
+            *reinterpret_cast<t8*>(op) = o0;
+            *reinterpret_cast<t8*>(op + 8) = o1;
+        }
+    }
+}
+
+extern "C" osr_status osr_stem_maxpool_fwd(const void* xpad, int32_t n, int32_t hp, int32_t wp, const void* w_view, int32_t w_rows, const float* bias,
+                                           void* out, int32_t dtype, void* stream) {
+    OSR_REQUIRE(xpad && w_view && bias && out, OSR_ERR_INVALID_ARG, "osr_stem_maxpool_fwd: null pointer");
+    OSR_REQUIRE(dtype == OSR_F16 || dtype == OSR_BF16, OSR_ERR_UNSUPPORTED, "osr_stem_maxpool_fwd: f16 / bf16 storage");
+    OSR_REQUIRE(n >= 1 && hp >= 2 && wp >= 2 && hp % 2 == 0 && wp % 2 == 0 && (w_rows == 7 || w_rows == 8), OSR_ERR_INVALID_ARG,
+                "osr_stem_maxpool_fwd: bad sizes (even padded image, 7- or 8-row stem view)");
+    OSR_REQUIRE((((uintptr_t)xpad | (uintptr_t)w_view | (uintptr_t)out | (uintptr_t)bias) & 15) == 0, OSR_ERR_INVALID_ARG, "osr_stem_maxpool_fwd: pointers must be 16-byte aligned");
+    StemPoolArgs a;
+    a.x = xpad; a.w = w_view; a.bias = bias; a.out = out;
+    a.n = n; a.hd = hp + 6; a.wd = osr_stem_padded_width(wp);
+    a.hs = hp / 2; a.ws = wp / 2;                         // stem output: floor((hp + 6 - 7) / 2) + 1
+    a.hq = (a.hs - 1) / 2 + 1; a.wq = (a.ws - 1) / 2 + 1;  // pool output
+    a.tiles_x = (a.wq + SP_PW - 1) / SP_PW; a.tiles_y = (a.hq + SP_PH - 1) / SP_PH;
+    a.wrow = w_rows;
+    const long long tiles = (long long)n * a.tiles_x * a.tiles_y;
+    OSR_REQUIRE(tiles < (1ll << 31), OSR_ERR_UNSUPPORTED, "osr_stem_maxpool_fwd: too many tiles");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == OSR_F16) hipLaunchKernelGGL(stem_pool_kernel<f16_t>, dim3((unsigned)tiles), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(stem_pool_kernel<bf16_t>, dim3((unsigned)tiles), dim3(256), 0, st, a);
+    OSR_CHECK_LAUNCH("osr_stem_maxpool_fwd");
+    return OSR_OK;
+}

@@ -116,6 +116,8 @@ class OpensetRCNNEngine:
         self.fuse_res2 = dtype != torch.float32
         # conv2 -> conv3 + shortcut of a res3 block run as ONE launch (osr_conv2d_chain_fwd: conv2's output stays in LDS)
         self.chain_res3 = dtype != torch.float32
+        # the stem's convolution, ReLU and max pool run as ONE launch (osr_stem_maxpool_fwd): fp16 / bf16 storage only
+        self.fuse_stem = dtype != torch.float32
         # RoIAlign tile-centric (ops.roi_align_tiled: regions of the pyramid staged once in LDS, x contraction on the matrix cores):
         # OFF by default -- built, parity-green and measured SLOWER than the wave-per-RoI kernel on the benchmark's proposals (2.4 ms
         # against 1.3 ms). fp16 storage only. It reads a channel-slice-planar copy of p2..p5 that the FPN output
@@ -261,14 +263,23 @@ class OpensetRCNNEngine:
         if self.profile is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        x = ops.stem_conv(xpad, self.w["backbone.bottom_up.stem.conv1.w"], self.w["backbone.bottom_up.stem.conv1.b"], hp, wp, relu=True)
-        if self.profile is not None:
-            e1.record()
-            self.profile.append(("backbone.bottom_up.stem.conv1", 2.0 * x.numel() * 147, e0, e1,
-                                 xpad.numel() * 2 + x.numel() * 2, 2.0 * x.numel() * 147))  # 7*7*3 real taps
-        if keep is not None:
-            keep["stem"] = x
-        x = ops.maxpool3x3s2(x)
+        sw, sb = self.w["backbone.bottom_up.stem.conv1.w"], self.w["backbone.bottom_up.stem.conv1.b"]
+        if self.fuse_stem and keep is None:  # conv1 + ReLU + max pool in one launch: the stem output never reaches HBM (keep wants it)
+            x = ops.stem_maxpool(xpad, sw, sb, hp, wp)
+            stem_px = images.shape[0] * (hp // 2) * (wp // 2) * 64
+            if self.profile is not None:
+                e1.record()
+                self.profile.append(("backbone.bottom_up.stem (conv1 + max pool, fused)", 2.0 * stem_px * 147, e0, e1,
+                                     xpad.numel() * 2 + x.numel() * 2, 2.0 * stem_px * 147))  # 7*7*3 real taps of every stem pixel
+        else:
+            x = ops.stem_conv(xpad, sw, sb, hp, wp, relu=True)
+            if self.profile is not None:
+                e1.record()
+                self.profile.append(("backbone.bottom_up.stem.conv1", 2.0 * x.numel() * 147, e0, e1,
+                                     xpad.numel() * 2 + x.numel() * 2, 2.0 * x.numel() * 147))  # 7*7*3 real taps
+            if keep is not None:
+                keep["stem"] = x
+            x = ops.maxpool3x3s2(x)
         feats = {}
         for si, nb in enumerate(R50_BLOCKS):
             for b in range(nb):

@@ -188,6 +188,22 @@ def stem_conv(xpad: torch.Tensor, w_view: torch.Tensor, bias: torch.Tensor, hp: 
     return out
 
 
+def stem_maxpool(xpad: torch.Tensor, w_view: torch.Tensor, bias: torch.Tensor, hp: int, wp: int) -> torch.Tensor:
+    """[d2] BasicStem in one launch (osr_stem_maxpool_fwd): 7x7/s2/p3 conv + ReLU + 3x3/s2/p1 max pool on the pre-padded NHWC4 image;
+    the (n, hp/2, wp/2, 64) stem output stays in LDS. Same bits as stem_conv + maxpool3x3s2. f16 / bf16."""
+    lib = _lib.load()
+    _need(xpad, name="xpad"); _need(w_view, xpad.dtype, "w_view"); _need(bias, torch.float32, "bias")
+    n, hd, wd, c4 = xpad.shape
+    assert c4 == 4 and hd == hp + 6 and wd == stem_padded_width(wp) and hp % 2 == 0 and wp % 2 == 0
+    assert w_view.shape[0] == 64 and tuple(w_view.shape[2:]) == (1, 32) and w_view.shape[1] in (7, 8)
+    hs, ws = hp // 2, wp // 2
+    out = torch.empty((n, (hs - 1) // 2 + 1, (ws - 1) // 2 + 1, 64), dtype=xpad.dtype, device=xpad.device)
+    if FLOP_COUNT is not None:
+        FLOP_COUNT["conv"] += 2.0 * n * hs * ws * 64 * 147  # 7*7*3 real taps of every stem pixel (the pool's halo recompute is not credited)
+    check(lib.osr_stem_maxpool_fwd(_p(xpad), n, hp, wp, _p(w_view), int(w_view.shape[1]), _p(bias), _p(out), _DT[xpad.dtype], _stream()), "osr_stem_maxpool_fwd")
+    return out
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, relu: bool = False,
            out_dtype: Optional[torch.dtype] = None, row_seg: Optional[Tuple[torch.Tensor, int]] = None) -> torch.Tensor:
     """Fully connected layer on the MFMA path: x (m,k) f16/bf16, weight (n,k). row_seg: see conv2d."""
