@@ -187,7 +187,7 @@ def measure_traffic(timeout_s: int = 150):
                     kill_group(proc)
                     return None
                 out[counter] = PS.counter_sum(d, passes)
-        conv = lambda c, f: sum(v[0] for k, v in out[c].items() if k.startswith("conv_igemm") or k.startswith("splitk_reduce") or k.startswith("bottleneck64")) * 1024 * f / 1e9  # noqa: E731
+        conv = lambda c, f: sum(v[0] for k, v in out[c].items() if k.startswith("conv_igemm") or k.startswith("splitk_reduce") or k.startswith("bottleneck64") or k.startswith("stem_pool")) * 1024 * f / 1e9  # noqa: E731
         roi = lambda c, f: sum(v[0] for k, v in out[c].items() if k.startswith("roi_align")) * 1024 * f / 1e9  # noqa: E731
         return (round(conv("FETCH_SIZE", 2) + conv("WRITE_SIZE", 1), 2), round(roi("FETCH_SIZE", 2) + roi("WRITE_SIZE", 1), 2),
                 "measured in this run: two child passes of `bench.py --steps 2 --warmup 1 --streams 1 --no-graph` under rocprofv3 --pmc FETCH_SIZE "
@@ -656,7 +656,7 @@ def main(argv=None) -> int:
     roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic,
                     traffic_unit="GB of HBM traffic per step of the same kernel family (all its launches)", traffic_source=traffic_source,
                     algorithmic_GB_per_step=round(algo_bytes / 1e9, 2),
-                    kernel="MFMA implicit-GEMM conv / FC family (conv_igemm64_kernel + the fused bottleneck kernels)", launches_per_step=len(prof),
+                    kernel="MFMA implicit-GEMM conv / FC family (conv_igemm64_kernel + the fused bottleneck and stem kernels)", launches_per_step=len(prof),
                     flops_per_step=mfma_flops, kernel_ms_per_step=round(mfma_ms, 3),
                     flops_note="algorithmic: 2*M*K*N of every layer definition with M = real rows -- the box head's FC layers are credited for the "
                                "proposals that exist, not for the padding rows of the fixed-capacity lists",

@@ -75,7 +75,7 @@ def main():
                           write_GB_per_step=round(write.get(k, (0, 0))[0] * 1024 / 1e9, 3))
         if k in mfma:
             kernels[k].update(mfma_util=mfma[k]["mfma_util"], clock_GHz=mfma[k]["clock_GHz"], mfma_executed_TFLOP_per_step=round(mfma[k]["mfma_TFLOP"] / steps, 3))
-    conv = [v for k, v in kernels.items() if k.startswith("conv_igemm") or k.startswith("bottleneck64") or k.startswith("splitk_reduce")]
+    conv = [v for k, v in kernels.items() if k.startswith("conv_igemm") or k.startswith("bottleneck64") or k.startswith("splitk_reduce") or k.startswith("stem_pool")]
     print(json.dumps(dict(
         note="scripts/profile_round.sh: rocprofv3 --kernel-trace --stats, then --pmc FETCH_SIZE, --pmc WRITE_SIZE and --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 in separate passes of "
              "`bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train-step --streams 1 --no-graph` (`steps` passes of the path each: 2 warm-up + 5 timed + the attribution passes + the 4-image calibration pass); FETCH_SIZE doubled per "
