@@ -311,6 +311,14 @@ osr_status osr_roi_align_fwd_masked(const osr_pyramid* feats, int32_t feat_dtype
                                     const int32_t* batch_idx, int64_t m, int32_t pooled, int32_t canonical_level,
                                     int32_t canonical_size, int32_t min_level, const int32_t* skip, int32_t slice_major,
                                     void* out, int32_t out_dtype, void* stream);
+/* osr_roi_align_fwd_ordered with flags. OSR_ROI_NO_PADDING_FILL: padding rows (batch index -1) are left UNWRITTEN instead of
+ * zero-filled -- for a caller whose consumers never read them (the engine: the box head skips or ignores those rows; a fifth of the
+ * benchmark's list, 0.37 GB of zeros per step). */
+#define OSR_ROI_NO_PADDING_FILL 1
+osr_status osr_roi_align_fwd_ordered_ex(const osr_pyramid* feats, int32_t feat_dtype, int32_t n, const float* boxes,
+                                        const int32_t* batch_idx, int64_t m, int32_t pooled, int32_t canonical_level,
+                                        int32_t canonical_size, int32_t min_level, const int32_t* order,
+                                        const int32_t* order_nvalid, int32_t flags, void* out, int32_t out_dtype, void* stream);
 int64_t osr_roi_locality_order_workspace_bytes(int32_t n, int64_t m);
 osr_status osr_roi_locality_order(const osr_pyramid* feats, int32_t n, const float* boxes, const int32_t* batch_idx, int64_t m,
                                   int32_t canonical_level, int32_t canonical_size, int32_t min_level, int32_t* order,

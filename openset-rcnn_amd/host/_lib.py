@@ -101,6 +101,7 @@ PROTOTYPES = {
     "osr_fastrcnn_candidates": (I32, [P, P, I32, I32, P, P, I32, I32, P, P, F32, P, P, P, P, P, P]),
     "osr_roi_align_fwd": (I32, [C.POINTER(Pyramid), I32, I32, P, P, I64, I32, I32, I32, I32, P, I32, P]),
     "osr_roi_align_fwd_ordered": (I32, [C.POINTER(Pyramid), I32, I32, P, P, I64, I32, I32, I32, I32, P, P, P, I32, P]),
+    "osr_roi_align_fwd_ordered_ex": (I32, [C.POINTER(Pyramid), I32, I32, P, P, I64, I32, I32, I32, I32, P, P, I32, P, I32, P]),
     "osr_roi_align_tiled_workspace_bytes": (I64, [C.POINTER(Pyramid), I32, I64]),
     "osr_roi_align_fwd_tiled": (I32, [C.POINTER(Pyramid), P, I32, P, P, I64, I32, I32, I32, I32, P, I32, P, P, I64, P]),
     "osr_roi_align_fwd_masked": (I32, [C.POINTER(Pyramid), I32, I32, P, P, I64, I32, I32, I32, I32, P, I32, P, I32, P]),

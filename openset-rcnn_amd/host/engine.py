@@ -307,7 +307,7 @@ class OpensetRCNNEngine:
             keep.update(feats)
         return out
 
-    def pool_rois(self, feats: Dict[str, torch.Tensor], boxes: torch.Tensor, batch_idx: torch.Tensor, out_dtype=None) -> torch.Tensor:
+    def pool_rois(self, feats: Dict[str, torch.Tensor], boxes: torch.Tensor, batch_idx: torch.Tensor, out_dtype=None, fill_padding: bool = True) -> torch.Tensor:
         """[d2] ROIPooler + torchvision roi_align on p2..p5 (osrcnn_roi_heads.py:306) -> (m, 49 * 256) rows in the K order self.fc1_w is
         packed in: the tiled kernel's slice-major rows (planar copies of the levels from the backbone, or made here when the
         pyramid came from elsewhere), or the wave-per-RoI kernel's (ph, pw, c) rows."""
@@ -319,7 +319,7 @@ class OpensetRCNNEngine:
                                          c["canonical_level"], c["canonical_size"], 2)
         else:
             pooled = ops.roi_align(fl, c["pooler_scales"], boxes, batch_idx, c["pooler_resolution"], out_dtype or self.dtype,
-                                   c["canonical_level"], c["canonical_size"], 2)
+                                   c["canonical_level"], c["canonical_size"], 2, fill_padding=fill_padding)
         return pooled.view(pooled.shape[0], -1)
 
     def pooled_bin_major(self, pooled: torch.Tensor) -> torch.Tensor:
@@ -419,7 +419,9 @@ class OpensetRCNNEngine:
         row_b = c["pooler_resolution"] ** 2 * 256 * es + 20
         pooled_dt = torch.float32 if "pooled" in self.fp32_points else self.dtype
         h1_dt = torch.float32 if self.fp32_points & {"pooled", "h1"} else None  # (the fp32 kernel writes fp32 only)
-        pooled = self._hbm("roi_align", lambda: self.pool_rois(feats, boxes, sel["batch_idx"], pooled_dt),
+        # (the padding rows of the per-image lists are not zero-filled unless `keep` hands the pooled rows out: the box head skips the
+        # tiles that hold only padding, computes row by row in the others, and nothing downstream reads a padding row)
+        pooled = self._hbm("roi_align", lambda: self.pool_rois(feats, boxes, sel["batch_idx"], pooled_dt, fill_padding=keep is not None),
                            lambda: (lambda: sum(f.numel() for f in fl) * es + real() * row_b),
                            lambda o: (lambda: dict(real_rois=real(), list_rows=boxes.shape[0], nominal_bytes=sum(f.numel() for f in fl) * es + boxes.shape[0] * row_b)))
         m = pooled.shape[0]

@@ -513,10 +513,10 @@ def roi_locality_order(feats: List[torch.Tensor], scales: Sequence[float], boxes
 
 def roi_align(feats: List[torch.Tensor], scales: Sequence[float], boxes: torch.Tensor, batch_idx: torch.Tensor,
               pooled: int = 7, out_dtype: Optional[torch.dtype] = None, canonical_level: int = 4, canonical_size: int = 224,
-              min_level: int = 2, order: Optional[torch.Tensor] = None) -> torch.Tensor:
+              min_level: int = 2, order: Optional[torch.Tensor] = None, fill_padding: bool = True) -> torch.Tensor:
     """feats: NHWC per level; boxes (m,4) fp32; batch_idx (m) int32. Returns (m, pooled, pooled, c). order: processing order, (m,)
     int32 or (m + 1,) as roi_locality_order returns it (None: that order when ROI_LOCALITY_ORDER, else list order); the result
-    does not depend on it."""
+    does not depend on it. fill_padding=False: the rows of padding entries (batch index -1) are left unwritten instead of zeroed."""
     lib = _lib.load()
     _need(boxes, torch.float32, "boxes"); _need(batch_idx, torch.int32, "batch_idx")
     py = _pyramid(feats, scales)
@@ -531,9 +531,9 @@ def roi_align(feats: List[torch.Tensor], scales: Sequence[float], boxes: torch.T
             nvalid = C.c_void_p(order.data_ptr() + 4 * m)
     out_dtype = out_dtype or feats[0].dtype
     out = torch.empty((m, pooled, pooled, py.c), dtype=out_dtype, device=boxes.device)
-    check(lib.osr_roi_align_fwd_ordered(C.byref(py), _DT[feats[0].dtype], feats[0].shape[0], _p(boxes), _p(batch_idx), m, pooled,
-                                        canonical_level, canonical_size, min_level, _p(order), nvalid, _p(out), _DT[out_dtype], _stream()),
-          "osr_roi_align_fwd")
+    check(lib.osr_roi_align_fwd_ordered_ex(C.byref(py), _DT[feats[0].dtype], feats[0].shape[0], _p(boxes), _p(batch_idx), m, pooled,
+                                           canonical_level, canonical_size, min_level, _p(order), nvalid, 0 if fill_padding else 1, _p(out),
+                                           _DT[out_dtype], _stream()), "osr_roi_align_fwd")
     return out
 
 
