@@ -171,6 +171,11 @@ osr_status osr_resize_bilinear_u8(const uint8_t* in, int32_t h, int32_t w, int64
  * rounding points as osr_conv2d_fwd(stem view) followed by osr_maxpool3x3s2. dtype f16 / bf16 (hp, wp even). */
 osr_status osr_stem_maxpool_fwd(const void* xpad, int32_t n, int32_t hp, int32_t wp, const void* w_view, int32_t w_rows, const float* bias,
                                 void* out, int32_t dtype, void* stream);
+/* The same from the RAW batch: osr_preprocess' normalisation, halo and /32 padding are applied while the kernel stages its input patch
+ * (src (n,3,h,w) NCHW uint8 or float32, mean / std as osr_preprocess): same bits, no pre-padded copy of the batch in HBM. */
+osr_status osr_stem_maxpool_fwd_raw(const void* src, int32_t src_is_u8, int32_t n, int32_t h, int32_t w, int32_t hp, int32_t wp,
+                                    const float mean[3], const float std[3], const void* w_view, int32_t w_rows, const float* bias,
+                                    void* out, int32_t dtype, void* stream);
 /* [d2] F.max_pool2d(k=3,s=2,p=1) of the ResNet stem, NHWC contiguous. */
 osr_status osr_maxpool3x3s2(const void* in, int32_t n, int32_t hi, int32_t wi, int32_t c, void* out, int32_t dtype,
                             void* stream);

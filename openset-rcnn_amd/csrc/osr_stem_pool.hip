@@ -21,6 +21,7 @@
 //    pooled pixels, two columns apart, do not share banks), fp32 max, two 16-byte stores; the tile's output rows are 2 KB runs.
 // Same K order (kernel rows ascending, fp32 accumulation) and rounding points as osr_conv2d_fwd(stem view) + osr_maxpool3x3s2.
 #include "osr_common.h"
+#include <type_traits>
 
 typedef f16_t sp_h8 __attribute__((ext_vector_type(8)));
 typedef bf16_t sp_b8 __attribute__((ext_vector_type(8)));
@@ -52,14 +53,16 @@ template <> struct SpFrag<bf16_t> {
 #define SP_LDS (SP_TILE_OFF + SP_NGRP * 16 * 128)          // + 38 912 = 52 224
 
 struct StemPoolArgs {
-    const void* x;       // (n, hd, wd, 4)
+    const void* x;       // SRC 0: (n, hd, wd, 4) pre-padded, normalised image in the storage dtype; SRC 1 / 2: (n, 3, h, w) uint8 / float32 raw image
+    int ih, iw;          // raw image size (SRC 1 / 2)
+    float m0, m1, m2, s0, s1, s2;  // pixel mean / std (SRC 1 / 2): the patch is normalised while it is staged, as osr_preprocess does
     const void* w;       // (64, >= 7, 1, 32): stem view, row stride wrow elements
     const float* bias;   // (64)
     void* out;           // (n, hq, wq, 64)
     int n, hd, wd, hs, ws, hq, wq, tiles_x, tiles_y, wrow;
 };
 
-template <class T>
+template <class T, int SRC>
 __global__ __launch_bounds__(256, 3) void stem_pool_kernel(StemPoolArgs a) {
     typedef typename SpFrag<T>::type frag_t;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[SP_LDS];
@@ -86,6 +89,27 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(StemPoolArgs a) {
     }
     const float4 b4 = *reinterpret_cast<const float4*>(a.bias + 16 * wid + 4 * kg);  // the lane's D rows are channels 16 wid + 4 kg + 0..3
 
+    // ---- stage the patch. SRC 1 / 2: straight from the raw NCHW image -- (value - mean) / std rounded to the storage dtype, zero in
+    //      the 3-pixel halo, the /32 padding and the 4th channel: the bits osr_preprocess writes, without the 139 MB round trip ----
+    if constexpr (SRC != 0) {
+        typedef typename std::conditional<SRC == 1, unsigned char, float>::type S;
+        const S* src = reinterpret_cast<const S*>(a.x) + (size_t)img * 3 * a.ih * a.iw;
+        const size_t plane = (size_t)a.ih * a.iw;
+        typedef T t4 __attribute__((ext_vector_type(4)));
+        const bool unit_std = a.s0 == 1.0f && a.s1 == 1.0f && a.s2 == 1.0f;  // (x / 1.0f == x exactly: both Openset yaml files; skips three divisions per pixel)
+        for (int i = tid; i < SP_IR * SP_IC; i += 256) {
+            const int r = i / SP_IC, px = i - r * SP_IC;
+            const int y = iy0 + r - 3, x = ix0 + px - 3;
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+            if (y >= 0 && y < a.ih && x >= 0 && x < a.iw) {
+                const size_t o = (size_t)y * a.iw + x;
+                v0 = (float)src[o] - a.m0; v1 = (float)src[o + plane] - a.m1; v2 = (float)src[o + 2 * plane] - a.m2;
+                if (!unit_std) { v0 = v0 / a.s0; v1 = v1 / a.s1; v2 = v2 / a.s2; }
+            }
+            const t4 o4 = {(T)v0, (T)v1, (T)v2, (T)0.f};
+            *reinterpret_cast<t4*>(lds + r * SP_IPITCH + px * 8) = o4;
+        }
+    } else
     // ---- stage the patch: 23 rows x 36 chunks of 16 bytes, zero outside the pre-padded image ----
     {
         const char* xi = reinterpret_cast<const char*>(a.x) + (size_t)img * a.hd * a.wd * 8;
@@ -157,6 +181,23 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(StemPoolArgs a) {
     }
 }
 
+static osr_status stem_pool_launch(StemPoolArgs& a, int32_t n, int32_t hp, int32_t wp, int32_t w_rows, int32_t dtype, int src_kind, hipStream_t st) {
+    a.n = n; a.hd = hp + 6; a.wd = osr_stem_padded_width(wp);
+    a.hs = hp / 2; a.ws = wp / 2;                         // stem output: floor((hp + 6 - 7) / 2) + 1
+    a.hq = (a.hs - 1) / 2 + 1; a.wq = (a.ws - 1) / 2 + 1;  // pool output
+    a.tiles_x = (a.wq + SP_PW - 1) / SP_PW; a.tiles_y = (a.hq + SP_PH - 1) / SP_PH;
+    a.wrow = w_rows;
+    const long long tiles = (long long)n * a.tiles_x * a.tiles_y;
+    OSR_REQUIRE(tiles < (1ll << 31), OSR_ERR_UNSUPPORTED, "osr_stem_maxpool_fwd: too many tiles");
+    const dim3 grid((unsigned)tiles), block(256);
+#define SP_LAUNCH(T, K) hipLaunchKernelGGL((stem_pool_kernel<T, K>), grid, block, 0, st, a)
+    if (dtype == OSR_F16) { if (src_kind == 0) SP_LAUNCH(f16_t, 0); else if (src_kind == 1) SP_LAUNCH(f16_t, 1); else SP_LAUNCH(f16_t, 2); }
+    else                  { if (src_kind == 0) SP_LAUNCH(bf16_t, 0); else if (src_kind == 1) SP_LAUNCH(bf16_t, 1); else SP_LAUNCH(bf16_t, 2); }
+#undef SP_LAUNCH
+    OSR_CHECK_LAUNCH("osr_stem_maxpool_fwd");
+    return OSR_OK;
+}
+
 extern "C" osr_status osr_stem_maxpool_fwd(const void* xpad, int32_t n, int32_t hp, int32_t wp, const void* w_view, int32_t w_rows, const float* bias,
                                            void* out, int32_t dtype, void* stream) {
     OSR_REQUIRE(xpad && w_view && bias && out, OSR_ERR_INVALID_ARG, "osr_stem_maxpool_fwd: null pointer");
@@ -166,16 +207,21 @@ extern "C" osr_status osr_stem_maxpool_fwd(const void* xpad, int32_t n, int32_t 
     OSR_REQUIRE((((uintptr_t)xpad | (uintptr_t)w_view | (uintptr_t)out | (uintptr_t)bias) & 15) == 0, OSR_ERR_INVALID_ARG, "osr_stem_maxpool_fwd: pointers must be 16-byte aligned");
     StemPoolArgs a;
     a.x = xpad; a.w = w_view; a.bias = bias; a.out = out;
-    a.n = n; a.hd = hp + 6; a.wd = osr_stem_padded_width(wp);
-    a.hs = hp / 2; a.ws = wp / 2;                         // stem output: floor((hp + 6 - 7) / 2) + 1
-    a.hq = (a.hs - 1) / 2 + 1; a.wq = (a.ws - 1) / 2 + 1;  // pool output
-    a.tiles_x = (a.wq + SP_PW - 1) / SP_PW; a.tiles_y = (a.hq + SP_PH - 1) / SP_PH;
-    a.wrow = w_rows;
-    const long long tiles = (long long)n * a.tiles_x * a.tiles_y;
-    OSR_REQUIRE(tiles < (1ll << 31), OSR_ERR_UNSUPPORTED, "osr_stem_maxpool_fwd: too many tiles");
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == OSR_F16) hipLaunchKernelGGL(stem_pool_kernel<f16_t>, dim3((unsigned)tiles), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(stem_pool_kernel<bf16_t>, dim3((unsigned)tiles), dim3(256), 0, st, a);
-    OSR_CHECK_LAUNCH("osr_stem_maxpool_fwd");
-    return OSR_OK;
+    a.ih = a.iw = 0; a.m0 = a.m1 = a.m2 = 0.f; a.s0 = a.s1 = a.s2 = 1.f;
+    return stem_pool_launch(a, n, hp, wp, w_rows, dtype, 0, (hipStream_t)stream);
+}
+
+// The same from the RAW image: osr_preprocess ([d2] GeneralizedRCNN.preprocess_image + ImageList.from_tensors) folded into the staging.
+extern "C" osr_status osr_stem_maxpool_fwd_raw(const void* src, int32_t src_is_u8, int32_t n, int32_t h, int32_t w, int32_t hp, int32_t wp,
+                                               const float mean[3], const float stdv[3], const void* w_view, int32_t w_rows, const float* bias,
+                                               void* out, int32_t dtype, void* stream) {
+    OSR_REQUIRE(src && mean && stdv && w_view && bias && out, OSR_ERR_INVALID_ARG, "osr_stem_maxpool_fwd_raw: null pointer");
+    OSR_REQUIRE(dtype == OSR_F16 || dtype == OSR_BF16, OSR_ERR_UNSUPPORTED, "osr_stem_maxpool_fwd_raw: f16 / bf16 storage");
+    OSR_REQUIRE(n >= 1 && h >= 1 && w >= 1 && hp >= h && wp >= w && hp % 2 == 0 && wp % 2 == 0 && (w_rows == 7 || w_rows == 8), OSR_ERR_INVALID_ARG,
+                "osr_stem_maxpool_fwd_raw: bad sizes (even padded size >= image size, 7- or 8-row stem view)");
+    OSR_REQUIRE((((uintptr_t)w_view | (uintptr_t)out | (uintptr_t)bias) & 15) == 0, OSR_ERR_INVALID_ARG, "osr_stem_maxpool_fwd_raw: pointers must be 16-byte aligned");
+    StemPoolArgs a;
+    a.x = src; a.w = w_view; a.bias = bias; a.out = out;
+    a.ih = h; a.iw = w; a.m0 = mean[0]; a.m1 = mean[1]; a.m2 = mean[2]; a.s0 = stdv[0]; a.s1 = stdv[1]; a.s2 = stdv[2];
+    return stem_pool_launch(a, n, hp, wp, w_rows, dtype, src_is_u8 ? 1 : 2, (hipStream_t)stream);
 }

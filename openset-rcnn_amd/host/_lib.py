@@ -86,6 +86,7 @@ PROTOTYPES = {
     "osr_resize_tmp_bytes": (I64, [I32, I32]),
     "osr_resize_bilinear_u8": (I32, [P, I32, I32, I64, P, P, I32, P, P, I32, I32, I32, I32, I32, P, I64, P, P]),
     "osr_stem_maxpool_fwd": (I32, [P, I32, I32, I32, P, I32, P, P, I32, P]),
+    "osr_stem_maxpool_fwd_raw": (I32, [P, I32, I32, I32, I32, I32, I32, C.POINTER(C.c_float), C.POINTER(C.c_float), P, I32, P, P, I32, P]),
     "osr_maxpool3x3s2": (I32, [P, I32, I32, I32, I32, P, I32, P]),
     "osr_subsample2": (I32, [P, I32, I32, I32, I32, P, I32, P]),
     "osr_gemm_f32": (I32, [P, I64, P, P, P, I64, I32, I32, I32, I32, P]),

@@ -259,18 +259,19 @@ class OpensetRCNNEngine:
         if "backbone" in self.fp32_points:  # diagnostic: the fp32 kernels compute the pyramid, the heads get it in the storage dtype
             return {k: v.to(self.dtype) for k, v in self._bb32._backbone(images, hp, wp, None, normalized).items()}
         mean, std = ((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)) if normalized else (c["pixel_mean"], c["pixel_std"])
-        xpad = ops.preprocess(images, hp, wp, mean, std, self.dtype)
+        fused = self.fuse_stem and keep is None
+        xpad = None if fused else ops.preprocess(images, hp, wp, mean, std, self.dtype)
         if self.profile is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         sw, sb = self.w["backbone.bottom_up.stem.conv1.w"], self.w["backbone.bottom_up.stem.conv1.b"]
-        if self.fuse_stem and keep is None:  # conv1 + ReLU + max pool in one launch: the stem output never reaches HBM (keep wants it)
-            x = ops.stem_maxpool(xpad, sw, sb, hp, wp)
+        if fused:  # normalise + pad + conv1 + ReLU + max pool in one launch: neither the padded batch nor the stem output reaches HBM (keep wants the latter)
+            x = ops.stem_maxpool_raw(images, hp, wp, mean, std, sw, sb)
             stem_px = images.shape[0] * (hp // 2) * (wp // 2) * 64
             if self.profile is not None:
                 e1.record()
-                self.profile.append(("backbone.bottom_up.stem (conv1 + max pool, fused)", 2.0 * stem_px * 147, e0, e1,
-                                     xpad.numel() * 2 + x.numel() * 2, 2.0 * stem_px * 147))  # 7*7*3 real taps of every stem pixel
+                self.profile.append(("backbone.bottom_up.stem (preprocess + conv1 + max pool, fused)", 2.0 * stem_px * 147, e0, e1,
+                                     images.numel() * images.element_size() + x.numel() * 2, 2.0 * stem_px * 147))  # 7*7*3 real taps of every stem pixel
         else:
             x = ops.stem_conv(xpad, sw, sb, hp, wp, relu=True)
             if self.profile is not None:

@@ -204,6 +204,27 @@ def stem_maxpool(xpad: torch.Tensor, w_view: torch.Tensor, bias: torch.Tensor, h
     return out
 
 
+def stem_maxpool_raw(images: torch.Tensor, hp: int, wp: int, mean, std, w_view: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """preprocess + stem_maxpool in one launch (osr_stem_maxpool_fwd_raw): (n,3,h,w) uint8 / float32 images -> (n, hp/4, wp/4, 64) in
+    w_view's dtype; the normalised, padded copy of the batch is never written. Same bits as preprocess -> stem_maxpool."""
+    lib = _lib.load()
+    _need(images, name="images"); _need(w_view, name="w_view"); _need(bias, torch.float32, "bias")
+    if images.dtype not in (torch.uint8, torch.float32) or w_view.dtype not in (torch.float16, torch.bfloat16):
+        raise OsrError("stem_maxpool_raw: uint8 / float32 images, f16 / bf16 weights")
+    n, c, h, w = images.shape
+    assert c == 3 and hp >= h and wp >= w and hp % 2 == 0 and wp % 2 == 0
+    assert w_view.shape[0] == 64 and tuple(w_view.shape[2:]) == (1, 32) and w_view.shape[1] in (7, 8)
+    hs, ws = hp // 2, wp // 2
+    out = torch.empty((n, (hs - 1) // 2 + 1, (ws - 1) // 2 + 1, 64), dtype=w_view.dtype, device=images.device)
+    if FLOP_COUNT is not None:
+        FLOP_COUNT["conv"] += 2.0 * n * hs * ws * 64 * 147
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s = (C.c_float * 3)(*[float(v) for v in std])
+    check(lib.osr_stem_maxpool_fwd_raw(_p(images), int(images.dtype == torch.uint8), n, h, w, hp, wp, m, s, _p(w_view), int(w_view.shape[1]), _p(bias),
+                                       _p(out), _DT[w_view.dtype], _stream()), "osr_stem_maxpool_fwd_raw")
+    return out
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, relu: bool = False,
            out_dtype: Optional[torch.dtype] = None, row_seg: Optional[Tuple[torch.Tensor, int]] = None) -> torch.Tensor:
     """Fully connected layer on the MFMA path: x (m,k) f16/bf16, weight (n,k). row_seg: see conv2d."""

@@ -269,10 +269,10 @@ class OpensetRCNNTrainer:
             with torch.cuda.stream(self._side):
                 rpn_targets = e.rpn_targets_forward(lv, n, gt_boxes, gt_count, keys)
                 targets_ready = self._side.record_event()
-        xpad = ops.preprocess(images, hp, wp, c["pixel_mean"], c["pixel_std"], self.dtype)
         if e.fuse_stem and self.freeze_at >= 1:  # (the stem is frozen: nothing of it is needed by the backward)
-            x = ops.stem_maxpool(xpad, e.w["backbone.bottom_up.stem.conv1.w"], e.w["backbone.bottom_up.stem.conv1.b"], hp, wp)
+            x = ops.stem_maxpool_raw(images, hp, wp, c["pixel_mean"], c["pixel_std"], e.w["backbone.bottom_up.stem.conv1.w"], e.w["backbone.bottom_up.stem.conv1.b"])
         else:
+            xpad = ops.preprocess(images, hp, wp, c["pixel_mean"], c["pixel_std"], self.dtype)
             x = ops.stem_conv(xpad, e.w["backbone.bottom_up.stem.conv1.w"], e.w["backbone.bottom_up.stem.conv1.b"], hp, wp, relu=True)
             x = ops.maxpool3x3s2(x)
         blocks = []

@@ -22,3 +22,6 @@ y = ops.stem_conv(xpad, wv, b, 800, 1344)
 t(lambda: ops.maxpool3x3s2(y), "max pool")
 t(lambda: ops.stem_maxpool(xpad, wv, b, 800, 1344), "fused stem")
 assert torch.equal(ops.stem_maxpool(xpad, wv, b, 800, 1344), ops.maxpool3x3s2(y))
+t(lambda: ops.preprocess(img, 800, 1344, (103.53, 116.28, 123.675), (1.0, 1.0, 1.0), torch.float16), "preprocess")
+t(lambda: ops.stem_maxpool_raw(img, 800, 1344, (103.53, 116.28, 123.675), (1.0, 1.0, 1.0), wv, b), "fused stem from the raw batch")
+assert torch.equal(ops.stem_maxpool_raw(img, 800, 1344, (103.53, 116.28, 123.675), (1.0, 1.0, 1.0), wv, b), ops.maxpool3x3s2(y))

@@ -51,3 +51,20 @@ def test_engine_uses_the_fused_stem_and_keeps_its_results(osr, ops):
     b = eng.forward(images)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("src_dt", [torch.uint8, torch.float32])
+def test_raw_image_variant_equals_preprocess_then_fused_stem(osr, ops, src_dt):
+    """osr_stem_maxpool_fwd_raw: [d2] preprocess_image + ImageList.from_tensors folded into the staging -- the same bits as
+    osr_preprocess -> osr_stem_maxpool_fwd on uint8 and float32 batches, with an image smaller than its /32-padded size."""
+    from openset_rcnn_amd.host.weights import pack_stem_weight
+    g = torch.Generator().manual_seed(11)
+    n, h, w, hp, wp = 3, 123, 181, 128, 192
+    img = torch.randint(0, 256, (n, 3, h, w), generator=g, dtype=torch.uint8)
+    img = (img.float() + torch.rand(n, 3, h, w, generator=g)).to(DEV) if src_dt == torch.float32 else img.to(DEV)
+    wv = pack_stem_weight(torch.randn(64, 3, 7, 7, generator=g) * 0.05, torch.float16).to(DEV)
+    b = (torch.randn(64, generator=g) * 0.5).to(DEV)
+    mean, std = (103.53, 116.28, 123.675), (57.375, 57.12, 58.395)
+    want = ops.stem_maxpool(ops.preprocess(img, hp, wp, mean, std, torch.float16), wv, b, hp, wp)
+    got = ops.stem_maxpool_raw(img, hp, wp, mean, std, wv, b)
+    assert got.shape == (n, hp // 4, wp // 4, 64) and torch.equal(got, want)
