@@ -209,7 +209,7 @@ def synthetic_gt(n: int, h: int, w: int, per_image: int = 8, seed: int = 0):
     return boxes, classes, torch.full((n,), per_image, dtype=torch.int32)
 
 
-def train_step_leg(params, tdt, device, images, image_hw, steps: int, warmup: int, dist=None, rank: int = 0, world: int = 1):
+def train_step_leg(params, tdt, device, images, image_hw, steps: int, warmup: int, dist=None, rank: int = 0, world: int = 1, dense_rpn_bwd: bool = False):
     """BASELINE.json config 3: forward + explicit backward + SGD, batch 16 per GPU at 800x1333. With several ranks (configs 4 / 5's
     pattern) every rank trains on its own images and the flat gradient buffer is all-reduced over RCCL in >= 25 MB buckets issued
     from inside the backward (parallel.GradBuckets); the time is the maximum over the ranks, bracketed by barriers."""
@@ -217,6 +217,7 @@ def train_step_leg(params, tdt, device, images, image_hw, steps: int, warmup: in
     from openset_rcnn_amd.host.train import OpensetRCNNTrainer
     n = images.shape[0]
     tr = OpensetRCNNTrainer(params, dtype=tdt, device=device, lr=1e-4, loss_scale=1024.0 if tdt == torch.float16 else 1.0)
+    tr.sparse_rpn_bwd = not dense_rpn_bwd
     gt, gcls, gcnt = synthetic_gt(n, 800, 1333)
     shapes = [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
     r = sum(a * b for a, b in shapes)
@@ -275,7 +276,10 @@ def train_step_leg(params, tdt, device, images, image_hw, steps: int, warmup: in
                 forward_TFLOPs=round(fwd["conv"] / ms[0] / 1e9, 1), backward_TFLOPs=round((bwd["conv"] + bwd["wgrad"]) / ms[1] / 1e9, 1),
                 whole_iteration_TFLOPs=round((fwd["conv"] + bwd["conv"] + bwd["wgrad"]) * world / dt / 1e12, 1), roofline=roofline,
                 trainable_params=tr.num_params, gradient_bytes_all_reduced=tr.num_params * 4 if world > 1 else 0, gt_boxes_per_image=8,
-                proposals_per_image_train=cap, rois_sampled_per_image=512, loss_total_last=round(total, 4), overflow_skipped_steps=tr.overflow_steps)
+                proposals_per_image_train=cap, rois_sampled_per_image=512, loss_total_last=round(total, 4), overflow_skipped_steps=tr.overflow_steps,
+                rpn_head_backward="on the anchors the loss samples (<= 512 per image; osr_rpn_sparse_rows / gather_cols / scatter_cols_add): hidden state "
+                                  "recomputed, dW and the per-tap data gradient as GEMMs over the listed rows -- the FLOPs above count those, not the "
+                                  "dense launches' 2 x 1.7 TFLOP on zero rows" if tr.sparse_rpn_bwd else "dense (every anchor row)")
 
 
 def train_step_child(args) -> dict:
@@ -474,6 +478,7 @@ def main(argv=None) -> int:
     ap.add_argument("--no-parity", action="store_true", help="skip the fast-mode-vs-fp32 agreement / parity-mode throughput leg")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--train-steps", type=int, default=5)
+    ap.add_argument("--dense-rpn-bwd", action="store_true", help="train step: the CF-RPN head's backward over every anchor row (rounds 1-3), for A/B")
     ap.add_argument("--train-only", action="store_true", help="(internal) run only the train-step leg and print its object")
     ap.add_argument("--streams", type=int, default=1, help="micro-batch streams inside one pass (1 = the pass is one stream of launches)")
     ap.add_argument("--passes-in-flight", type=int, default=4,
@@ -536,7 +541,7 @@ def main(argv=None) -> int:
     params = with_known_unknown_mix(params, emb)
     del cal, keep
     if args.train_only:  # child of the single-GPU run (see train_step_child): the train-step leg in a process of its own
-        print(json.dumps(train_step_leg(params, tdt, dev, images, image_hw, args.train_steps, 2)), flush=True)
+        print(json.dumps(train_step_leg(params, tdt, dev, images, image_hw, args.train_steps, 2, dense_rpn_bwd=args.dense_rpn_bwd)), flush=True)
         return 0
     eng = OpensetRCNNEngine(params, dtype=tdt, device=dev)
     if args.no_chain:

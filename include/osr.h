@@ -599,6 +599,29 @@ osr_status osr_cfrpn_tail_bwd(const void* t, int32_t dtype, int64_t rows, const 
                               float* dw_tail, float* db_tail, int32_t accumulate, void* workspace,
                               int64_t workspace_bytes, void* stream);
 
+/* Sparse backward of the CF-RPN head's shared 3x3 convolution. ClsFreeRPN.losses (classification_free_rpn.py:446-490) sums over
+ * the sampled anchors only (:299-316: <= 2 * BATCH_SIZE_PER_IMAGE per image), so d_out5 -- and the gradient of the hidden state
+ * t = relu(conv3x3(p_l)) (:159-161) -- is zero on every other anchor row; autograd runs the conv's two gradients over the dense,
+ * almost-all-zero tensor. These three entry points restate them on the non-zero rows (csrc/osr_rpn_sparse.hip):
+ *  osr_rpn_sparse_rows: row_ids (cap) = the rows of d_out5 (rows,5) with a non-zero entry, ascending, -1 behind them; row_map
+ *    (rows) = list slot of a row or -1; count2 = {min(found, cap), found}. Rows found beyond cap are dropped (the caller sizes cap
+ *    by the sampling bound and may check count2[1]).
+ *  osr_rpn_gather_cols: cols (cap, 9, 256) in the feature dtype = the im2col row of every listed anchor (tap-major, the 3x3 conv's
+ *    K order; zero outside the map and for the -1 slots) from its level of `feats` (levels as in lv: level-major rows
+ *    (img * h + y) * w + x), and d_out5_rows (cap, 5) = its five gradients. With the head's weight W viewed as (256, 2304):
+ *    t_rows = relu(cols . W^T + b), dW = dt_rows^T . cols, y = dt_rows . W.
+ *  osr_rpn_scatter_cols_add: grads[l] (n, h_l, w_l, 256), in place: every pixel adds, in tap order and in fp32, the rows
+ *    y[row_map[q - tap offset]][tap] of its (<= 9) listed neighbours to the value already there and rounds once (no atomics; a pixel
+ *    that no listed anchor reaches is not touched). y: (cap, 9, 256) fp32. */
+int64_t osr_rpn_sparse_rows_workspace_bytes(void);
+osr_status osr_rpn_sparse_rows(const float* d_out5, int64_t rows, int32_t cap, int32_t* row_ids, int32_t* row_map,
+                               int32_t* count2, void* workspace, int64_t workspace_bytes, void* stream);
+osr_status osr_rpn_gather_cols(const osr_rpn_levels* lv, const osr_pyramid* feats, int32_t feat_dtype, int32_t n,
+                               const int32_t* row_ids, int32_t cap, const float* d_out5, void* cols, float* d_out5_rows,
+                               void* stream);
+osr_status osr_rpn_scatter_cols_add(const osr_rpn_levels* lv, int32_t n, const int32_t* row_map, const float* y,
+                                    void* const* grads, int32_t grad_dtype, void* stream);
+
 /* Gradient of osr_roi_box_losses_fwd w.r.t. the (m,5) predictor output {4 deltas, IoU logit}. workspace 16 bytes. */
 osr_status osr_roi_box_losses_bwd(const float* pred5, const float* proposal_boxes, const float* gt_boxes,
                                   const int64_t* gt_classes, const float* gt_iou, int64_t m, int32_t num_classes,

@@ -31,6 +31,7 @@ SOURCES = {
     "osr_roi_tiled.hip": ["-ffp-contract=off"],
     "osr_det_tail.hip": ["-ffp-contract=off"],
     "osr_train_fwd.hip": ["-ffp-contract=off"],
+    "osr_rpn_sparse.hip": ["-ffp-contract=off"],
     "osr_conv_bwd.hip": [],
     "osr_train_bwd.hip": [],
 }

@@ -190,12 +190,26 @@ __global__ __launch_bounds__(256) void cfrpn_tail_bwd_kernel(const TI* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void cfrpn_tail_bwd_reduce(const float* __restrict__ partial, int nparts, int accumulate, float* __restrict__ dw,
-                                                             float* __restrict__ db) {
-    const int i = blockIdx.x * 256 + threadIdx.x;  // 0 .. 5*256+5
-    if (i >= 5 * 256 + 5) return;
+// 64 columns per workgroup, 16 groups of partials per column summed side by side (each a contiguous run, eight loads in flight), then the
+// 16 group sums in a fixed order: deterministic, and 2048 partials deep instead of one 2048-long dependent chain per thread (0.61 ms)
+#define TAILR_GROUPS 16
+__global__ __launch_bounds__(64 * TAILR_GROUPS) void cfrpn_tail_bwd_reduce(const float* __restrict__ partial, int nparts, int accumulate, float* __restrict__ dw,
+                                                                           float* __restrict__ db) {
+    __shared__ float s_part[TAILR_GROUPS][64];
+    const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + col;  // 0 .. 5*256+5
+    const int per = (nparts + TAILR_GROUPS - 1) / TAILR_GROUPS, p0 = g * per, p1 = p0 + per < nparts ? p0 + per : nparts;
     float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += partial[(long long)p * (5 * 256 + 8) + i];
+    if (i < 5 * 256 + 5) {
+#pragma unroll 8
+        for (int p = p0; p < p1; ++p) s += partial[(long long)p * (5 * 256 + 8) + i];
+    }
+    s_part[g][col] = s;
+    __syncthreads();
+    if (g != 0 || i >= 5 * 256 + 5) return;
+    s = s_part[0][col];
+#pragma unroll
+    for (int k = 1; k < TAILR_GROUPS; ++k) s += s_part[k][col];
     if (i < 5 * 256) dw[i] = (accumulate ? dw[i] : 0.f) + s;
     else db[i - 5 * 256] = (accumulate ? db[i - 5 * 256] : 0.f) + s;
 }
@@ -213,7 +227,7 @@ extern "C" osr_status osr_cfrpn_tail_bwd(const void* t, int32_t dtype, int64_t r
     else
         hipLaunchKernelGGL(cfrpn_tail_bwd_kernel<bf16_t>, dim3(TAILB_BLOCKS), dim3(256), 0, st, (const bf16_t*)t, (long long)rows, w_tail, d_out5, (bf16_t*)dt, (float*)workspace);
     OSR_CHECK_LAUNCH("osr_cfrpn_tail_bwd");
-    hipLaunchKernelGGL(cfrpn_tail_bwd_reduce, dim3((5 * 256 + 5 + 255) / 256), dim3(256), 0, st, (const float*)workspace, TAILB_BLOCKS * 4, accumulate, dw_tail, db_tail);
+    hipLaunchKernelGGL(cfrpn_tail_bwd_reduce, dim3((5 * 256 + 5 + 63) / 64), dim3(64 * TAILR_GROUPS), 0, st, (const float*)workspace, TAILB_BLOCKS * 4, accumulate, dw_tail, db_tail);
     OSR_CHECK_LAUNCH("osr_cfrpn_tail_bwd(reduce)");
     return OSR_OK;
 }
@@ -437,7 +451,7 @@ __global__ __launch_bounds__(256) void pln_bwd_rows_kernel(const float* __restri
 
 // pass 2 (one workgroup per prototype): d phat_k = sum over rows (fixed order) coef * dD/dphat_k(ehat_row) + the centre term, then
 // the projection through the normalisation of the raw prototype
-__global__ __launch_bounds__(256) void pln_bwd_protos_kernel(const float* __restrict__ emb, long long m, int d, const float* __restrict__ protos, int K, int R,
+__global__ __launch_bounds__(1024) void pln_bwd_protos_kernel(const float* __restrict__ emb, long long m, int d, const float* __restrict__ protos, int K, int R,
                                                              int dist_type, const int* __restrict__ pair_idx, const float* __restrict__ pair_coef,
                                                              const float* __restrict__ pair_dist, const float* __restrict__ row_inv, float alpha, float beta,
                                                              float s, const float* __restrict__ rows, int accumulate, float* __restrict__ d_protos) {
@@ -470,49 +484,64 @@ __global__ __launch_bounds__(256) void pln_bwd_protos_kernel(const float* __rest
     __syncthreads();
     const int k = blockIdx.x;
     const float sc = s / fmaxf(rows[0], 1.0f);
-    // Rows whose (intra, inter) prototype pair names k, in row order, PLN_LIST rows at a time: every thread scans a contiguous
-    // run of rows, a prefix sum over the threads' counts gives each its place in the list. The channel loop then visits only
-    // those rows (a few hundred of the 8192), in the same order as a scan over all rows would: the sum is unchanged.
-    constexpr int PLN_LIST = 2048;
-    __shared__ int s_list[PLN_LIST];
-    __shared__ int s_off[257];
-    float acc4[4] = {0.f, 0.f, 0.f, 0.f};  // this thread owns channels tid, tid + 256, ... (d <= 1024)
+    // Rows whose (intra, inter) prototype pair names k, in row order, PLN_LIST rows at a time: a ballot per wave and the waves' counts
+    // give every hit its place in the list, and the thread that found the row parks its scalars (coefficients, distances, 1 / ||e||)
+    // beside it, so the channel loop's only global load is the embedding itself. The loop visits only those rows (a few hundred of
+    // the 8192): the thread groups (256 channels x blockDim / 256 groups) take every ng-th list entry each with several loads in
+    // flight -- one workgroup per prototype used to walk the list as one dependent chain, 0.25 ms -- and the groups' sums are added
+    // in group order at the end: a fixed order, so the result is reproducible.
+    constexpr int PLN_LIST = 512;
+    __shared__ int s_list[PLN_LIST], s_flag[PLN_LIST];
+    __shared__ float s_c0[PLN_LIST], s_c1[PLN_LIST], s_d0[PLN_LIST], s_d1[PLN_LIST], s_ri[PLN_LIST];
+    __shared__ int s_wcnt[16];
+    const int ct = threadIdx.x & 255, grp = threadIdx.x >> 8, ng = (int)blockDim.x >> 8;
+    float acc4[4] = {0.f, 0.f, 0.f, 0.f};  // this thread owns channels ct, ct + 256, ... (d <= 1024) of its group's share of the rows
     for (long long base = 0; base < m; base += PLN_LIST) {
         const int chunk = (int)((m - base) < PLN_LIST ? (m - base) : PLN_LIST);
-        const int seg = (chunk + (int)blockDim.x - 1) / (int)blockDim.x;
-        const int r0 = (int)threadIdx.x * seg, r1 = r0 + seg < chunk ? r0 + seg : chunk;
-        int cnt = 0;
-        for (int r = r0; r < r1; ++r) cnt += (pair_idx[(base + r) * 2] == k || pair_idx[(base + r) * 2 + 1] == k) ? 1 : 0;
-        s_off[threadIdx.x + 1] = cnt;
-        if (threadIdx.x == 0) s_off[0] = 0;
+        const int rr = (int)threadIdx.x;
+        int i0 = -1, i1 = -1;
+        if (rr < chunk) { i0 = pair_idx[(base + rr) * 2]; i1 = pair_idx[(base + rr) * 2 + 1]; }
+        const bool hit = i0 == k || i1 == k;
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) s_wcnt[wid] = __popcll(bal);
         __syncthreads();
-        if (threadIdx.x == 0)
-            for (int t = 1; t <= (int)blockDim.x; ++t) s_off[t] += s_off[t - 1];
+        int off = 0, nlist = 0;
+        for (int w = 0; w < nw; ++w) { const int c = s_wcnt[w]; off += w < wid ? c : 0; nlist += c; }
+        if (hit) {
+            const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+            const long long r = base + rr;
+            s_list[pos] = rr;
+            s_flag[pos] = (i0 == k ? 1 : 0) | (i1 == k ? 2 : 0);
+            s_c0[pos] = pair_coef[r * 2]; s_c1[pos] = pair_coef[r * 2 + 1];
+            s_d0[pos] = pair_dist[r * 2]; s_d1[pos] = pair_dist[r * 2 + 1];
+            s_ri[pos] = row_inv[r];
+        }
         __syncthreads();
-        int pos = s_off[threadIdx.x];
-        for (int r = r0; r < r1; ++r)
-            if (pair_idx[(base + r) * 2] == k || pair_idx[(base + r) * 2 + 1] == k) s_list[pos++] = r;
-        __syncthreads();
-        const int nlist = s_off[blockDim.x];
-        int q = 0;
-        for (int ch = threadIdx.x; ch < d; ch += blockDim.x, ++q) {
-            float acc = acc4[q];
-            const float pk = s_p[k * d + ch];
-            for (int li = 0; li < nlist; ++li) {
-                const long long r = base + s_list[li];
-                const int i0 = pair_idx[r * 2], i1 = pair_idx[r * 2 + 1];
-                const float eh = emb[r * d + ch] * row_inv[r];  // ehat of the row
-                if (i0 == k) acc += pair_coef[r * 2] * osr_pln_ddist_db(eh, pk, pair_dist[r * 2], dist_type);
-                if (i1 == k) acc += pair_coef[r * 2 + 1] * osr_pln_ddist_db(eh, pk, pair_dist[r * 2 + 1], dist_type);
+#pragma unroll 4
+        for (int li = grp; li < nlist; li += ng) {
+            const long long r = base + s_list[li];
+            const int f = s_flag[li];
+            const float ri = s_ri[li], c0 = s_c0[li], c1 = s_c1[li], d0 = s_d0[li], d1 = s_d1[li];
+            int q = 0;
+            for (int ch = ct; ch < d; ch += 256, ++q) {
+                const float pk = s_p[k * d + ch];
+                const float eh = emb[r * d + ch] * ri;  // ehat of the row
+                if (f & 1) acc4[q] += c0 * osr_pln_ddist_db(eh, pk, d0, dist_type);
+                if (f & 2) acc4[q] += c1 * osr_pln_ddist_db(eh, pk, d1, dist_type);
             }
-            acc4[q] = acc;
         }
         __syncthreads();
     }
     float* dph = s_p + KR * d + 3 * KR;  // d phat_k staged behind the tables
-    int qc = 0;
-    for (int ch = threadIdx.x; ch < d; ch += blockDim.x, ++qc) {
-        float acc = acc4[qc];
+    for (int gi = 0; gi < ng; ++gi) {  // the groups' sums, in group order
+        if (grp == gi) {
+            int q = 0;
+            for (int ch = ct; ch < d; ch += 256, ++q) dph[ch] = (gi == 0 ? 0.f : dph[ch]) + acc4[q];
+        }
+        __syncthreads();
+    }
+    for (int ch = threadIdx.x; ch < d; ch += blockDim.x) {
+        float acc = dph[ch];
         // centre term: L += sc * relu(alpha + beta - cd_j) for every prototype j; cd_j = dist(phat_j, phat_arg(j))
         //   dL/dcd_j = -sc [alpha + beta > cd_j];  d phat_k gets dcd_j/dphat_j when k == j and dcd_j/dphat_arg(j) when k == arg(j)
         for (int j = 0; j < KR; ++j) {
@@ -525,7 +554,7 @@ __global__ __launch_bounds__(256) void pln_bwd_protos_kernel(const float* __rest
     }
     __syncthreads();
     // projection: d p = (d phat - phat (phat . d phat)) / ||p||
-    __shared__ float s_dot[4];
+    __shared__ float s_dot[16];
     float part = 0.f;
     for (int ch = threadIdx.x; ch < d; ch += blockDim.x) part += s_p[k * d + ch] * dph[ch];
     part = osr_wave_sum(part);
@@ -572,7 +601,7 @@ extern "C" osr_status osr_pln_loss_bwd_ex(const float* emb, int64_t m, int32_t d
     hipLaunchKernelGGL(pln_bwd_rows_kernel, dim3(256), dim3(256), smem_rows, st, emb, (long long)m, d, protos_raw, num_known, reps, distance_type,
                        (const long long*)gt_classes, ious, iou_thr, alpha, beta, s, (const float*)rows, d_emb, pair_idx, pair_coef, pair_dist, row_inv);
     OSR_CHECK_LAUNCH("osr_pln_loss_bwd(rows)");
-    hipLaunchKernelGGL(pln_bwd_protos_kernel, dim3((unsigned)kr), dim3(256), smem_protos, st, emb, (long long)m, d, protos_raw, num_known, reps, distance_type,
+    hipLaunchKernelGGL(pln_bwd_protos_kernel, dim3((unsigned)kr), dim3(1024), smem_protos, st, emb, (long long)m, d, protos_raw, num_known, reps, distance_type,
                        (const int*)pair_idx, (const float*)pair_coef, (const float*)pair_dist, (const float*)row_inv, alpha, beta, s, (const float*)rows,
                        accumulate_protos, d_protos);
     OSR_CHECK_LAUNCH("osr_pln_loss_bwd(protos)");

@@ -139,6 +139,10 @@ PROTOTYPES = {
     "osr_rpn_losses_bwd_ex": (I32, [P, P, I32, P, P, P, P, P, P, F32, F32, I32, F32, P, P, P]),
     "osr_cfrpn_tail_bwd_workspace_bytes": (I64, []),
     "osr_cfrpn_tail_bwd": (I32, [P, I32, I64, P, P, P, P, P, I32, P, I64, P]),
+    "osr_rpn_sparse_rows_workspace_bytes": (I64, []),
+    "osr_rpn_sparse_rows": (I32, [P, I64, I32, P, P, P, P, I64, P]),
+    "osr_rpn_gather_cols": (I32, [P, P, I32, I32, P, I32, P, P, P, P]),
+    "osr_rpn_scatter_cols_add": (I32, [P, I32, P, P, P, I32, P]),
     "osr_roi_box_losses_bwd": (I32, [P, P, P, P, P, I64, I32, P, F32, F32, F32, P, P, I64, P]),
     "osr_roi_box_losses_bwd_ex": (I32, [P, P, P, P, P, I64, I32, P, F32, F32, F32, P, P, P, I64, P]),
     "osr_softmax_ce_loss_bwd": (I32, [P, I64, I32, P, I32, F32, F32, P, P, I64, P]),

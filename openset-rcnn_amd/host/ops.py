@@ -1035,6 +1035,50 @@ def cfrpn_tail_bwd(t: torch.Tensor, w_tail: torch.Tensor, d_out5: torch.Tensor):
     return dt, dw, db
 
 
+def rpn_sparse_rows(d_out5: torch.Tensor, cap: int):
+    """The rows of d_out5 (rows,5) with a non-zero gradient: (row_ids (cap) int32 ascending, -1 behind them; row_map (rows) int32 =
+    list slot or -1; count2 = {listed, found})."""
+    lib = _lib.load()
+    _need(d_out5, torch.float32, "d_out5")
+    rows = d_out5.shape[0]
+    dev = d_out5.device
+    ids = torch.empty((cap,), dtype=torch.int32, device=dev)
+    rmap = torch.empty((rows,), dtype=torch.int32, device=dev)
+    cnt = torch.empty((2,), dtype=torch.int32, device=dev)
+    wsb = lib.osr_rpn_sparse_rows_workspace_bytes()
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    check(lib.osr_rpn_sparse_rows(_p(d_out5), rows, cap, _p(ids), _p(rmap), _p(cnt), _p(ws), wsb, _stream()), "osr_rpn_sparse_rows")
+    return ids, rmap, cnt
+
+
+def rpn_gather_cols(lv: RpnLevels, feats: List[torch.Tensor], n: int, row_ids: torch.Tensor, d_out5: torch.Tensor):
+    """-> (cols (cap, 2304) in the feature dtype: the im2col rows (tap-major) of the listed anchors; d_out5_rows (cap, 5))."""
+    lib = _lib.load()
+    _need(row_ids, torch.int32, "row_ids"); _need(d_out5, torch.float32, "d_out5")
+    py = _pyramid(feats, [1.0] * len(feats))
+    cap = row_ids.shape[0]
+    cols = torch.empty((cap, 9 * 256), dtype=feats[0].dtype, device=row_ids.device)
+    d5r = torch.empty((cap, 5), dtype=torch.float32, device=row_ids.device)
+    check(lib.osr_rpn_gather_cols(C.byref(lv), C.byref(py), _DT[feats[0].dtype], n, _p(row_ids), cap, _p(d_out5), _p(cols), _p(d5r), _stream()),
+          "osr_rpn_gather_cols")
+    return cols, d5r
+
+
+def rpn_scatter_cols_add_(lv: RpnLevels, n: int, row_map: torch.Tensor, y: torch.Tensor, grads: List[torch.Tensor]) -> List[torch.Tensor]:
+    """In place on grads[l] (n, h_l, w_l, 256): += the per-tap data gradients y (cap, 2304) fp32 of the listed anchors (col2im)."""
+    lib = _lib.load()
+    _need(row_map, torch.int32, "row_map"); _need(y, torch.float32, "y")
+    for i, gr in enumerate(grads):
+        _need(gr, grads[0].dtype, f"grads[{i}]")
+        if gr.shape[0] != n or gr.shape[1] != lv.h[i] or gr.shape[2] != lv.w[i] or gr.shape[3] != 256:
+            raise OsrError(f"grads[{i}] must be ({n}, {lv.h[i]}, {lv.w[i]}, 256)")
+    if len(grads) != lv.num_levels or y.shape[1] != 9 * 256:
+        raise OsrError("one gradient tensor per level; y must be (cap, 2304)")
+    ptrs = (C.c_void_p * len(grads))(*[gr.data_ptr() for gr in grads])
+    check(lib.osr_rpn_scatter_cols_add(C.byref(lv), n, _p(row_map), _p(y), ptrs, _DT[grads[0].dtype], _stream()), "osr_rpn_scatter_cols_add")
+    return grads
+
+
 def roi_box_losses_bwd(pred5, proposal_boxes, gt_boxes, gt_classes, gt_iou, num_classes: int, reg_weights=(10.0, 10.0, 5.0, 5.0),
                        box_weight=0.5, iou_weight=0.5, loss_scale=1.0, box_loss=("smooth_l1", 0.0), iou_beta=0.0) -> torch.Tensor:
     lib = _lib.load()

@@ -118,7 +118,9 @@ class OpensetRCNNTrainer:
         self.frozen_bn = frozen_bn or {}
         self.row_scale: Dict[str, torch.Tensor] = {}
         self.eng = OpensetRCNNEngine(params, cfg, dtype, device, class_map, tiled_roi=False)  # (the backward reads (ph, pw, c) rows)
-        self.eng.rpn_keep_hidden = True  # the hidden state of the head is needed by its backward: the fused head kernel also writes it
+        # the CF-RPN head's backward runs on the sampled anchors only and recomputes their hidden state (osr_rpn_sparse.hip); False:
+        # the dense launches of rounds 1-3 (the fused head kernel then also writes the hidden state of every anchor: 0.7 GB)
+        self.sparse_rpn_bwd = True
         self.dtype, self.device = dtype, self.eng.device
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         self.scaler = DynamicLossScale(loss_scale, scale_growth_interval, self.eng.device)
@@ -304,6 +306,7 @@ class OpensetRCNNTrainer:
         s["lat"], s["p"] = lat, out
         # CF-RPN head (unfused: the hidden state t is kept), targets, losses
         keep: dict = {}
+        e.rpn_keep_hidden = not self.sparse_rpn_bwd
         sel = e._rpn(out, image_hw, keep, topk=c["pre_nms_topk_train"])
         s["rpn_t"], s["rpn_shapes"], s["sel"] = keep["rpn_t"], keep["rpn_shapes"], sel
         self._proposal_status = sel["status_flags"]  # read with this iteration's overflow verdict (DynamicLossScale.record)
@@ -397,6 +400,23 @@ class OpensetRCNNTrainer:
             d5 = ops.rpn_losses_bwd(sel["levels"], e.cell_anchors, n, sel["pred_deltas"], sel["pred_ctr"], s["labels"], s["obj_labels"], s["matched_boxes"],
                                     s["ctr_target"], c["rpn_loc_weight"], c["rpn_ctr_weight"], c["rpn_batch_size"], S, box_loss=lt_["rpn_box"],
                                     ctr_beta=lt_["rpn_ctr"][1])
+            if self.sparse_rpn_bwd:
+                # the loss touches the sampled anchors only: list the rows with a gradient, gather their im2col rows, and run the
+                # head's backward on that list (csrc/osr_rpn_sparse.hip) -- hidden state recomputed, weight gradient and per-tap data
+                # gradient as three small GEMMs; the dense launches spent 2 x 1.7 TFLOP on zeros
+                lvl_keys = ("p2", "p3", "p4", "p5", "p6")
+                cap = n * 2 * int(c["rpn_batch_size"])
+                ids, rmap, _ = ops.rpn_sparse_rows(d5, cap)
+                cols, d5r = ops.rpn_gather_cols(sel["levels"], [p[k_] for k_ in lvl_keys], n, ids, d5)
+                w3 = e.w[rn + ".w"].view(256, 9 * 256)
+                t_rows = ops.linear(cols, w3, e.w[rn + ".b"], relu=True)
+                dt_rows, dw_tail, db_tail = ops.cfrpn_tail_bwd(t_rows, e.rpn_wtail, d5r)
+                g["rpn_tail.w"].copy_(dw_tail)
+                g["rpn_tail.b"].copy_(db_tail)
+                ops.conv2d_wgrad(cols.view(1, cap, 1, 9 * 256), dt_rows.view(1, cap, 1, 256), 1, 1, dw=g[rn + ".w"].view(256, 1, 1, 9 * 256))
+                ops.bias_grad(dt_rows, g[rn + ".b"])
+                y_rows = ops.linear(dt_rows, w3.t().contiguous(), ops._zero_bias(9 * 256, self.device), out_dtype=torch.float32)
+                return (rmap, y_rows), torch.cuda.current_stream(self.device).record_event()
             dta, dw_tail, db_tail = ops.cfrpn_tail_bwd(s["rpn_t"], e.rpn_wtail, d5)
             g["rpn_tail.w"].copy_(dw_tail)
             g["rpn_tail.b"].copy_(db_tail)
@@ -458,10 +478,24 @@ class OpensetRCNNTrainer:
         if self.side_wgrad:
             torch.cuda.current_stream(self.device).wait_event(rpn_ready)
             if not torch.cuda.is_current_stream_capturing():
-                dt_all.record_stream(torch.cuda.current_stream(self.device))
+                for t_ in (dt_all if isinstance(dt_all, tuple) else (dt_all,)):
+                    t_.record_stream(torch.cuda.current_stream(self.device))
         dP = {}
+        if self.sparse_rpn_bwd:
+            # col2im of the listed anchors' per-tap gradients straight into the RoI heads' feature gradient (p6: into zeros)
+            rmap, y_rows = dt_all
+            glist = []
+            for li, (k, (h, w)) in enumerate(zip(("p2", "p3", "p4", "p5", "p6"), s["rpn_shapes"])):
+                if li < 4:
+                    glist.append(d_feat[li] if d_feat[li].dtype == dt else ops.add_cast(d_feat[li], None, dt))
+                else:
+                    glist.append(torch.zeros((n, h, w, 256), dtype=dt, device=self.device))
+                dP[k] = glist[-1]
+            ops.rpn_scatter_cols_add_(sel["levels"], n, rmap, y_rows, glist)
         off = 0
         for li, (k, (h, w)) in enumerate(zip(("p2", "p3", "p4", "p5", "p6"), s["rpn_shapes"])):
+            if self.sparse_rpn_bwd:
+                break
             rows = n * h * w
             dtl = dt_all[off:off + rows].view(n, h, w, 256)
             off += rows

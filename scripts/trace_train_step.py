@@ -33,3 +33,15 @@ for q, ks in sorted(byq.items(), key=lambda kv: kv[1][0][0]):
         cov = sum(max(0, min(e, hi) - max(s, lo)) for s, e, _ in ks) / 1e6
         line.append("#" if cov > 0.66 else ("+" if cov > 0.33 else ("." if cov > 0.02 else " ")))
     print(f"queue {q:>3s} |{''.join(line)}|")
+# --list: every kernel of the busiest queue in launch order with the idle gap in front of it (where the critical path waits)
+if "--list" in sys.argv:
+    q, ks = max(byq.items(), key=lambda kv: sum(e - s for s, e, _ in kv[1]))
+    print(f"queue {q} in order: start ms, duration us, gap before us, kernel")
+    prev = None
+    gaps = 0.0
+    for s, e, n in ks:
+        gap = (s - prev) / 1e3 if prev is not None else 0.0
+        gaps += max(gap, 0.0)
+        print(f"{s / 1e6:7.3f} {(e - s) / 1e3:8.1f} {gap:7.1f}  {n}")
+        prev = e
+    print(f"sum of gaps {gaps / 1e3:.2f} ms")
