@@ -167,40 +167,51 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(RsGeom g, const int* __
     const int lane = threadIdx.x & 63;
     const long long total = g.off[g.nl];
     const long long r = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;
-    int l = 0, img = 0, py = 0, px = 0;
-    bool any = false;
+    int mj[9];  // list slot of the anchor that reaches this pixel through tap t, or -1
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) mj[tap] = -1;
+    int l = 0;
     if (r < total) {
+        int img, py, px;
         rs_decode(g, r, l, img, py, px);
         const long long lb = g.off[l] + (long long)img * g.h[l] * g.w[l];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int qy = py - (tap / 3 - 1), qx = px - (tap % 3 - 1);
-            if (qy >= 0 && qy < g.h[l] && qx >= 0 && qx < g.w[l]) any |= row_map[lb + (long long)qy * g.w[l] + qx] >= 0;
+            if (qy >= 0 && qy < g.h[l] && qx >= 0 && qx < g.w[l]) mj[tap] = row_map[lb + (long long)qy * g.w[l] + qx];
         }
     }
+    bool any = false;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) any |= mj[tap] >= 0;
     unsigned long long bal = __ballot(any);
-    while (bal) {
+    while (bal) {  // one reached pixel per turn: its nine slots come from the lane that looked at it, the nine rows of y are loaded side by side
         const int src = __builtin_ctzll(bal);
         bal &= bal - 1;
-        const int sl = __shfl(l, src), si = __shfl(img, src), sy = __shfl(py, src), sx = __shfl(px, src);
+        const int sl = __shfl(l, src);
         const long long rr = r - lane + src;
-        const int h = g.h[sl], w = g.w[sl];
-        const long long lb = g.off[sl] + (long long)si * h * w;
         T* dst = reinterpret_cast<T*>(g.grad[sl]) + ((rr - g.off[sl]) * 256 + lane * 4);
-        float acc[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = osr_to_float(dst[e]);
+        int j[9];
+        float4 v[9];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int qy = sy - (tap / 3 - 1), qx = sx - (tap % 3 - 1);
-            if (qy < 0 || qy >= h || qx < 0 || qx >= w) continue;  // (wave-uniform)
-            const int j = row_map[lb + (long long)qy * w + qx];
-            if (j < 0) continue;
-            const float4 v = *reinterpret_cast<const float4*>(y + ((long long)j * 9 + tap) * 256 + lane * 4);
-            acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+            j[tap] = __shfl(mj[tap], src);
+            v[tap] = *reinterpret_cast<const float4*>(y + ((long long)(j[tap] < 0 ? 0 : j[tap]) * 9 + tap) * 256 + lane * 4);
         }
+        typedef T v4t __attribute__((ext_vector_type(4)));
+        const v4t cur = *reinterpret_cast<const v4t*>(dst);
+        float acc[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dst[e] = osr_from_float<T>(acc[e]);
+        for (int e = 0; e < 4; ++e) acc[e] = (float)cur[e];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (j[tap] < 0) continue;  // (wave-uniform; slot 0's row was loaded in its place and is dropped here)
+            acc[0] += v[tap].x; acc[1] += v[tap].y; acc[2] += v[tap].z; acc[3] += v[tap].w;
+        }
+        v4t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = osr_from_float<T>(acc[e]);
+        *reinterpret_cast<v4t*>(dst) = o;
     }
 }
 

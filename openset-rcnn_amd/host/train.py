@@ -180,6 +180,9 @@ class OpensetRCNNTrainer:
         self.overlap_targets = True
         self._wside: Optional[torch.cuda.Stream] = None  # stream of the weight / bias gradient launches (see _wg)
         self.side_wgrad = True
+        # blocks whose weight gradients ride on the main stream (measured with res3.0 / res3.0-1 / all of res3: 25.4-25.5 against 25.5-25.7 ms,
+        # inside the run-to-run spread: the backward is bound by the sum of its kernels, not by which stream ends last) -- left empty
+        self.wgrad_on_main: set = set()
         self._refresh_derived()
 
     @property
@@ -362,12 +365,12 @@ class OpensetRCNNTrainer:
             for b in ready:
                 self.buckets.issue(b)
 
-    def _wg(self, fn, *reads: torch.Tensor) -> None:
+    def _wg(self, fn, *reads: torch.Tensor, main: bool = False) -> None:
         """Run a weight / bias gradient launch group off the critical path: the chain of data gradients (dy of a layer -> dy of the
         layer below) stays on the main stream, the launches that only consume a layer's dy and its saved input (wgrad, its split
         reduction, the bias gradient) go to a second stream, where they fill the sparse last rounds of the data-gradient kernels
         and vice versa. `reads`: the tensors of the main stream the launches read (kept alive for the second stream)."""
-        if not self.side_wgrad:
+        if not self.side_wgrad or main:
             fn()
             return
         cur = torch.cuda.current_stream(self.device)
@@ -533,14 +536,17 @@ class OpensetRCNNTrainer:
             if last_of_stage:  # the stage output also feeds its FPN lateral
                 d_ls, ln = d_res[blk["stage"]]
                 G = ops.conv2d_dgrad(d_ls, self.wd[ln], (hy, wy), 1, 0, add=G, post_mask=y)
+            # (the last blocks of the backward: the weight-gradient stream is behind the data-gradient chain by then and nothing waits for
+            # the chain's end, so their weight gradients ride on the main stream, beside the other stream's backlog)
+            on_main = pre in self.wgrad_on_main
             d_o2 = ops.conv2d_dgrad(G, self.wd[pre + ".conv3"], (hy, wy), 1, 0, mask=o2)
-            self._wg(lambda o2=o2, G=G, pre=pre: ops.conv2d_wgrad(o2, G, 1, 1, dw=g[pre + ".conv3.w"]), G)
+            self._wg(lambda o2=o2, G=G, pre=pre: ops.conv2d_wgrad(o2, G, 1, 1, dw=g[pre + ".conv3.w"]), G, main=on_main)
             d_o1 = ops.conv2d_dgrad(d_o2, self.wd[pre + ".conv2"], (o1.shape[1], o1.shape[2]), 1, 1, mask=o1)
             self._wg(lambda o1=o1, d_o2=d_o2, x=x, d_o1=d_o1, pre=pre, stride=stride: (
                 ops.conv2d_wgrad(o1, d_o2, 3, 3, 1, 1, dw=g[pre + ".conv2.w"]),
-                ops.conv2d_wgrad(x, d_o1, 1, 1, stride, 0, dw=g[pre + ".conv1.w"])), d_o2, d_o1)
+                ops.conv2d_wgrad(x, d_o1, 1, 1, stride, 0, dw=g[pre + ".conv1.w"])), d_o2, d_o1, main=on_main)
             if blk["first"]:
-                self._wg(lambda x=x, G=G, pre=pre, stride=stride: ops.conv2d_wgrad(x, G, 1, 1, stride, 0, dw=g[pre + ".shortcut.w"]), G)
+                self._wg(lambda x=x, G=G, pre=pre, stride=stride: ops.conv2d_wgrad(x, G, 1, 1, stride, 0, dw=g[pre + ".shortcut.w"]), G, main=on_main)
                 self._done(pre + ".shortcut.w")
             self._done(pre + ".conv3.w", pre + ".conv2.w", pre + ".conv1.w")
             if blk["first"] and blk["stage"] == self.freeze_at + 1:
