@@ -638,6 +638,7 @@ def main(argv=None) -> int:
     # one collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x2 per the gfx950 guide) on this
     # very command by scripts/profile_round.sh and committed under profiles/ (newest round first); null when absent.
     traffic, traffic_source, hbm_traffic = None, None, None
+    profile_ms, profile_tag = None, None  # the same family's time per step in the newest committed rocprofv3 --stats summary
     import glob
     for tfile in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_times_and_traffic.json")), reverse=True):  # newest round / letter first
         tag = os.path.basename(tfile)[: -len("_kernel_times_and_traffic.json")]
@@ -650,6 +651,7 @@ def main(argv=None) -> int:
             if ra:
                 hbm_traffic = round(ra.get("fetch_GB_per_step_x2corrected", 0.0) + ra.get("write_GB_per_step", 0.0), 2)
             traffic_source = f"profiles/{tag}_kernel_times_and_traffic.json (scripts/profile_round.sh: --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+            profile_ms, profile_tag = cf.get("ms_per_step"), tag
             break
     if world == 1 and rank == 0 and not args.no_pmc:
         live = measure_traffic()
@@ -667,6 +669,12 @@ def main(argv=None) -> int:
                                "proposals that exist, not for the padding rows of the fixed-capacity lists",
                     flops_per_step_nominal=mfma_flops_nominal, frac_nominal=round(mfma_flops_nominal / (mfma_ms * 1e-3) / 1e12 / peak, 4) if mfma_ms > 0 else 0.0,
                     real_proposals=real_rois, proposal_list_rows=list_rows)
+    if profile_ms:
+        # the committed profiler summary of the same command gives the family a few percent more time than the HIP events of this run
+        # (another box, the tracer's per-dispatch cost): both are printed so that the fraction reads as a range, not a point
+        roofline["kernel_ms_per_step_profile"] = profile_ms
+        roofline["frac_profile"] = round(mfma_flops / (profile_ms * 1e-3) / 1e12 / peak, 4)
+        roofline["profile_source"] = f"profiles/{profile_tag}_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --steps 5 --warmup 2 --streams 1 --no-graph`)"
     # the two figures north_star's targets are worded in: (1) the R50 + FPN backbone alone (its MFMA launches' FLOPs over their
     # own time); (2) SURVEY.md 8d's dense-conv group formula, 392.9 GFLOP (ResNet-50 + FPN + CF-RPN head at 800 x 1344) x img/s
     bb = [(f, e0.elapsed_time(e1)) for name, f, e0, e1, _, _ in prof if name.startswith("backbone.")]
