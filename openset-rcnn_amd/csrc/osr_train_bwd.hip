@@ -369,6 +369,7 @@ extern "C" osr_status osr_softmax_ce_loss_bwd(const float* logits, int64_t m, in
 // PLN hinge loss backward: d emb (m,d) and d prototypes (K,d) w.r.t. the RAW (un-normalised) prototypes
 // ------------------------------------------------------------------------------------------------------
 // pass 1 (wave per row): coefficients of the two prototypes a foreground row pulls on, and the row's d emb
+template <int NJ>
 __global__ __launch_bounds__(256) void pln_bwd_rows_kernel(const float* __restrict__ emb, long long m, int d, const float* __restrict__ protos, int K, int R,
                                                            int dist_type, const long long* __restrict__ cls, const float* __restrict__ ious, float iou_thr,
                                                            float alpha, float beta, float s, const float* __restrict__ rows, float* __restrict__ d_emb,
@@ -387,53 +388,103 @@ __global__ __launch_bounds__(256) void pln_bwd_rows_kernel(const float* __restri
     __syncthreads();
     const float sc = s / fmaxf(rows[0], 1.0f);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (long long r = (long long)blockIdx.x * nw + wid; r < m; r += (long long)gridDim.x * nw) {
+    const int W = (int)gridDim.x * nw, w = (int)blockIdx.x * nw + wid;
+    for (long long k = 0; k * W < m; ++k) {
+        const long long r = osr_pln_row(k, w, W);
+        if (r >= m) continue;
         const long long y = cls[r];
+        const float iou = ious[r];  // (both loads up front: one round trip)
         float* de = d_emb + r * d;
-        const bool fg = y >= 0 && y < K && ious[r] > iou_thr;
+        const bool fg = y >= 0 && y < K && iou > iou_thr;
         int i0 = -1, i1 = -1;
         float c0 = 0.f, c1 = 0.f, d0 = 0.f, d1 = 0.f, rinv = 0.f;
         if (fg) {
             const float* e = emb + r * d;
+            const bool in_regs = d <= NJ * 64;  // (wave-uniform) the normalised row lives in registers for the class loop
+            float ehr[NJ];  // the row, read once: ||e|| from these registers, then scaled in place
             float ss = 0.f;
-            for (int i = lane; i < d; i += 64) { const float x = e[i]; ss += x * x; }
+            if (in_regs) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { const int i = lane + 64 * j; ehr[j] = i < d ? e[i] : 0.f; ss += ehr[j] * ehr[j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) ehr[j] = 0.f;
+                for (int i = lane; i < d; i += 64) { const float x = e[i]; ss += x * x; }
+            }
             ss = osr_wave_sum(ss);
             const float nrm = sqrtf(ss), inv = 1.0f / fmaxf(nrm, 1e-12f);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) ehr[j] = ehr[j] * inv;
             // own class: its nearest prototype (i0, intra); other classes: the nearest prototype of the nearest class (i1, inter)
             float intra = 0.f, inter = 1000.f;
             int pstar = -1, ystar = -1;
-            const bool in_regs = d <= OSR_PLN_REG * 64;  // (wave-uniform) the normalised row lives in registers for the class loop
-            float ehr[OSR_PLN_REG];
-#pragma unroll
-            for (int j = 0; j < OSR_PLN_REG; ++j) { const int i = lane + 64 * j; ehr[j] = (in_regs && i < d) ? e[i] * inv : 0.f; }
-            for (int c = 0; c < K; ++c) {
+            if (in_regs) {  // the prototypes four at a time, in order (osr_pln_distance_reg4); same comparisons in the same order as the class loop below
                 float dist = 0.f;
-                int arg = c * R;
-                for (int q = 0; q < R; ++q) {
-                    const float* pq = s_p + (size_t)(c * R + q) * d;
-                    const float dq = in_regs ? osr_pln_distance_reg(ehr, pq, d, lane, dist_type)
-                                             : osr_pln_distance([&](int i) { return e[i] * inv; }, pq, d, lane, dist_type);
-                    if (q == 0 || dq < dist) { dist = dq; arg = c * R + q; }
+                int arg = 0;
+                for (int k0 = 0; k0 < KR; k0 += 4) {
+                    float dq[4];
+                    osr_pln_distance_reg4<NJ>(ehr, s_p + (size_t)k0 * d, d, KR - k0 < 4 ? KR - k0 : 4, lane, dist_type, dq);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int kr = k0 + t;
+                        if (kr < KR) {
+                            const int c = kr / R, q = kr - c * R;
+                            if (q == 0 || dq[t] < dist) { dist = dq[t]; arg = kr; }
+                            if (q == R - 1) {
+                                if (c == (int)y) { intra = dist; ystar = arg; }
+                                else if (dist < inter) { inter = dist; pstar = arg; }
+                            }
+                        }
+                    }
                 }
-                if (c == (int)y) { intra = dist; ystar = arg; }
-                else if (dist < inter) { inter = dist; pstar = arg; }
+            } else {
+                for (int c = 0; c < K; ++c) {
+                    float dist = 0.f;
+                    int arg = c * R;
+                    for (int q = 0; q < R; ++q) {
+                        const float dq = osr_pln_distance([&](int i) { return e[i] * inv; }, s_p + (size_t)(c * R + q) * d, d, lane, dist_type);
+                        if (q == 0 || dq < dist) { dist = dq; arg = c * R + q; }
+                    }
+                    if (c == (int)y) { intra = dist; ystar = arg; }
+                    else if (dist < inter) { inter = dist; pstar = arg; }
+                }
             }
             // dL/dD_y = sc [D_y > alpha];  dL/dD_c* = -sc [beta > D_c*]
             const float gy = intra - alpha > 0.f ? sc : 0.f, gc = (pstar >= 0 && beta - inter > 0.f) ? -sc : 0.f;
             // d ehat = gy dD/dehat(p_y*) + gc dD/dehat(p_c*);  d e = (d ehat - ehat (ehat . d ehat)) / ||e||
             float dot = 0.f;
-            for (int i = lane; i < d; i += 64) {
-                const float eh = e[i] * inv;
-                const float dh = gy * osr_pln_ddist_da(eh, s_p[ystar * d + i], intra, dist_type) +
-                                 (pstar >= 0 ? gc * osr_pln_ddist_da(eh, s_p[pstar * d + i], inter, dist_type) : 0.f);
-                dot += eh * dh;
-            }
-            dot = osr_wave_sum(dot);
-            for (int i = lane; i < d; i += 64) {
-                const float eh = e[i] * inv;
-                const float dh = gy * osr_pln_ddist_da(eh, s_p[ystar * d + i], intra, dist_type) +
-                                 (pstar >= 0 ? gc * osr_pln_ddist_da(eh, s_p[pstar * d + i], inter, dist_type) : 0.f);
-                de[i] = nrm > 1e-12f ? (dh - eh * dot) * inv : dh * inv;
+            if (in_regs) {
+                float dhr[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int i = lane + 64 * j;
+                    dhr[j] = 0.f;
+                    if (i < d) {
+                        dhr[j] = gy * osr_pln_ddist_da(ehr[j], s_p[ystar * d + i], intra, dist_type) +
+                                 (pstar >= 0 ? gc * osr_pln_ddist_da(ehr[j], s_p[pstar * d + i], inter, dist_type) : 0.f);
+                        dot += ehr[j] * dhr[j];
+                    }
+                }
+                dot = osr_wave_sum(dot);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int i = lane + 64 * j;
+                    if (i < d) de[i] = nrm > 1e-12f ? (dhr[j] - ehr[j] * dot) * inv : dhr[j] * inv;
+                }
+            } else {
+                for (int i = lane; i < d; i += 64) {
+                    const float eh = e[i] * inv;
+                    const float dh = gy * osr_pln_ddist_da(eh, s_p[ystar * d + i], intra, dist_type) +
+                                     (pstar >= 0 ? gc * osr_pln_ddist_da(eh, s_p[pstar * d + i], inter, dist_type) : 0.f);
+                    dot += eh * dh;
+                }
+                dot = osr_wave_sum(dot);
+                for (int i = lane; i < d; i += 64) {
+                    const float eh = e[i] * inv;
+                    const float dh = gy * osr_pln_ddist_da(eh, s_p[ystar * d + i], intra, dist_type) +
+                                     (pstar >= 0 ? gc * osr_pln_ddist_da(eh, s_p[pstar * d + i], inter, dist_type) : 0.f);
+                    de[i] = nrm > 1e-12f ? (dh - eh * dot) * inv : dh * inv;
+                }
             }
             // d phat_y* += gy dD/dphat ; d phat_c* += gc dD/dphat (pass 2)
             i0 = ystar; c0 = gy; d0 = intra; i1 = pstar; c1 = gc; d1 = inter; rinv = inv;
@@ -594,12 +645,17 @@ extern "C" osr_status osr_pln_loss_bwd_ex(const float* emb, int64_t m, int32_t d
     if (smem_protos > 64 * 1024) {
         static osr_dev_mask attr{0};
         osr_once_per_device(attr, [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pln_bwd_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pln_bwd_rows_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pln_bwd_rows_kernel<OSR_PLN_REG>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pln_bwd_protos_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         });
     }
-    hipLaunchKernelGGL(pln_bwd_rows_kernel, dim3(256), dim3(256), smem_rows, st, emb, (long long)m, d, protos_raw, num_known, reps, distance_type,
-                       (const long long*)gt_classes, ious, iou_thr, alpha, beta, s, (const float*)rows, d_emb, pair_idx, pair_coef, pair_dist, row_inv);
+    if (d <= 256)
+        hipLaunchKernelGGL(pln_bwd_rows_kernel<4>, dim3(256), dim3(256), smem_rows, st, emb, (long long)m, d, protos_raw, num_known, reps, distance_type,
+                           (const long long*)gt_classes, ious, iou_thr, alpha, beta, s, (const float*)rows, d_emb, pair_idx, pair_coef, pair_dist, row_inv);
+    else
+        hipLaunchKernelGGL(pln_bwd_rows_kernel<OSR_PLN_REG>, dim3(256), dim3(256), smem_rows, st, emb, (long long)m, d, protos_raw, num_known, reps, distance_type,
+                           (const long long*)gt_classes, ious, iou_thr, alpha, beta, s, (const float*)rows, d_emb, pair_idx, pair_coef, pair_dist, row_inv);
     OSR_CHECK_LAUNCH("osr_pln_loss_bwd(rows)");
     hipLaunchKernelGGL(pln_bwd_protos_kernel, dim3((unsigned)kr), dim3(1024), smem_protos, st, emb, (long long)m, d, protos_raw, num_known, reps, distance_type,
                        (const int*)pair_idx, (const float*)pair_coef, (const float*)pair_dist, (const float*)row_inv, alpha, beta, s, (const float*)rows,

@@ -348,16 +348,26 @@ __device__ __forceinline__ void tr_block_reduce_store(float v[NV], float* __rest
 struct TrScale { float s[RED_MAXV]; };
 // out[q] = scale[q] * sum_b partial[b][q] (fixed order); with norm_col >= 0 every column q < norm_col is also divided by
 // max(sum_b partial[b][norm_col], 1) -- the "rows that count" normaliser when the row list is padded.
-__global__ void tr_final_reduce(const float* __restrict__ partial, int nblocks, int nv, TrScale scale, int norm_col, float* __restrict__ out) {
-    const int q = threadIdx.x;
-    if (q >= nv) return;
-    float x = 0.f, c = 0.f;
-    for (int b = 0; b < nblocks; ++b) x += partial[(long long)b * nv + q];
-    if (norm_col >= 0 && q < norm_col) {
-        for (int b = 0; b < nblocks; ++b) c += partial[(long long)b * nv + norm_col];
-        x = x / fmaxf(c, 1.0f);
+// One wave: lane l adds the partials of workgroups l, l + 64, ... of column q, then the 64 lane sums go down a shuffle tree -- a fixed
+// order, so the value is reproducible. (One thread walking all the workgroups' partials was a 16-30 us dependent chain per loss, four
+// times on the training step's critical stream.)
+__device__ __forceinline__ float tr_wave_column_sum(const float* __restrict__ partial, int nblocks, int nv, int q) {
+    const int lane = threadIdx.x & 63;
+    float x = 0.f;
+#pragma unroll 4
+    for (int b = lane; b < nblocks; b += 64) x += partial[(long long)b * nv + q];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
+    return __shfl(x, 0, 64);
+}
+
+__global__ __launch_bounds__(64) void tr_final_reduce(const float* __restrict__ partial, int nblocks, int nv, TrScale scale, int norm_col, float* __restrict__ out) {
+    const float c = norm_col >= 0 ? tr_wave_column_sum(partial, nblocks, nv, norm_col) : 1.0f;
+    for (int q = 0; q < nv; ++q) {
+        float x = tr_wave_column_sum(partial, nblocks, nv, q);
+        if (norm_col >= 0 && q < norm_col) x = x / fmaxf(c, 1.0f);
+        if (threadIdx.x == 0) out[q] = x * scale.s[q];
     }
-    out[q] = x * scale.s[q];
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -614,63 +624,101 @@ extern "C" osr_status osr_roi_box_losses_fwd(const float* pred_deltas, int32_t d
 // ------------------------------------------------------------------------------------------------------
 // PLN hinge loss forward (prototype_learning_network.py:133-187, COS distance, one prototype per class)
 // ------------------------------------------------------------------------------------------------------
+template <int NJ>
 __global__ __launch_bounds__(256) void pln_loss_kernel(const float* __restrict__ emb, long long m, int d, const float* __restrict__ protos, int K, int R,
                                                        int dist_type, const long long* __restrict__ cls, const float* __restrict__ ious, float iou_thr,
                                                        float alpha, float beta, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float s_p[];  // [K * R][d]: R prototypes per class, class-major
     const int KR = K * R;
-    for (int i = threadIdx.x; i < KR * d; i += blockDim.x) s_p[i] = protos[i];
+    if (((KR * d) & 3) == 0 && (reinterpret_cast<uintptr_t>(protos) & 15) == 0) {  // 16-byte copies, four in flight per thread
+        const int n4 = (KR * d) >> 2;
+#pragma unroll 4
+        for (int i = threadIdx.x; i < n4; i += blockDim.x) reinterpret_cast<float4*>(s_p)[i] = reinterpret_cast<const float4*>(protos)[i];
+    } else {
+        for (int i = threadIdx.x; i < KR * d; i += blockDim.x) s_p[i] = protos[i];
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     float v[4] = {0.f, 0.f, 0.f, 0.f};  // intra, inter, center, rows that count (class >= 0; padding rows carry -1)
-    for (long long r = (long long)blockIdx.x * nw + wid; r < m; r += (long long)gridDim.x * nw) {
+    const int W = (int)gridDim.x * nw, w = (int)blockIdx.x * nw + wid;
+    for (long long k = 0; k * W < m; ++k) {
+        const long long r = osr_pln_row(k, w, W);
+        if (r >= m) continue;
         const long long y = cls[r];
+        const float iou = ious[r];  // (both loads up front: one round trip)
         if (lane == 0 && y >= 0) v[3] += 1.f;
-        if (!(y >= 0 && y < K && ious[r] > iou_thr)) continue;  // foreground of a known class with IoU above the threshold
+        if (!(y >= 0 && y < K && iou > iou_thr)) continue;  // foreground of a known class with IoU above the threshold
         const float* e = emb + r * d;
+        const bool in_regs = d <= NJ * 64;  // (wave-uniform) the normalised row lives in registers for the class loop
+        float eh[NJ];  // the row, read once: ||e|| from these registers, then divided in place
         float ss = 0.f;
-        for (int i = lane; i < d; i += 64) { const float x = e[i]; ss += x * x; }
+        if (in_regs) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { const int i = lane + 64 * j; eh[j] = i < d ? e[i] : 0.f; ss += eh[j] * eh[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) eh[j] = 0.f;
+            for (int i = lane; i < d; i += 64) { const float x = e[i]; ss += x * x; }
+        }
         ss = osr_wave_sum(ss);
         const float den = fmaxf(sqrtf(ss), 1e-12f);
         float intra = 0.f, inter = 1000.f;  // the reference overwrites the own-class column with 1000 before the min
-        const bool in_regs = d <= OSR_PLN_REG * 64;  // (wave-uniform) the normalised row lives in registers for the class loop
-        float eh[OSR_PLN_REG];
 #pragma unroll
-        for (int j = 0; j < OSR_PLN_REG; ++j) { const int i = lane + 64 * j; eh[j] = (in_regs && i < d) ? e[i] / den : 0.f; }
-        for (int c = 0; c < K; ++c) {
-            float dist = 0.f;  // min over the class's prototypes (prototype_learning_network.py:163)
-            for (int q = 0; q < R; ++q) {
-                const float* pq = s_p + (size_t)(c * R + q) * d;
-                const float dq = in_regs ? osr_pln_distance_reg(eh, pq, d, lane, dist_type)
-                                         : osr_pln_distance([&](int i) { return e[i] / den; }, pq, d, lane, dist_type);
-                dist = (q == 0 || dq < dist) ? dq : dist;
+        for (int j = 0; j < NJ; ++j) eh[j] = eh[j] / den;
+        if (in_regs) {  // the prototypes four at a time, in order; a class's distance is the minimum over its R consecutive prototypes (prototype_learning_network.py:163)
+            float dist = 0.f;
+            for (int k0 = 0; k0 < KR; k0 += 4) {
+                float dq[4];
+                osr_pln_distance_reg4<NJ>(eh, s_p + (size_t)k0 * d, d, KR - k0 < 4 ? KR - k0 : 4, lane, dist_type, dq);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int kr = k0 + t;
+                    if (kr < KR) {
+                        const int c = kr / R, q = kr - c * R;
+                        dist = (q == 0 || dq[t] < dist) ? dq[t] : dist;
+                        if (q == R - 1) { if (c == (int)y) intra = dist; else inter = fminf(inter, dist); }
+                    }
+                }
             }
-            if (c == (int)y) intra = dist; else inter = fminf(inter, dist);
+        } else {
+            for (int c = 0; c < K; ++c) {
+                float dist = 0.f;
+                for (int q = 0; q < R; ++q) {
+                    const float dq = osr_pln_distance([&](int i) { return e[i] / den; }, s_p + (size_t)(c * R + q) * d, d, lane, dist_type);
+                    dist = (q == 0 || dq < dist) ? dq : dist;
+                }
+                if (c == (int)y) intra = dist; else inter = fminf(inter, dist);
+            }
         }
         if (lane == 0) { v[0] += fmaxf(intra - alpha, 0.f); v[1] += fmaxf(beta - inter, 0.f); }
     }
-    // prototype-to-prototype term, once (workgroup 0): c_dist[k] = min over the prototypes j of OTHER classes of dist(p_k, p_j)
-    // (prototype_learning_network.py:170-180: the diagonal class blocks are overwritten with 1000)
-    if (blockIdx.x == 0) {
-        for (int k = wid; k < KR; k += nw) {
-            float cd = 1000.f;
-            for (int j = 0; j < KR; ++j) {
-                if (j / R == k / R) continue;
-                const float* pk = s_p + (size_t)k * d;
-                cd = fminf(cd, osr_pln_distance([&](int i) { return pk[i]; }, s_p + (size_t)j * d, d, lane, dist_type));
-            }
-            if (lane == 0) v[2] += fmaxf(beta + alpha - cd, 0.f);
+    // prototype-to-prototype term, once: c_dist[k] = min over the prototypes j of OTHER classes of dist(p_k, p_j)
+    // (prototype_learning_network.py:170-180: the diagonal class blocks are overwritten with 1000). Workgroup b takes prototypes b,
+    // b + gridDim.x, ..., its waves every nw-th j each (all of them in workgroup 0 was a 24 us tail behind that workgroup's rows).
+    __shared__ float s_cdw[16];
+    for (int k = blockIdx.x; k < KR; k += gridDim.x) {  // (uniform over the workgroup)
+        float cd = 1000.f;
+        const float* pk = s_p + (size_t)k * d;
+        for (int j = wid; j < KR; j += nw) {
+            if (j / R == k / R) continue;
+            cd = fminf(cd, osr_pln_distance([&](int i) { return pk[i]; }, s_p + (size_t)j * d, d, lane, dist_type));
+        }
+        __syncthreads();
+        if (lane == 0) s_cdw[wid] = cd;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w2 = 1; w2 < nw; ++w2) cd = fminf(cd, s_cdw[w2]);
+            v[2] += fmaxf(beta + alpha - cd, 0.f);
         }
     }
     tr_block_reduce_store<4>(v, partial);
 }
 
 // loss = weight / M * (sum intra + sum inter + sum center), each sum in workgroup order
-__global__ void pln_finish(const float* __restrict__ partial, int nblocks, float scale, float* __restrict__ out) {
-    if (threadIdx.x != 0) return;
-    float a = 0.f, b = 0.f, c = 0.f, rows = 0.f;
-    for (int i = 0; i < nblocks; ++i) { a += partial[i * 4]; b += partial[i * 4 + 1]; c += partial[i * 4 + 2]; rows += partial[i * 4 + 3]; }
-    out[0] = ((a + b) + c) * scale / fmaxf(rows, 1.0f);
+__global__ __launch_bounds__(64) void pln_finish(const float* __restrict__ partial, int nblocks, float scale, float* __restrict__ out) {
+    const float a = tr_wave_column_sum(partial, nblocks, 4, 0), b = tr_wave_column_sum(partial, nblocks, 4, 1);
+    const float c = tr_wave_column_sum(partial, nblocks, 4, 2), rows = tr_wave_column_sum(partial, nblocks, 4, 3);
+    if (threadIdx.x == 0) out[0] = ((a + b) + c) * scale / fmaxf(rows, 1.0f);
 }
 
 extern "C" osr_status osr_pln_loss_fwd_ex(const float* emb, int64_t m, int32_t d, const float* protos_normed, int32_t num_known, int32_t reps,
@@ -686,10 +734,17 @@ extern "C" osr_status osr_pln_loss_fwd_ex(const float* emb, int64_t m, int32_t d
     const size_t smem = (size_t)num_known * reps * d * 4;
     if (smem > 64 * 1024) {
         static osr_dev_mask attr{0};
-        osr_once_per_device(attr, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pln_loss_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); });
+        osr_once_per_device(attr, [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pln_loss_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pln_loss_kernel<OSR_PLN_REG>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        });
     }
-    hipLaunchKernelGGL(pln_loss_kernel, dim3(RED_BLOCKS), dim3(256), smem, st, emb, (long long)m, d, protos_normed, num_known, reps, distance_type,
-                       (const long long*)gt_classes, ious, iou_thr, alpha, beta, partial);
+    if (d <= 256)
+        hipLaunchKernelGGL(pln_loss_kernel<4>, dim3(RED_BLOCKS), dim3(256), smem, st, emb, (long long)m, d, protos_normed, num_known, reps, distance_type,
+                           (const long long*)gt_classes, ious, iou_thr, alpha, beta, partial);
+    else
+        hipLaunchKernelGGL(pln_loss_kernel<OSR_PLN_REG>, dim3(RED_BLOCKS), dim3(256), smem, st, emb, (long long)m, d, protos_normed, num_known, reps, distance_type,
+                           (const long long*)gt_classes, ious, iou_thr, alpha, beta, partial);
     OSR_CHECK_LAUNCH("osr_pln_loss_fwd");
     hipLaunchKernelGGL(pln_finish, dim3(1), dim3(64), 0, st, (const float*)partial, RED_BLOCKS, loss_weight, out1);
     OSR_CHECK_LAUNCH("osr_pln_loss_fwd(final)");
@@ -724,11 +779,9 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
     tr_block_reduce_store<2>(v, partial);
 }
 
-__global__ void ce_finish(const float* __restrict__ partial, int nblocks, float weight, float* __restrict__ out) {
-    if (threadIdx.x != 0) return;
-    float s = 0.f, c = 0.f;
-    for (int b = 0; b < nblocks; ++b) { s += partial[b * 2]; c += partial[b * 2 + 1]; }
-    out[0] = c > 0.f ? weight * (s / c) : 0.f;
+__global__ __launch_bounds__(64) void ce_finish(const float* __restrict__ partial, int nblocks, float weight, float* __restrict__ out) {
+    const float s = tr_wave_column_sum(partial, nblocks, 2, 0), c = tr_wave_column_sum(partial, nblocks, 2, 1);
+    if (threadIdx.x == 0) out[0] = c > 0.f ? weight * (s / c) : 0.f;
 }
 
 extern "C" osr_status osr_softmax_ce_loss_fwd(const float* logits, int64_t m, int32_t num_known, const int64_t* gt_classes, int32_t num_classes,
