@@ -384,7 +384,17 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const TI* __restrict__ d
     const long long m0 = (long long)blockIdx.x * rows_per_block, m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (co < cout) {  // cout is a multiple of 8
-        for (long long m = m0 + rl; m < m1; m += 8) {
+        long long m = m0 + rl;
+        if constexpr (sizeof(TI) == 2) {  // four 16-byte loads in flight per thread (one at a time left the pass at 3.6 TB/s); same order of additions
+            typedef TI v8 __attribute__((ext_vector_type(8)));
+            for (; m + 24 < m1; m += 32) {
+                const v8 v0 = *reinterpret_cast<const v8*>(dy + m * cout + co), v1 = *reinterpret_cast<const v8*>(dy + (m + 8) * cout + co);
+                const v8 v2 = *reinterpret_cast<const v8*>(dy + (m + 16) * cout + co), v3 = *reinterpret_cast<const v8*>(dy + (m + 24) * cout + co);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] = (((s[e] + (float)v0[e]) + (float)v1[e]) + (float)v2[e]) + (float)v3[e];
+            }
+        }
+        for (; m < m1; m += 8) {
             if constexpr (sizeof(TI) == 2) {
                 typedef TI v8 __attribute__((ext_vector_type(8)));
                 const v8 v = *reinterpret_cast<const v8*>(dy + m * cout + co);

@@ -242,6 +242,39 @@ def test_roi_align_backward_dense_extreme_footprints_and_ragged_tiles(ops):
     assert rel(got.permute(0, 3, 1, 2), feat.grad) < 1e-4
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_pool_bwd_two_byte_vector_path(ops, dt):
+    """osr_pool_bwd on f16 / bf16 with c % 8 == 0 takes the 16-byte kernel: same sums in the same order as the scalar kernel (base, then
+    the fine pixels row by row, fp32, one rounding) -- odd fine sizes (the last coarse row / column has fewer than four sources), with
+    and without base, both modes."""
+    gg = g(92)
+    n, hf, wf, c = 2, 9, 7, 24
+    fine = torch.randn(n, hf, wf, c, generator=gg).to(dt)
+    base = torch.randn(n, 5, 4, c, generator=gg).to(dt)
+    for b in (base, None):
+        got = ops.pool_bwd(fine.to(DEV), (5, 4), None if b is None else b.to(DEV), 0).cpu()
+        ref = torch.zeros(n, 5, 4, c) if b is None else b.float().clone()
+        for dy in range(2):
+            for dx in range(2):
+                part = fine.float()[:, dy::2, dx::2]
+                ref[:, :part.shape[1], :part.shape[2]] += part
+        assert got.dtype == dt and torch.equal(got, ref.to(dt))
+    src = torch.randn(n, 5, 4, c, generator=gg).to(dt)
+    got = ops.pool_bwd(src.to(DEV), (hf, wf), fine.to(DEV), 1).cpu()
+    ref = fine.float().clone()
+    ref[:, ::2, ::2] += src.float()
+    assert torch.equal(got, ref.to(dt))
+    # a channel count the vector kernel does not take: the scalar kernel, same answer
+    f2, b2 = fine[..., :20].contiguous(), base[..., :20].contiguous()
+    got = ops.pool_bwd(f2.to(DEV), (5, 4), b2.to(DEV), 0).cpu()
+    ref = b2.float().clone()
+    for dy in range(2):
+        for dx in range(2):
+            part = f2.float()[:, dy::2, dx::2]
+            ref[:, :part.shape[1], :part.shape[2]] += part
+    assert torch.equal(got, ref.to(dt))
+
+
 def test_elementwise_and_sgd(ops):
     gg = g(91)
     a = torch.randn(2, 9, 7, 16, generator=gg)
