@@ -336,8 +336,10 @@ class OpensetRCNNTrainer:
         g = self.grad
         dyp = dy if dy_pad is None else torch.nn.functional.pad(dy, (0, dy_pad - dy.shape[1]))
         dx = ops.gemm_f32(dyp, wt, None)                                                    # (m, k_in)
-        ops.gemm_f32_tn(dy, x, out=g[name + ".w"])                                          # dW = dy^T x, (n_out, k_in)
-        ops.bias_grad(dy, g[name + ".b"])
+        # dW / db only consume dy and the saved input: off the chain of small launches between the forward and the heavy backward, which
+        # sits alone on the critical stream (the weight-gradient stream has nothing else to do at that point)
+        self._wg(lambda: (ops.gemm_f32_tn(dy, x, out=g[name + ".w"]),                      # dW = dy^T x, (n_out, k_in)
+                          ops.bias_grad(dy, g[name + ".b"])), dy, x)
         self._done(name + ".w", name + ".b")
         return dx
 
