@@ -691,6 +691,34 @@ osr_status osr_sgd_step(float* param, const float* grad, float* momentum_buf, in
 osr_status osr_pack_dgrad_weight(const void* weight, void* out, int32_t cout, int32_t kh, int32_t kw, int32_t cin,
                                  int32_t dtype, void* stream);
 
+/* The update of a whole training step as two launches (csrc/osr_multi_tensor.hip): osr_sgd_step over every entry of a DEVICE-resident
+ * table, and osr_pack_dgrad_weight over every entry of another. `chunks`: (tensor index, chunk index) int32 pairs, one per workgroup,
+ * on the device: for the SGD launch chunk c of tensor t is the elements [c * chunk_elems, min((c + 1) * chunk_elems, n)); for the packing
+ * launch it is the linear index of a 32 x 32 tile, (tap * ceil(cout / 32) + co_tile) * ceil(cin / 32) + ci_tile. The caller builds both
+ * once (the buffers' addresses are stable across steps). Same arithmetic per element as the single-tensor entry points: bit-identical. */
+typedef struct osr_sgd_tensor {
+    float* param;
+    const float* grad;
+    float* momentum;
+    const float* row_scale; /* nullable */
+    void* lowp;             /* nullable: low-precision working copy, lowp_dtype */
+    int64_t n;
+    int64_t row_elems;      /* >= 1 */
+    int32_t lowp_dtype;
+    int32_t reserved;
+} osr_sgd_tensor;
+typedef struct osr_pack_tensor {
+    const void* src;        /* (cout, kh, kw, cin) */
+    void* dst;              /* (cin, kh, kw, cout), spatially flipped */
+    int32_t cout, kh, kw, cin;
+    int32_t elem_bytes;     /* 2 or 4 */
+    int32_t reserved;
+} osr_pack_tensor;
+osr_status osr_sgd_step_multi(const osr_sgd_tensor* table, const int32_t* chunks, int32_t num_chunks, int32_t chunk_elems,
+                              float lr, float momentum, float weight_decay, float grad_scale, const int32_t* apply_flag,
+                              void* stream);
+osr_status osr_pack_dgrad_weight_multi(const osr_pack_tensor* table, const int32_t* chunks, int32_t num_chunks, void* stream);
+
 /* Overflow guard: *flag (device int32, preset to 1 by the caller) is cleared when any of the n floats of x is inf or NaN.
  * The reference trains in fp32 and has no such step (train.py:135-146); the fp16 gradients of this build do, and an
  * overflowed iteration must not reach the fp32 masters or a checkpoint. x 16-byte aligned. Asynchronous, no host sync. */

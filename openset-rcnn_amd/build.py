@@ -32,6 +32,7 @@ SOURCES = {
     "osr_det_tail.hip": ["-ffp-contract=off"],
     "osr_train_fwd.hip": ["-ffp-contract=off"],
     "osr_rpn_sparse.hip": ["-ffp-contract=off"],
+    "osr_multi_tensor.hip": [],  # (same contraction setting as osr_train_bwd.hip: the multi-tensor SGD must round like osr_sgd_step)
     "osr_conv_bwd.hip": [],
     "osr_train_bwd.hip": [],
 }

@@ -99,6 +99,17 @@ __device__ __forceinline__ int osr_block_excl_scan(int v, int* smem, int* total)
     return base + inc - v;
 }
 
+// One element of SGD with momentum and weight decay (torch.optim.SGD): shared by osr_sgd_step and osr_sgd_step_multi so that the two
+// round alike -- contraction into fused multiply-adds is switched off here, otherwise the compiler is free to fuse differently in the
+// two kernels and the multi-tensor update would not be bit-identical to the per-tensor one.
+__device__ __forceinline__ void osr_sgd_element(float& p, float& v, float g, float rs, float lr, float mu, float wd, float gs) {
+#pragma clang fp contract(off)
+    const float gi = g * gs * rs + wd * p;
+    const float vi = mu * v + gi;
+    p = p - lr * vi;
+    v = vi;
+}
+
 __device__ __forceinline__ float osr_wave_sum(float v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);

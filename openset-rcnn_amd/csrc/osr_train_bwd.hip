@@ -828,9 +828,8 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     if (gate && *gate == 0) return;  // this iteration's gradients held an inf / NaN (osr_check_finite): leave parameters and momentum alone
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float rs = row_scale ? row_scale[i / row_elems] : 1.0f;
-        const float gi = g[i] * grad_scale * rs + wd * p[i];
-        const float vi = mu * v[i] + gi;
-        const float pi = p[i] - lr * vi;
+        float pi = p[i], vi = v[i];
+        osr_sgd_element(pi, vi, g[i], rs, lr, mu, wd, grad_scale);
         v[i] = vi;
         p[i] = pi;
         if (lp) lp[i] = osr_from_float<T>(pi * rs);

@@ -60,6 +60,16 @@ class RpnLevels(C.Structure):
     ]
 
 
+class SgdTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("momentum", C.c_void_p), ("row_scale", C.c_void_p), ("lowp", C.c_void_p),
+                ("n", C.c_int64), ("row_elems", C.c_int64), ("lowp_dtype", C.c_int32), ("reserved", C.c_int32)]
+
+
+class PackTensor(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("cout", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("cin", C.c_int32),
+                ("elem_bytes", C.c_int32), ("reserved", C.c_int32)]
+
+
 class Pyramid(C.Structure):
     _fields_ = [
         ("num_levels", C.c_int32), ("c", C.c_int32),
@@ -157,6 +167,8 @@ PROTOTYPES = {
     "osr_sgd_step": (I32, [P, P, P, I64, F32, F32, F32, F32, P, I64, P, I32, P, P]),
     "osr_check_finite": (I32, [P, I64, P, P]),
     "osr_pack_dgrad_weight": (I32, [P, P, I32, I32, I32, I32, I32, P]),
+    "osr_sgd_step_multi": (I32, [P, P, I32, I32, F32, F32, F32, F32, P, P]),
+    "osr_pack_dgrad_weight_multi": (I32, [P, P, I32, P]),
 }
 
 _lib = None

@@ -1208,6 +1208,82 @@ def pack_dgrad_weight(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> to
     return out
 
 
+class MultiTensorPlan:
+    """Device-resident table + chunk list of a multi-tensor launch (osr_sgd_step_multi / osr_pack_dgrad_weight_multi). `keep` holds the
+    tensors the table points at: the plan is only valid while they live at the same addresses."""
+
+    def __init__(self, table: torch.Tensor, chunks: torch.Tensor, num_chunks: int, keep, chunk_elems: int = 0):
+        self.table, self.chunks, self.num_chunks, self.keep, self.chunk_elems = table, chunks, num_chunks, keep, chunk_elems
+
+
+def _upload_struct_array(arr, device) -> torch.Tensor:
+    raw = bytes(memoryview(arr).cast("B"))
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+
+SGD_CHUNK_ELEMS = 16384
+
+
+def sgd_multi_plan(entries, device) -> MultiTensorPlan:
+    """entries: [(param, grad, momentum_buf, row_scale | None, lowp | None)], fp32 param / grad / buf of equal size."""
+    tab = (_lib.SgdTensor * len(entries))()
+    chunks: List[int] = []
+    keep = []
+    for ti, (pm, gr, buf, rs, lp) in enumerate(entries):
+        _need(pm, torch.float32, "param"); _need(gr, torch.float32, "grad"); _need(buf, torch.float32, "buf")
+        if gr.numel() != pm.numel() or buf.numel() != pm.numel() or (lp is not None and lp.numel() != pm.numel()):
+            raise OsrError("sgd_multi_plan: size mismatch")
+        if rs is not None:
+            _need(rs, torch.float32, "row_scale")
+        if lp is not None:
+            _need(lp, name="lowp")
+        t = tab[ti]
+        t.param, t.grad, t.momentum = pm.data_ptr(), gr.data_ptr(), buf.data_ptr()
+        t.row_scale = rs.data_ptr() if rs is not None else None
+        t.lowp = lp.data_ptr() if lp is not None else None
+        t.n = pm.numel()
+        t.row_elems = pm.numel() // pm.shape[0] if rs is not None else 1
+        t.lowp_dtype = _DT[lp.dtype] if lp is not None else 0
+        for c in range((pm.numel() + SGD_CHUNK_ELEMS - 1) // SGD_CHUNK_ELEMS):
+            chunks += [ti, c]
+        keep += [pm, gr, buf, rs, lp]
+    ch = torch.tensor(chunks, dtype=torch.int32).to(device)
+    return MultiTensorPlan(_upload_struct_array(tab, device), ch, len(chunks) // 2, keep, SGD_CHUNK_ELEMS)
+
+
+def sgd_step_multi_(plan: MultiTensorPlan, lr: float, momentum: float, weight_decay: float, grad_scale: float = 1.0,
+                    apply_flag: Optional[torch.Tensor] = None) -> None:
+    """osr_sgd_step on every tensor of the plan, one launch."""
+    lib = _lib.load()
+    check(lib.osr_sgd_step_multi(_p(plan.table), _p(plan.chunks), plan.num_chunks, plan.chunk_elems, lr, momentum, weight_decay, grad_scale,
+                                 _p(apply_flag), _stream()), "osr_sgd_step_multi")
+
+
+def pack_dgrad_multi_plan(pairs, device) -> MultiTensorPlan:
+    """pairs: [(w, out)] as pack_dgrad_weight takes them (w (cout,kh,kw,cin) or a 2-d (n,k) matrix; out of the same size and dtype)."""
+    tab = (_lib.PackTensor * len(pairs))()
+    chunks: List[int] = []
+    keep = []
+    for ti, (w, out) in enumerate(pairs):
+        _need(w, name="w"); _need(out, w.dtype, "out")
+        if out.numel() != w.numel() or w.element_size() not in (2, 4):
+            raise OsrError("pack_dgrad_multi_plan: out has the wrong size / unsupported element size")
+        cout, kh, kw, cin = (w.shape[0], 1, 1, w.shape[1]) if w.dim() == 2 else tuple(w.shape)
+        t = tab[ti]
+        t.src, t.dst, t.cout, t.kh, t.kw, t.cin, t.elem_bytes = w.data_ptr(), out.data_ptr(), cout, kh, kw, cin, w.element_size()
+        for c in range(kh * kw * ((cout + 31) // 32) * ((cin + 31) // 32)):
+            chunks += [ti, c]
+        keep += [w, out]
+    ch = torch.tensor(chunks, dtype=torch.int32).to(device)
+    return MultiTensorPlan(_upload_struct_array(tab, device), ch, len(chunks) // 2, keep)
+
+
+def pack_dgrad_weight_multi_(plan: MultiTensorPlan) -> None:
+    """osr_pack_dgrad_weight on every pair of the plan, one launch."""
+    lib = _lib.load()
+    check(lib.osr_pack_dgrad_weight_multi(_p(plan.table), _p(plan.chunks), plan.num_chunks, _stream()), "osr_pack_dgrad_weight_multi")
+
+
 _ZERO_BIAS = {}
 
 

@@ -180,6 +180,9 @@ class OpensetRCNNTrainer:
         self.overlap_targets = True
         self._wside: Optional[torch.cuda.Stream] = None  # stream of the weight / bias gradient launches (see _wg)
         self.side_wgrad = True
+        self.multi_tensor_update = True  # the update as two launches (ops.sgd_step_multi_, ops.pack_dgrad_weight_multi_); False: one launch per tensor
+        self._sgd_plan = None
+        self._pack_plan = None
         # blocks whose weight gradients ride on the main stream (measured with res3.0 / res3.0-1 / all of res3: 25.4-25.5 against 25.5-25.7 ms,
         # inside the run-to-run spread: the backward is bound by the sum of its kernels, not by which stream ends last) -- left empty
         self.wgrad_on_main: set = set()
@@ -241,6 +244,13 @@ class OpensetRCNNTrainer:
             wd["fc1"] = ops.pack_dgrad_weight(e.fc1_w).view(e.fc1_w.shape[1], 1, 1, e.fc1_w.shape[0])
             wd["fc2"] = ops.pack_dgrad_weight(e.fc2_w).view(e.fc2_w.shape[1], 1, 1, e.fc2_w.shape[0])
             self.wd = wd
+        elif self.multi_tensor_update:
+            pairs = [(e.w[n + ".w"], wd[n]) for n in self.conv_names]
+            pairs += [(e.fc1_w, wd["fc1"].view(e.fc1_w.shape[1], e.fc1_w.shape[0])), (e.fc2_w, wd["fc2"].view(e.fc2_w.shape[1], e.fc2_w.shape[0]))]
+            sig = tuple(t.data_ptr() for pr in pairs for t in pr)
+            if self._pack_plan is None or self._pack_plan[0] != sig:
+                self._pack_plan = (sig, ops.pack_dgrad_multi_plan(pairs, self.device))
+            ops.pack_dgrad_weight_multi_(self._pack_plan[1])
         else:
             jobs = [lambda n=n: ops.pack_dgrad_weight(e.w[n + ".w"], wd[n]) for n in self.conv_names]
             jobs.append(lambda: ops.pack_dgrad_weight(e.fc1_w, wd["fc1"].view(e.fc1_w.shape[1], e.fc1_w.shape[0])))
@@ -433,16 +443,16 @@ class OpensetRCNNTrainer:
                 off_ += rows_
                 ops.conv2d_wgrad(p[k_], dtl_, 3, 3, 1, 1, dw=g[rn + ".w"], accumulate=li_ > 0)
                 ops.bias_grad(dtl_, g[rn + ".b"], accumulate=li_ > 0)
-            return dta, ready
+            return (dta,), ready
         if self.side_wgrad:
             cur0 = torch.cuda.current_stream(self.device)
             if self._wside is None:
                 self._wside = torch.cuda.Stream(device=self.device)
             self._wside.wait_stream(cur0)
             with torch.cuda.stream(self._wside):
-                dt_all, rpn_ready = rpn_chain()
+                rpn_grad, rpn_ready = rpn_chain()
         else:
-            dt_all, rpn_ready = rpn_chain()
+            rpn_grad, rpn_ready = rpn_chain()
         self._done("rpn_tail.w", "rpn_tail.b", rn + ".w", rn + ".b")
         # --- RoI-head losses -> predictor / PLN / classifier (fp32 heads) ---
         lt = loss_types_of(c)
@@ -483,29 +493,24 @@ class OpensetRCNNTrainer:
         if self.side_wgrad:
             torch.cuda.current_stream(self.device).wait_event(rpn_ready)
             if not torch.cuda.is_current_stream_capturing():
-                for t_ in (dt_all if isinstance(dt_all, tuple) else (dt_all,)):
+                for t_ in rpn_grad:
                     t_.record_stream(torch.cuda.current_stream(self.device))
         dP = {}
+        lvl_shapes = list(zip(("p2", "p3", "p4", "p5", "p6"), s["rpn_shapes"]))
+        roi_part = [(d_feat[li] if d_feat[li].dtype == dt else ops.add_cast(d_feat[li], None, dt)) for li in range(4)] + [None]
         if self.sparse_rpn_bwd:
-            # col2im of the listed anchors' per-tap gradients straight into the RoI heads' feature gradient (p6: into zeros)
-            rmap, y_rows = dt_all
-            glist = []
-            for li, (k, (h, w)) in enumerate(zip(("p2", "p3", "p4", "p5", "p6"), s["rpn_shapes"])):
-                if li < 4:
-                    glist.append(d_feat[li] if d_feat[li].dtype == dt else ops.add_cast(d_feat[li], None, dt))
-                else:
-                    glist.append(torch.zeros((n, h, w, 256), dtype=dt, device=self.device))
-                dP[k] = glist[-1]
+            # col2im of the listed anchors' per-tap gradients straight into the RoI heads' feature gradient (p6 has none: into zeros)
+            rmap, y_rows = rpn_grad
+            h6, w6 = s["rpn_shapes"][4]
+            glist = roi_part[:4] + [torch.zeros((n, h6, w6, 256), dtype=dt, device=self.device)]
             ops.rpn_scatter_cols_add_(sel["levels"], n, rmap, y_rows, glist)
-        off = 0
-        for li, (k, (h, w)) in enumerate(zip(("p2", "p3", "p4", "p5", "p6"), s["rpn_shapes"])):
-            if self.sparse_rpn_bwd:
-                break
-            rows = n * h * w
-            dtl = dt_all[off:off + rows].view(n, h, w, 256)
-            off += rows
-            roi_part = (d_feat[li] if d_feat[li].dtype == dt else ops.add_cast(d_feat[li], None, dt)) if li < 4 else None
-            dP[k] = ops.conv2d_dgrad(dtl, self.wd[rn], (h, w), 1, 1, add=roi_part)
+            dP = {k: gl for (k, _), gl in zip(lvl_shapes, glist)}
+        else:
+            (dt_all,), off = rpn_grad, 0
+            for li, (k, (h, w)) in enumerate(lvl_shapes):
+                rows = n * h * w
+                dP[k] = ops.conv2d_dgrad(dt_all[off:off + rows].view(n, h, w, 256), self.wd[rn], (h, w), 1, 1, add=roi_part[li])
+                off += rows
         h5, w5 = p["p5"].shape[1], p["p5"].shape[2]
         dP["p5"] = ops.pool_bwd(dP["p6"], (h5, w5), dP["p5"], 1)  # p6 = p5[::2, ::2]
         # --- FPN: output convs, top-down adds, laterals (finest level first: its gradient flows up to the coarser sums) ---
@@ -580,10 +585,19 @@ class OpensetRCNNTrainer:
         gs = 1.0 / (getattr(self, "_scale_used", self.loss_scale) * world)
         self._ok.fill_(1)
         ops.check_finite_(self.grad_flat, self._ok)
-        # ~75 in-place launches of a few microseconds each (one per parameter tensor), then ~70 repacking launches: dealt over the
-        # three streams of the trainer they run three abreast instead of one behind the other
-        self._fan([lambda k=k, pm=pm: ops.sgd_step_(pm, self.grad[k], self.mom[k], self.lr, self.momentum, self.weight_decay, gs, self.row_scale.get(k),
-                                                   self.lowp.get(k), self._ok) for k, pm in self.master.items()])
+        if self.multi_tensor_update:
+            # every parameter tensor in ONE launch (osr_sgd_step_multi over a device-resident table), then every backward-data weight in
+            # one more (_refresh_derived): ~145 launches of a few microseconds of work each became two; same bits per element
+            sig = tuple(t.data_ptr() for k in self.master for t in (self.master[k], self.grad[k], self.mom[k]) + ((self.lowp[k],) if self.lowp.get(k) is not None else ()))
+            if self._sgd_plan is None or self._sgd_plan[0] != sig:
+                self._sgd_plan = (sig, ops.sgd_multi_plan([(pm, self.grad[k], self.mom[k], self.row_scale.get(k), self.lowp.get(k))
+                                                           for k, pm in self.master.items()], self.device))
+            ops.sgd_step_multi_(self._sgd_plan[1], self.lr, self.momentum, self.weight_decay, gs, self._ok)
+        else:
+            # ~75 in-place launches of a few microseconds each (one per parameter tensor), then ~70 repacking launches: dealt over the
+            # three streams of the trainer they run three abreast instead of one behind the other
+            self._fan([lambda k=k, pm=pm: ops.sgd_step_(pm, self.grad[k], self.mom[k], self.lr, self.momentum, self.weight_decay, gs, self.row_scale.get(k),
+                                                       self.lowp.get(k), self._ok) for k, pm in self.master.items()])
         self._refresh_derived()
         self.scaler.record(self._ok, getattr(self, "_proposal_status", None))
         self._proposal_status = None

@@ -249,3 +249,40 @@ def test_weight_gradients_on_the_second_stream_are_the_same_gradients(setup):
             assert torch.equal(a, b), k
         else:
             assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-6, k
+
+
+def test_multi_tensor_update_is_bit_identical_to_one_launch_per_tensor(setup):
+    """The update as two launches (osr_sgd_step_multi, osr_pack_dgrad_weight_multi over device-resident tables) against ~145 launches
+    (osr_sgd_step / osr_pack_dgrad_weight per tensor), from the SAME gradients, masters and momentum: two updates in a row -- masters,
+    momentum buffers, the low-precision working copies and the backward-data weights agree bit for bit; an overflowed iteration (flag
+    0) changes nothing in either form."""
+    from openset_rcnn_amd.host.train import OpensetRCNNTrainer
+    d = setup["dev"]
+    args = (d["images"], d["hw"], setup["h"], setup["w"], d["gt"], d["gcls"], d["gcnt"], d["keys"])
+    tr = OpensetRCNNTrainer(setup["params"], dtype=torch.float16, device=DEV, lr=0.01, loss_scale=512.0)
+    tr.step(*args, update=False)  # gradients of a real step
+    torch.cuda.synchronize()
+    snap = dict(master={k: v.clone() for k, v in tr.master.items()}, mom={k: v.clone() for k, v in tr.mom.items()}, grad=tr.grad_flat.clone())
+    state = {}
+    for multi in (True, False):
+        for k in snap["master"]:
+            tr.master[k].copy_(snap["master"][k])
+            tr.mom[k].copy_(snap["mom"][k])
+        tr.multi_tensor_update = multi
+        for _ in range(2):
+            tr.grad_flat.copy_(snap["grad"])
+            tr._update(1)
+        # a poisoned gradient: the overflow flag gates the whole update
+        before = {k: v.clone() for k, v in tr.master.items()}
+        tr.grad_flat.fill_(float("inf"))
+        tr._update(1)
+        torch.cuda.synchronize()
+        assert all(torch.equal(before[k], tr.master[k]) for k in before), "an overflowed update must not touch the masters"
+        assert tr.poll_overflow(wait=True)
+        state[multi] = dict(master={k: v.clone() for k, v in tr.master.items()}, mom={k: v.clone() for k, v in tr.mom.items()},
+                            lowp={k: v.clone() for k, v in tr.lowp.items() if v is not None}, wd={k: v.clone() for k, v in tr.wd.items()})
+    moved = sum(int(not torch.equal(state[True]["master"][k], snap["master"][k])) for k in snap["master"])
+    assert moved == len(snap["master"]), "every parameter tensor must have been updated"
+    for group in ("master", "mom", "lowp", "wd"):
+        for k, a in state[True][group].items():
+            assert torch.equal(a, state[False][group][k]), (group, k)
