@@ -907,12 +907,14 @@ def _conv_params(n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, dt_in, dt_ou
 
 def conv2d_dgrad(dy: torch.Tensor, w_dgrad: torch.Tensor, x_hw: Tuple[int, int], stride: int = 1, pad: int = 0,
                  mask: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None,
-                 post_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 post_mask: Optional[torch.Tensor] = None, strided_only: bool = False) -> torch.Tensor:
     """Gradient w.r.t. the input of a convolution: dy (n,ho,wo,cout), w_dgrad = pack_dgrad_weight(w) (cin,kh,kw,cout).
     mask: forward activation at dx's positions (n,hi,wi,cin) -> dx is zeroed where mask <= 0 (the ReLU below);
     add: a second gradient of dx's shape summed in (residual / shortcut branch). At most one of the two (they share the
     epilogue's auxiliary operand); post_mask: a forward activation of dx's shape applied as a ReLU mask AFTER the sum (the
-    join of a residual block: osr_conv2d_fwd_masked); stride 2 is supported for 1x1 layers (every second pixel of a zeroed dx)."""
+    join of a residual block: osr_conv2d_fwd_masked); stride 2 is supported for 1x1 layers (every second pixel of a zeroed dx).
+    strided_only (stride > 1): the caller reads dx only at the pixels the stride visits (as the `add` of a second strided launch
+    does), so the other pixels are left unwritten instead of zero-filled."""
     lib = _lib.load()
     _need(dy, name="dy"); _need(w_dgrad, dy.dtype, "w_dgrad")
     n, ho, wo, cout = dy.shape
@@ -935,7 +937,7 @@ def conv2d_dgrad(dy: torch.Tensor, w_dgrad: torch.Tensor, x_hw: Tuple[int, int],
         raise OsrError("x_hw inconsistent with dy and the stride")
     if FLOP_COUNT is not None:
         FLOP_COUNT["conv"] += 2.0 * n * ho * wo * cout * cin
-    dx = torch.zeros((n, hi, wi, cin), dtype=out_dtype, device=dy.device)
+    dx = (torch.empty if strided_only else torch.zeros)((n, hi, wi, cin), dtype=out_dtype, device=dy.device)
     p = _conv_params(n, ho, wo, cout, ho, wo, cin, 1, 1, 1, 0, dy.dtype, out_dtype)
     p.out_stride_n, p.out_stride_h, p.out_stride_w = hi * wi * cin, stride * wi * cin, stride * cin
     p.res_mode = mode

@@ -564,7 +564,8 @@ class OpensetRCNNTrainer:
             below_last = bi > 0 and s["blocks"][bi - 1]["pre"].endswith(f".{R50_BLOCKS[s['blocks'][bi - 1]['stage'] - 2] - 1}")
             pm = None if below_last else x
             if blk["first"]:
-                dx = ops.conv2d_dgrad(d_o1, self.wd[pre + ".conv1"], (hx, wx), stride, 0)
+                # (conv1's share is read back by the shortcut's launch at the strided pixels only: no zero fill of the others)
+                dx = ops.conv2d_dgrad(d_o1, self.wd[pre + ".conv1"], (hx, wx), stride, 0, strided_only=stride > 1)
                 G = ops.conv2d_dgrad(G, self.wd[pre + ".shortcut"], (hx, wx), stride, 0, add=dx, post_mask=pm)
             else:
                 G = ops.conv2d_dgrad(d_o1, self.wd[pre + ".conv1"], (hx, wx), 1, 0, add=G, post_mask=pm)
