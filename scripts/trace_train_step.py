@@ -7,8 +7,8 @@ from collections import defaultdict
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# an iteration ends with its sgd_kernel launches: take the window between the last two bursts of sgd kernels
-sgd = [int(r["End_Timestamp"]) for r in rows if "sgd_kernel" in r["Kernel_Name"]]
+# an iteration ends with its SGD launch(es) (one sgd_multi_kernel, or a burst of sgd_kernel): take the window between the last two
+sgd = [int(r["End_Timestamp"]) for r in rows if "sgd_kernel" in r["Kernel_Name"] or "sgd_multi_kernel" in r["Kernel_Name"]]
 bursts = []
 for t in sgd:
     if not bursts or t - bursts[-1][1] > 2e6:
