@@ -73,3 +73,23 @@ def test_wgrad_and_dgrad_vs_autograd(ops, osr, n, cin, cout, h, w, k, stride, pa
         keep[:, ::2, ::2] = 1
         ref = ref * keep
     assert rel(dxa, ref) < 2e-3
+
+
+def test_wgrad_single_split_writes_dw_directly(ops):
+    """A layer with enough weight tiles to fill the GPU on its own (FC1: 4 x 49 tiles of 256 x 256) runs as ONE split, and without an
+    accumulate the kernel then writes dw itself -- no workspace copy, no reduction launch. Checked against the fp32 product on the CPU,
+    into a view of a larger buffer (neighbouring elements untouched), and against the accumulating form (which keeps the reduction)."""
+    gg = g(77)
+    m, k, nout = 300, 12544, 1024
+    x = (torch.randn(m, k, generator=gg) * 0.5).half()
+    dy = (torch.randn(m, nout, generator=gg) * 0.1).half()
+    ref = dy.float().t() @ x.float()
+    flat = torch.full((nout * k + 64,), 7.0, dtype=torch.float32, device=DEV)
+    dw = flat[32:32 + nout * k].view(nout, 1, 1, k)
+    ops.conv2d_wgrad(x.to(DEV).view(1, m, 1, k), dy.to(DEV).view(1, m, 1, nout), 1, 1, dw=dw)
+    assert rel(dw.view(nout, k), ref) < 2e-3
+    assert float(flat[:32].min()) == 7.0 and float(flat[32 + nout * k:].max()) == 7.0
+    first = dw.clone()
+    ops.conv2d_wgrad(x.to(DEV).view(1, m, 1, k), dy.to(DEV).view(1, m, 1, nout), 1, 1, dw=dw, accumulate=True)
+    assert rel(dw, 2 * first) < 1e-6
+    assert torch.equal(ops.linear_wgrad(x.to(DEV), dy.to(DEV)), first.view(nout, k))
