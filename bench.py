@@ -209,7 +209,8 @@ def synthetic_gt(n: int, h: int, w: int, per_image: int = 8, seed: int = 0):
     return boxes, classes, torch.full((n,), per_image, dtype=torch.int32)
 
 
-def train_step_leg(params, tdt, device, images, image_hw, steps: int, warmup: int, dist=None, rank: int = 0, world: int = 1, dense_rpn_bwd: bool = False):
+def train_step_leg(params, tdt, device, images, image_hw, steps: int, warmup: int, dist=None, rank: int = 0, world: int = 1, dense_rpn_bwd: bool = False,
+                   no_chain: bool = False):
     """BASELINE.json config 3: forward + explicit backward + SGD, batch 16 per GPU at 800x1333. With several ranks (configs 4 / 5's
     pattern) every rank trains on its own images and the flat gradient buffer is all-reduced over RCCL in >= 25 MB buckets issued
     from inside the backward (parallel.GradBuckets); the time is the maximum over the ranks, bracketed by barriers."""
@@ -218,6 +219,7 @@ def train_step_leg(params, tdt, device, images, image_hw, steps: int, warmup: in
     n = images.shape[0]
     tr = OpensetRCNNTrainer(params, dtype=tdt, device=device, lr=1e-4, loss_scale=1024.0 if tdt == torch.float16 else 1.0)
     tr.sparse_rpn_bwd = not dense_rpn_bwd
+    tr.chain_forward = not no_chain
     gt, gcls, gcnt = synthetic_gt(n, 800, 1333)
     shapes = [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
     r = sum(a * b for a, b in shapes)
@@ -541,7 +543,7 @@ def main(argv=None) -> int:
     params = with_known_unknown_mix(params, emb)
     del cal, keep
     if args.train_only:  # child of the single-GPU run (see train_step_child): the train-step leg in a process of its own
-        print(json.dumps(train_step_leg(params, tdt, dev, images, image_hw, args.train_steps, 2, dense_rpn_bwd=args.dense_rpn_bwd)), flush=True)
+        print(json.dumps(train_step_leg(params, tdt, dev, images, image_hw, args.train_steps, 2, dense_rpn_bwd=args.dense_rpn_bwd, no_chain=args.no_chain)), flush=True)
         return 0
     eng = OpensetRCNNEngine(params, dtype=tdt, device=dev)
     if args.no_chain:

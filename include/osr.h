@@ -122,6 +122,12 @@ osr_status osr_conv2d_fwd_masked(const osr_conv_params* p, const void* in, const
  * Fused shapes: cout == 128, cout3 == 512 (the res3 blocks); anything else returns OSR_ERR_UNSUPPORTED, nothing launched. */
 osr_status osr_conv2d_chain_fwd(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* w3,
                                 const float* bias3, int32_t cout3, const void* residual, void* out, void* stream);
+/* The same, also writing the first convolution's activated output (what the separate launch would have stored), dense
+ * (n*ho*wo, cout) rows in the storage dtype, to mid_out (nullable): the training step keeps it for the block's backward (ReLU mask of
+ * conv3's data gradient, input of conv3's weight gradient) and still saves the second launch and its re-read. */
+osr_status osr_conv2d_chain_fwd_ex(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* w3,
+                                   const float* bias3, int32_t cout3, const void* residual, void* out, void* mid_out,
+                                   void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * One whole ResNet bottleneck block in ONE launch: y = relu(conv3(relu(conv2(relu(conv1(x))))) + shortcut(x)),

@@ -99,6 +99,7 @@ struct Conv64Args {
     const float* bias3;
     int cout3;
     unsigned w3_bytes, out_bytes;  // buffer sizes of w3 and of out / res (dense rows of cout3 elements)
+    void* mid_out;         // nullable: the parked relu(conv + bias) tile also goes to HBM, dense (rows, 128): the training step keeps it for the backward
 #ifdef C64_STAMPS
     unsigned long long* dbg;
 #endif
@@ -506,6 +507,10 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
                         t[4 + q] = (TI)(p.relu ? fmaxf(v1, 0.f) : v1);
                     }
                     *reinterpret_cast<frag_t*>(lds + CH_A + wc * CH_SL + r * 128 + ((chunk ^ ((r >> 1) & 7)) << 4)) = t;
+                    if (a.mid_out) {  // (uniform) the same eight channels of pixel m0 + r, as the separate launch would have written them
+                        const long long m = m0 + r;
+                        if (m < a.M) *reinterpret_cast<frag_t*>(reinterpret_cast<TI*>(a.mid_out) + m * 128 + wc * 64 + chunk * 8) = t;
+                    }
                 }
         const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w3), 0, a.w3_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res), 0, a.out_bytes, 0x00020000);
@@ -1136,9 +1141,17 @@ static osr_status conv_chain_launch(Conv64Args& a, hipStream_t st) {
     return OSR_OK;
 }
 
+extern "C" osr_status osr_conv2d_chain_fwd_ex(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* w3,
+                                              const float* bias3, int32_t cout3, const void* residual, void* out, void* mid_out, void* stream);
 extern "C" osr_status osr_conv2d_chain_fwd(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* w3,
                                            const float* bias3, int32_t cout3, const void* residual, void* out, void* stream) {
+    return osr_conv2d_chain_fwd_ex(p, in, weight, bias, w3, bias3, cout3, residual, out, nullptr, stream);
+}
+
+extern "C" osr_status osr_conv2d_chain_fwd_ex(const osr_conv_params* p, const void* in, const void* weight, const float* bias, const void* w3,
+                                              const float* bias3, int32_t cout3, const void* residual, void* out, void* mid_out, void* stream) {
     OSR_REQUIRE(p && in && weight && bias && w3 && bias3 && residual && out, OSR_ERR_INVALID_ARG, "osr_conv2d_chain_fwd: null pointer");
+    OSR_REQUIRE((((uintptr_t)mid_out) & 15) == 0, OSR_ERR_INVALID_ARG, "osr_conv2d_chain_fwd: mid_out must be 16-byte aligned");
     OSR_REQUIRE(p->in_dtype == OSR_F16 || p->in_dtype == OSR_BF16, OSR_ERR_UNSUPPORTED, "osr_conv2d_chain_fwd: in_dtype must be f16/bf16");
     OSR_REQUIRE(p->out_dtype == p->in_dtype, OSR_ERR_UNSUPPORTED, "osr_conv2d_chain_fwd: out_dtype must equal in_dtype");
     OSR_REQUIRE(p->cout == 128 && cout3 == 512 && p->cin % 64 == 0 && p->pad_mode == 0, OSR_ERR_UNSUPPORTED,
@@ -1168,6 +1181,7 @@ extern "C" osr_status osr_conv2d_chain_fwd(const osr_conv_params* p, const void*
     a.tail_w = a.tail_b = nullptr; a.tail_deltas = a.tail_ctr = nullptr; a.tail_lds_off = 0;
     a.w3 = w3; a.bias3 = bias3; a.cout3 = cout3;
     a.w3_bytes = (unsigned)((long long)cout3 * p->cout * 2); a.out_bytes = (unsigned)out_bytes;
+    a.mid_out = mid_out;
 #ifdef C64_STAMPS
     a.dbg = g_c64_stamps;
 #endif

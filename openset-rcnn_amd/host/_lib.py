@@ -92,6 +92,7 @@ PROTOTYPES = {
     "osr_conv2d_fwd_describe": (I32, [C.POINTER(ConvParams), I32, P, I32]),
     "osr_conv2d_fwd_masked": (I32, [C.POINTER(ConvParams), P, P, P, P, P, P, P]),
     "osr_conv2d_chain_fwd": (I32, [C.POINTER(ConvParams), P, P, P, P, P, I32, P, P, P]),
+    "osr_conv2d_chain_fwd_ex": (I32, [C.POINTER(ConvParams), P, P, P, P, P, I32, P, P, P, P]),
     "osr_bottleneck_fwd": (I32, [C.POINTER(BottleneckParams), P, P, P, P, P, P, P, P, P, P, P]),
     "osr_resize_tmp_bytes": (I64, [I32, I32]),
     "osr_resize_bilinear_u8": (I32, [P, I32, I32, I64, P, P, I32, P, P, I32, I32, I32, I32, I32, P, I64, P, P]),

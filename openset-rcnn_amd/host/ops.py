@@ -234,10 +234,11 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, relu: bool
 
 
 def conv2d_chain(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, w3: torch.Tensor, b3: torch.Tensor, residual: torch.Tensor,
-                 stride: int = 1, pad: int = 0) -> Optional[torch.Tensor]:
+                 stride: int = 1, pad: int = 0, keep_mid: bool = False):
     """A bottleneck's conv2 -> conv3 in one launch (osr_conv2d_chain_fwd): relu(conv1x1(relu(conv(x, weight) + bias), w3) + b3 +
     residual). x (n,h,w,cin) f16/bf16, weight (cmid,kh,kw,cin), w3 (cout3,1,1,cmid), residual (n,ho,wo,cout3). Returns None when the
-    shape is outside the fused kernel's envelope (the caller then runs conv2d twice)."""
+    shape is outside the fused kernel's envelope (the caller then runs conv2d twice). keep_mid: also return the first convolution's
+    activated output (n,ho,wo,cmid) -- (out, mid) -- as the training step needs it."""
     lib = _lib.load()
     _need(x, name="x")
     if x.dtype not in (torch.float16, torch.bfloat16):
@@ -261,13 +262,14 @@ def conv2d_chain(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, w3: 
     p.relu, p.res_mode, p.pad_mode = 1, 0, 0
     p.in_dtype = p.out_dtype = _DT[x.dtype]
     out = torch.empty((n, ho, wo, cout3), dtype=x.dtype, device=x.device)
-    st = lib.osr_conv2d_chain_fwd(C.byref(p), _p(x), _p(weight), _p(bias), _p(w3), _p(b3), cout3, _p(residual), _p(out), _stream())
+    mid = torch.empty((n, ho, wo, cmid), dtype=x.dtype, device=x.device) if keep_mid else None
+    st = lib.osr_conv2d_chain_fwd_ex(C.byref(p), _p(x), _p(weight), _p(bias), _p(w3), _p(b3), cout3, _p(residual), _p(out), _p(mid), _stream())
     if st == _lib.ERR_UNSUPPORTED:
         return None
     check(st, "osr_conv2d_chain_fwd")
     if FLOP_COUNT is not None:
         FLOP_COUNT["conv"] += 2.0 * n * ho * wo * (cmid * kh * kw * cin + cout3 * cmid)
-    return out
+    return (out, mid) if keep_mid else out
 
 
 def bottleneck(x: torch.Tensor, w1, b1, w2, b2, w3, b3, wsc=None, bsc=None) -> Optional[torch.Tensor]:

@@ -180,6 +180,7 @@ class OpensetRCNNTrainer:
         self.overlap_targets = True
         self._wside: Optional[torch.cuda.Stream] = None  # stream of the weight / bias gradient launches (see _wg)
         self.side_wgrad = True
+        self.chain_forward = True  # res3 blocks: conv2 -> conv3 in one launch that also stores conv2's output (osr_conv2d_chain_fwd_ex)
         self.multi_tensor_update = True  # the update as two launches (ops.sgd_step_multi_, ops.pack_dgrad_weight_multi_); False: one launch per tensor
         self._sgd_plan = None
         self._pack_plan = None
@@ -301,8 +302,14 @@ class OpensetRCNNTrainer:
                     continue
                 sc = e._conv(x, pre + ".shortcut", stride) if b == 0 else x
                 o1 = e._conv(x, pre + ".conv1", stride, relu=True)
-                o2 = e._conv(o1, pre + ".conv2", 1, 1, relu=True)
-                y = e._conv(o2, pre + ".conv3", relu=True, residual=sc, res_mode=1)
+                # res3: conv2 -> conv3 + shortcut as ONE launch that also stores conv2's output for the backward (bit-identical to the two)
+                ch = ops.conv2d_chain(o1, e.w[pre + ".conv2.w"], e.w[pre + ".conv2.b"], e.w[pre + ".conv3.w"], e.w[pre + ".conv3.b"], sc, 1, 1,
+                                      keep_mid=True) if (self.chain_forward and e.w[pre + ".conv2.w"].shape[0] == 128 and e.w[pre + ".conv3.w"].shape[0] == 512) else None
+                if ch is not None:
+                    y, o2 = ch
+                else:
+                    o2 = e._conv(o1, pre + ".conv2", 1, 1, relu=True)
+                    y = e._conv(o2, pre + ".conv3", relu=True, residual=sc, res_mode=1)
                 blocks.append(dict(pre=pre, x=x, o1=o1, o2=o2, y=y, stride=stride, first=b == 0, stage=si + 2))
                 x = y
             feats[f"res{si + 2}"] = x

@@ -47,6 +47,10 @@ def test_chain_matches_two_launches_and_torch(ops, case, dtype):
     sep = ops.conv2d(o2, w3, b3, relu=True, residual=rd, res_mode=1)
     torch.cuda.synchronize()
     assert torch.equal(y, sep), f"fused != separate launches: {(y.float() - sep.float()).abs().max().item()}"
+    # osr_conv2d_chain_fwd_ex: the first convolution's output stored as well (the training step keeps it): the separate launch's bits
+    y2, mid = ops.conv2d_chain(xd, w2, b2, w3, b3, rd, stride, pad, keep_mid=True)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, sep) and mid.shape == o2.shape and torch.equal(mid, o2)
     if n * ho * wo <= 4096:  # fp32 math on the rounded operands, the intermediate rounded where the kernels round it
         r = lambda t: t.to(dtype).float()  # noqa: E731
         o = r(F.relu(F.conv2d(x.float().permute(0, 3, 1, 2), wt["w2"].float(), wt["b2"], stride=stride, padding=pad)))

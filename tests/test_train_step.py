@@ -286,3 +286,22 @@ def test_multi_tensor_update_is_bit_identical_to_one_launch_per_tensor(setup):
     for group in ("master", "mom", "lowp", "wd"):
         for k, a in state[True][group].items():
             assert torch.equal(a, state[False][group][k]), (group, k)
+
+
+def test_chained_res3_forward_gives_the_same_step(setup):
+    """The trainer's res3 blocks run conv2 -> conv3 + shortcut as one launch that also stores conv2's output
+    (osr_conv2d_chain_fwd_ex); against the two launches: identical losses and gradients, bit for bit (the chain kernel is bit-identical
+    to the pair, and what it stores is what the pair's first launch stores)."""
+    from openset_rcnn_amd.host.train import OpensetRCNNTrainer
+    d = setup["dev"]
+    args = (d["images"], d["hw"], setup["h"], setup["w"], d["gt"], d["gcls"], d["gcnt"], d["keys"])
+    res = {}
+    for chain in (True, False):
+        tr = OpensetRCNNTrainer(setup["params"], dtype=torch.float16, device=DEV, lr=5e-5, loss_scale=512.0)
+        tr.chain_forward = chain
+        out = tr.step(*args, update=False)
+        torch.cuda.synchronize()
+        res[chain] = ({k: float(v) for k, v in out.items()}, {k: v.clone() for k, v in tr.grad.items()})
+    assert res[True][0] == res[False][0]
+    for k, a in res[True][1].items():
+        assert torch.equal(a, res[False][1][k]), k
