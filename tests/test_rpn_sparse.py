@@ -236,3 +236,26 @@ def test_trainer_sparse_and_dense_rpn_backward_agree(osr):
         assert bool(torch.isfinite(a).all()), k
         cos = float(F.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0))
         assert cos >= 0.9999 and abs(float(a.norm() / b.norm().clamp(min=1e-30)) - 1.0) <= 2e-3, (k, cos)
+
+
+def test_sparse_rows_fuzz(ops):
+    """Random sizes (around the 256-row walk and the 1024-workgroup split), densities from empty to full, caps below and above the
+    count: list == torch.nonzero, map == its inverse, counts as specified -- index work, bit-exact."""
+    gen = g(99)
+    sizes = [1, 5, 255, 256, 257, 1023, 1024, 1025, 4099, 65536, 262144 + 7, 262144 * 4 + 3]
+    for rows in sizes:
+        for dens in (0.0, 0.001, 0.03, 0.5, 1.0):
+            hit = torch.rand(rows, generator=gen) < dens
+            d5 = torch.zeros(rows, 5)
+            col = torch.randint(0, 5, (rows,), generator=gen)
+            d5[torch.arange(rows)[hit], col[hit]] = 1.0 + torch.rand(int(hit.sum()), generator=gen)
+            want = torch.nonzero(hit).squeeze(1).int()
+            for cap in {1, max(1, len(want) // 2), len(want) + 3}:
+                ids, rmap, cnt = ops.rpn_sparse_rows(d5.to(DEV), cap)
+                ids, rmap, cnt = ids.cpu(), rmap.cpu(), cnt.cpu().tolist()
+                k = min(cap, len(want))
+                assert cnt == [k, len(want)], (rows, dens, cap, cnt)
+                assert torch.equal(ids[:k], want[:k]) and bool((ids[k:] == -1).all()), (rows, dens, cap)
+                inv = torch.full((rows,), -1, dtype=torch.int32)
+                inv[want[:k].long()] = torch.arange(k, dtype=torch.int32)
+                assert torch.equal(rmap, inv), (rows, dens, cap)
