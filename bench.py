@@ -359,6 +359,49 @@ def graph_rate(eng, images, image_hw, steps: int, warm: int = 2):
     return images.shape[0] / dt, dt
 
 
+def full_lists_leg(params, tdt, dev, images, image_hw, batch: int, passes: int, steps: int = 10):
+    """The headline's schedule with EVERY slot of the proposal lists real: with random-init weights about a
+    fifth of the 4273 slots per image hold degenerate boxes the selection drops (empty after clipping), so RoIAlign and the box head do
+    ~79 % of the nominal work; a trained model fills all of them. Here the CF-RPN's delta branch is set to predict every anchor itself
+    (weights 0, bias 0.5: l = t = r = b = half the anchor), so nothing is dropped, and the same `passes` captured lanes are timed."""
+    from openset_rcnn_amd.host.engine import OpensetRCNNEngine
+    p2 = dict(params)
+    p2["proposal_generator.rpn_head.anchor_deltas.weight"] = torch.zeros_like(params["proposal_generator.rpn_head.anchor_deltas.weight"])
+    p2["proposal_generator.rpn_head.anchor_deltas.bias"] = torch.full_like(params["proposal_generator.rpn_head.anchor_deltas.bias"], 0.5)
+    eng = OpensetRCNNEngine(p2, dtype=tdt, device=dev)
+    keep = {}
+    eng.forward(images[:2], [(800, 1333)] * 2, keep=keep)
+    real = int(keep["sel"]["counts"].sum()) // 2
+    lane_images = [images]
+    for i in range(1, passes):
+        gi = torch.Generator().manual_seed(1000 + i)
+        lane_images.append(torch.randint(0, 256, (batch, 3, 800, 1333), generator=gi, dtype=torch.uint8).to(dev))
+    lanes, _ = make_lanes(eng, lane_images, image_hw, 1, 1)
+    turn = [0]
+    for _ in range(2 * passes):
+        step_lanes(lanes, turn)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_lanes(lanes, turn)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    g1 = lanes[0][0]
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        g1.replay()
+    torch.cuda.synchronize()
+    el1 = time.perf_counter() - t1
+    out = dict(images_per_sec=round(batch * steps / el, 2), ms_per_step=round(el / steps * 1e3, 3), passes_in_flight=passes, steps=steps,
+               single_pass_ms=round(el1 / steps * 1e3, 3), real_proposals_per_image=real,
+               note="CF-RPN deltas set to reproduce every anchor (no proposal is dropped: all 4273 slots per image real), same lanes and graphs as the "
+                    "headline; the headline's weights leave ~21 % of the slots as padding")
+    del lanes, eng
+    torch.cuda.empty_cache()
+    return out
+
+
 def parity_leg(tdt, dev, images, image_hw, flops_per_step: float, steps: int = 10):
     """What the benchmarked fp16 path gives up against fp32, and what fp32 costs. (1) agreement of the fast path's final
     detections with the engine's fp32 PARITY MODE (every tensor and product in fp32; tests/test_e2e_parity.py pins that mode to
@@ -768,6 +811,11 @@ def main(argv=None) -> int:
         except Exception as e:  # noqa: BLE001  (reported in the line; the headline stands)
             line["parity"] = {"error": repr(e)[:400]}
         torch.cuda.empty_cache()
+        if args.graph:
+            try:
+                line["full_lists"] = full_lists_leg(params, tdt, dev, images, image_hw, args.batch, max(1, args.passes_in_flight))
+            except Exception as e:  # noqa: BLE001
+                line["full_lists"] = {"error": repr(e)[:400]}
     # ---- train step leg: every rank takes part (the gradient all-reduce is a collective). With several ranks a watchdog makes
     # sure the headline line is printed even if that collective path hangs on the node -- and then the job FAILS (exit code 3).
     rc = 0
