@@ -245,6 +245,19 @@ def train_step_leg(params, tdt, device, images, image_hw, steps: int, warmup: in
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # the same loop with the loader's next batch handed to step(): its frozen prefix (stem + res2: weights no update touches) runs under
+    # this iteration's backward. Reported beside ms_per_iter, not in its place (one rank only: a secondary figure)
+    dt_pipe = None
+    if dist is None:
+        for _ in range(warmup):
+            tr.step(*args, next_images=images)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            losses_p = tr.step(*args, next_images=images)
+        torch.cuda.synchronize()
+        dt_pipe = (time.perf_counter() - t0) / steps
+        tr._prefetched = None
     # one instrumented iteration: algorithmic FLOPs of the MFMA launches per phase, HIP events around the phases
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     ops.FLOP_COUNT = dict(conv=0.0, wgrad=0.0)
@@ -279,6 +292,10 @@ def train_step_leg(params, tdt, device, images, image_hw, steps: int, warmup: in
                 whole_iteration_TFLOPs=round((fwd["conv"] + bwd["conv"] + bwd["wgrad"]) * world / dt / 1e12, 1), roofline=roofline,
                 trainable_params=tr.num_params, gradient_bytes_all_reduced=tr.num_params * 4 if world > 1 else 0, gt_boxes_per_image=8,
                 proposals_per_image_train=cap, rois_sampled_per_image=512, loss_total_last=round(total, 4), overflow_skipped_steps=tr.overflow_steps,
+                pipelined_ms_per_iter=round(dt_pipe * 1e3, 3) if dt_pipe is not None else None,
+                pipelined_note="step(next_images=...): the NEXT batch's frozen prefix (preprocessing + stem + res2, 1.3 ms, a function of that batch and of "
+                               "frozen weights only) is enqueued between this iteration's forward and backward and runs under the chain of small head / loss "
+                               "launches; every iteration still computes one prefix -- software pipelining, not caching; ms_per_iter above is WITHOUT it",
                 rpn_head_backward="on the anchors the loss samples (<= 512 per image; osr_rpn_sparse_rows / gather_cols / scatter_cols_add): hidden state "
                                   "recomputed, dW and the per-tap data gradient as GEMMs over the listed rows -- the FLOPs above count those, not the "
                                   "dense launches' 2 x 1.7 TFLOP on zero rows" if tr.sparse_rpn_bwd else "dense (every anchor row)")

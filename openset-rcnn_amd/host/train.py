@@ -184,6 +184,8 @@ class OpensetRCNNTrainer:
         self.multi_tensor_update = True  # the update as two launches (ops.sgd_step_multi_, ops.pack_dgrad_weight_multi_); False: one launch per tensor
         self._sgd_plan = None
         self._pack_plan = None
+        self._pre: Optional[torch.cuda.Stream] = None  # stream of the next batch's frozen prefix (_prefetch_frozen)
+        self._prefetched = None                        # (images, (hp, wp), x, event)
         # blocks whose weight gradients ride on the main stream (measured with res3.0 / res3.0-1 / all of res3: 25.4-25.5 against 25.5-25.7 ms,
         # inside the run-to-run spread: the backward is bound by the sum of its kernels, not by which stream ends last) -- left empty
         self.wgrad_on_main: set = set()
@@ -285,21 +287,21 @@ class OpensetRCNNTrainer:
             with torch.cuda.stream(self._side):
                 rpn_targets = e.rpn_targets_forward(lv, n, gt_boxes, gt_count, keys)
                 targets_ready = self._side.record_event()
-        if e.fuse_stem and self.freeze_at >= 1:  # (the stem is frozen: nothing of it is needed by the backward)
-            x = ops.stem_maxpool_raw(images, hp, wp, c["pixel_mean"], c["pixel_std"], e.w["backbone.bottom_up.stem.conv1.w"], e.w["backbone.bottom_up.stem.conv1.b"])
+        pref, self._prefetched = self._prefetched, None
+        if pref is not None and pref[0] is images and pref[1] == (hp, wp):
+            # the frozen prefix of THIS batch was computed under the previous iteration's backward (step(next_images=...)): take it
+            x, frozen_feats = pref[2]
+            cur.wait_event(pref[3])
         else:
-            xpad = ops.preprocess(images, hp, wp, c["pixel_mean"], c["pixel_std"], self.dtype)
-            x = ops.stem_conv(xpad, e.w["backbone.bottom_up.stem.conv1.w"], e.w["backbone.bottom_up.stem.conv1.b"], hp, wp, relu=True)
-            x = ops.maxpool3x3s2(x)
+            x, frozen_feats = self._frozen_prefix(images, hp, wp)
         blocks = []
         feats = {}
         for si, nb in enumerate(R50_BLOCKS):
             for b in range(nb):
                 pre = f"backbone.bottom_up.res{si + 2}.{b}"
                 stride = 2 if (b == 0 and si > 0) else 1
-                if si + 2 <= self.freeze_at:  # frozen stage: nothing of the block is needed by the backward (res2: one fused launch)
-                    x = e._bottleneck(x, pre, b == 0, stride)
-                    continue
+                if si + 2 <= self.freeze_at:  # frozen stage: part of the prefix above (nothing of it is needed by the backward)
+                    break
                 sc = e._conv(x, pre + ".shortcut", stride) if b == 0 else x
                 o1 = e._conv(x, pre + ".conv1", stride, relu=True)
                 # res3: conv2 -> conv3 + shortcut as ONE launch that also stores conv2's output for the backward (bit-identical to the two)
@@ -312,7 +314,7 @@ class OpensetRCNNTrainer:
                     y = e._conv(o2, pre + ".conv3", relu=True, residual=sc, res_mode=1)
                 blocks.append(dict(pre=pre, x=x, o1=o1, o2=o2, y=y, stride=stride, first=b == 0, stage=si + 2))
                 x = y
-            feats[f"res{si + 2}"] = x
+            feats[f"res{si + 2}"] = frozen_feats[f"res{si + 2}"] if si + 2 <= self.freeze_at else x
         s["blocks"], s["res"] = blocks, feats
         out, lat = {}, {}
         prev = e._conv(feats["res5"], "backbone.fpn_lateral5")
@@ -346,6 +348,43 @@ class OpensetRCNNTrainer:
         losses = dict(loss_rpn_loc=rpn[0], loss_rpn_ctr=rpn[1], loss_box_reg=roi["loss_box_reg"], loss_iou=roi["loss_iou"],
                       loss_dml=roi["loss_dml"], loss_cls=roi["loss_cls"])
         return losses, s
+
+    def _frozen_prefix(self, images, hp, wp):
+        """Stem (+ preprocessing) and the frozen residual stages: what depends on the batch and on frozen weights only -- the output of
+        the last frozen stage (the stem's max pool output when only the stem is frozen)."""
+        e, c = self.eng, self.eng.cfg
+        if e.fuse_stem and self.freeze_at >= 1:  # (the stem is frozen: nothing of it is needed by the backward)
+            x = ops.stem_maxpool_raw(images, hp, wp, c["pixel_mean"], c["pixel_std"], e.w["backbone.bottom_up.stem.conv1.w"], e.w["backbone.bottom_up.stem.conv1.b"])
+        else:
+            xpad = ops.preprocess(images, hp, wp, c["pixel_mean"], c["pixel_std"], self.dtype)
+            x = ops.stem_conv(xpad, e.w["backbone.bottom_up.stem.conv1.w"], e.w["backbone.bottom_up.stem.conv1.b"], hp, wp, relu=True)
+            x = ops.maxpool3x3s2(x)
+        feats = {}
+        for si, nb in enumerate(R50_BLOCKS):
+            if si + 2 > self.freeze_at:
+                break
+            for b in range(nb):
+                x = e._bottleneck(x, f"backbone.bottom_up.res{si + 2}.{b}", b == 0, 2 if (b == 0 and si > 0) else 1)
+            feats[f"res{si + 2}"] = x
+        return x, feats
+
+    def _prefetch_frozen(self, images, hp, wp) -> None:
+        """Software pipelining across iterations: the next batch's frozen prefix (a function of that batch and of weights no update
+        touches) is enqueued on a stream of its own behind the main stream's CURRENT point -- called between the forward and the
+        backward, it runs under the chain of small head / loss launches that leaves the GPU nearly idle there. The next step() that is
+        handed the same tensor object picks the result up (and waits for it); any other batch recomputes. Same values either way."""
+        if self.freeze_at < 2 or self.device.type != "cuda":
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if self._pre is None:
+            self._pre = torch.cuda.Stream(device=self.device)
+        self._pre.wait_event(cur.record_event())
+        with torch.cuda.stream(self._pre):
+            x, feats = self._frozen_prefix(images, hp, wp)
+            done = self._pre.record_event()
+        for t in [x] + list(feats.values()):
+            t.record_stream(cur)
+        self._prefetched = (images, (hp, wp), (x, feats), done)
 
     # ---- backward -------------------------------------------------------------------------------------------------
     def _f32_linear_bwd(self, x, dy, wt, name, dy_pad=None):
@@ -402,7 +441,7 @@ class OpensetRCNNTrainer:
             for t in reads:
                 t.record_stream(self._wside)
 
-    def _backward(self, s, n, grad_scale: float = 1.0, overlap: bool = True):
+    def _backward(self, s, n, grad_scale: float = 1.0, overlap: bool = True, prefetch=None):
         """Gradients of grad_scale * (sum of the six losses), times the loss scale, into self.grad. overlap: start each gradient
         bucket's all-reduce as soon as the backward has passed it (several ranks only; all_reduce_grads() then just waits)."""
         e, c, g, S = self.eng, self.eng.cfg, self.grad, self.loss_scale * grad_scale
@@ -576,6 +615,8 @@ class OpensetRCNNTrainer:
                 G = ops.conv2d_dgrad(G, self.wd[pre + ".shortcut"], (hx, wx), stride, 0, add=dx, post_mask=pm)
             else:
                 G = ops.conv2d_dgrad(d_o1, self.wd[pre + ".conv1"], (hx, wx), 1, 0, add=G, post_mask=pm)
+        if prefetch is not None:  # behind the last data gradient: the main stream is done, the weight-gradient stream still has its backlog
+            self._prefetch_frozen(*prefetch)
         if self.side_wgrad and self._wside is not None:  # join: the update (and any collective issued from here on) sees every weight gradient
             torch.cuda.current_stream(self.device).wait_stream(self._wside)
 
@@ -626,14 +667,16 @@ class OpensetRCNNTrainer:
         (`wait=True` is also what the checkpoint writer uses, so that no skipped or half-applied state is written blind.)"""
         return self.scaler.poll(wait, lag)
 
-    def step(self, images, image_hw, hp, wp, gt_boxes, gt_classes, gt_count, keys, update: bool = True) -> Dict[str, torch.Tensor]:
+    def step(self, images, image_hw, hp, wp, gt_boxes, gt_classes, gt_count, keys, update: bool = True, next_images=None) -> Dict[str, torch.Tensor]:
         """One iteration: returns the loss dict (GPU scalars). update=False leaves the parameters untouched (gradients stay in
-        self.grad, scaled by loss_scale)."""
+        self.grad, scaled by loss_scale). next_images (optional): the NEXT iteration's image batch, if the loader already has it: its
+        frozen prefix (stem + frozen stages) is computed under this iteration's backward (_prefetch_frozen) and used by the next
+        step() that is given that same tensor."""
         # earlier iterations' verdicts adjust the loss scale here, at one deterministic point of the iteration; with several ranks
         # the call waits for them, so that all ranks change the scale at the same iteration (see poll_overflow)
         self.poll_overflow(wait=parallel.is_dist(), lag=self.MULTI_RANK_LAG if parallel.is_dist() else 0)
         losses, saved = self._forward(images, image_hw, hp, wp, gt_boxes, gt_classes, gt_count, keys)
-        self._backward(saved, images.shape[0], overlap=update)
+        self._backward(saved, images.shape[0], overlap=update, prefetch=(next_images, hp, wp) if next_images is not None else None)
         if update:
             self._update(self.all_reduce_grads())
         return losses

@@ -305,3 +305,31 @@ def test_chained_res3_forward_gives_the_same_step(setup):
     assert res[True][0] == res[False][0]
     for k, a in res[True][1].items():
         assert torch.equal(a, res[False][1][k]), k
+
+
+def test_prefetched_frozen_prefix_gives_the_same_steps(setup):
+    """step(next_images=...) computes the next batch's frozen prefix (stem + res2) under the current backward; the next step() that is
+    handed that tensor uses it. Three updates on alternating batches with and without the hand-over: identical losses and parameters,
+    bit for bit; a step given ANOTHER tensor than the announced one recomputes (and is still right)."""
+    from openset_rcnn_amd.host.train import OpensetRCNNTrainer
+    d = setup["dev"]
+    imgs_a = d["images"]
+    imgs_b = torch.flip(d["images"], dims=(3,)).contiguous()
+    rest = (d["hw"], setup["h"], setup["w"], d["gt"], d["gcls"], d["gcnt"], d["keys"])
+    seq = [imgs_a, imgs_b, imgs_a, imgs_b]
+    res = {}
+    for mode in ("plain", "pipelined", "wrong_announcement"):
+        tr = OpensetRCNNTrainer(setup["params"], dtype=torch.float16, device=DEV, lr=0.002, loss_scale=512.0)
+        losses = []
+        for i in range(3):
+            nxt = None if mode == "plain" else (seq[i + 1] if mode == "pipelined" else imgs_a.clone())
+            out = tr.step(seq[i], *rest, next_images=nxt)
+            losses.append({k: float(v) for k, v in out.items()})
+            if mode == "pipelined":
+                assert tr._prefetched is not None and tr._prefetched[0] is seq[i + 1]
+        torch.cuda.synchronize()
+        res[mode] = (losses, {k: v.clone() for k, v in tr.master.items()})
+    for mode in ("pipelined", "wrong_announcement"):
+        assert res[mode][0] == res["plain"][0], mode
+        for k, a in res[mode][1].items():
+            assert torch.equal(a, res["plain"][1][k]), (mode, k)
