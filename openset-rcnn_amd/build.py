@@ -49,7 +49,9 @@ def _hipcc() -> str:
 
 def _digest(path: str, flags) -> str:
     h = hashlib.sha1()
-    for f in (path, os.path.join(CSRC, "osr_common.h"), os.path.join(HERE, "..", "include", "osr.h")):
+    # every header under csrc/ (osr_common.h, osr_pln_dist.h, osr_box_loss.h, ...) and the public header: an edit to any of them rebuilds
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    for f in [path] + headers + [os.path.join(HERE, "..", "include", "osr.h")]:
         with open(f, "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(COMMON + list(flags)).encode())

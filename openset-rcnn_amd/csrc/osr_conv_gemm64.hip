@@ -102,6 +102,7 @@ struct Conv64Args {
     void* mid_out;         // nullable: the parked relu(conv + bias) tile also goes to HBM, dense (rows, 128): the training step keeps it for the backward
 #ifdef C64_STAMPS
     unsigned long long* dbg;
+    unsigned long long* p8;
 #endif
 };
 
@@ -113,8 +114,16 @@ struct Conv64Args {
 static unsigned long long* g_c64_stamps = nullptr;
 extern "C" void osr_debug_set_conv_stamps(unsigned long long* p) { g_c64_stamps = p; }
 #define C64_STAMP(i) if (a.dbg && tid == 0) a.dbg[(long long)blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memrealtime()
+// 8-phase K loop: shader-clock stamps of K tile P8_STAMP_TILE at the section boundaries of its four phases (phase start, fragment
+// reads issued, pieces issued, first barrier passed, MFMAs issued), kept in registers and written after the loop (a store inside the
+// loop would count on vmcnt); lanes 0 of waves 0 and 4 -> p8[(block * 2 + wave group) * 24 + i]
+static unsigned long long* g_p8_stamps = nullptr;
+extern "C" void osr_debug_set_p8_stamps(unsigned long long* p) { g_p8_stamps = p; }
+#define P8_STAMP_TILE 6
+#define P8_STAMP(i) if (ks == P8_STAMP_TILE) p8s[i] = __builtin_amdgcn_s_memtime()
 #else
 #define C64_STAMP(i)
+#define P8_STAMP(i)
 #endif
 
 template <class TO> __device__ __forceinline__ void store8_64(TO* p, const float v[8]);
@@ -195,10 +204,23 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
     //      and one select per piece: offset = mask bit ? a_off0 + (scalar tap offset) : out of bounds (zero fill).
     //      Bit 31 is never set: tap 31 is the "issue nothing" tap of the last K step. ----
     const int lrow = lane >> 3, slot = lane & 7;
+    // TWO == 2 (the 8-phase K loop below): the 256 x 256 tile is staged in four UNITS of 16 pieces, the rows that one phase's fragment reads
+    // cover: activation rows of row half qa of both wave rows, weight rows of column half qb of all four wave columns; a wave issues
+    // two pieces of every unit (descriptor j = 2 q + jj). Otherwise a wave's pieces are consecutive.
+    constexpr bool PH8 = (TWO == 2);
+    static_assert(!PH8 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && EPI != 2), "8-phase K loop: 256 x 256 tile, 2 x 4 waves");
+    auto a_piece = [&](int j) -> int {
+        if constexpr (PH8) { const int lp = wid * 2 + (j & 1); return (lp >> 3) * 16 + (j >> 1) * 8 + (lp & 7); }
+        else return wid * A_PIECES + j;
+    };
+    auto b_piece = [&](int j) -> int {
+        if constexpr (PH8) { const int lp = wid * 2 + (j & 1); return (lp >> 2) * 8 + (j >> 1) * 4 + (lp & 3); }
+        else return wid * B_PIECES + j;
+    };
     unsigned a_off0[A_PIECES], a_mask[A_PIECES];
 #pragma unroll
     for (int j = 0; j < A_PIECES; ++j) {
-        const int row = (wid * A_PIECES + j) * 8 + lrow;
+        const int row = a_piece(j) * 8 + lrow;
         const long long m = m0 + row;
         const bool ok = m < a.M;
         const long long mm = ok ? m : 0;
@@ -221,7 +243,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
     unsigned b_off[B_PIECES];
 #pragma unroll
     for (int j = 0; j < B_PIECES; ++j) {
-        const int row = (wid * B_PIECES + j) * 8 + lrow;
+        const int row = b_piece(j) * 8 + lrow;
         const unsigned chunk = (unsigned)(slot ^ ((row >> 1) & 7));
         // EPI == 2 runs the MFMAs with the weights as the A operand (D = W X^T: a lane then holds output channels of ONE pixel); LDS row
         // rho of a 32-row group takes weight row 8 ((rho >> 2) & 3) + 4 (rho >> 4) + (rho & 3), so that the lane's rows 4g..4g+3 of the
@@ -242,11 +264,11 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
         if ((q) < A_PIECES) {                                                                                                     \
             const int j_ = (q) < A_PIECES ? (q) : 0;                                                                              \
             const unsigned off_ = ((a_mask[j_] >> tap) & 1u) ? a_off0[j_] + tap_off : OOB_OFF;                                     \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t*)(sa_ + (wid * A_PIECES + j_) * 1024), 16, off_, 0, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t*)(sa_ + a_piece(j_) * 1024), 16, off_, 0, 0, 0);            \
         } else {                                                                                                                  \
             const int j_ = (q) >= A_PIECES ? (q) - A_PIECES : 0;                                                                  \
             const unsigned boff_ = b_off[j_]; /* plain variables only: a type-dependent argument makes the host pass drop the kernel */ \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(sa_ + BM * 128 + (wid * B_PIECES + j_) * 1024), 16, boff_, kbyte, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(sa_ + BM * 128 + b_piece(j_) * 1024), 16, boff_, kbyte, 0, 0); \
         }                                                                                                                         \
     }
 #define C64_ISSUE(stage)                                                                  \
@@ -442,7 +464,151 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
         }                                                                                                                           \
     }
 #define C64_FIRST_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-    if constexpr (TWO) {
+    if constexpr (PH8) {
+        // ---- 8-phase K loop (round 5; cdna_hip_programming.md section 5, "The 256^2 8-phase template", rebuilt here for the implicit-GEMM
+        // gather). A K tile is four phases, one 64 x 32 quadrant of the wave's 128 x 64 outputs each (16 MFMAs), in the order
+        // (qa, qb) = (0,0) (0,1) (1,1) (1,0); every phase issues ONE staging unit (two LDS-DMA pieces per wave) and reads only the fragments
+        // that are new to it:
+        //     phase 1: read A half 0 + B half 0 | issue A half 1 of tile t+1        phase 3: read A half 1 | issue B half 0 of tile t+2
+        //     phase 2: read B half 1            | issue A half 0 of tile t+2        phase 4: (no read)     | issue B half 1 of tile t+2
+        // Waves 4-7 (wr == 1) run one barrier behind waves 0-3: while one wave of a SIMD is in its 16-MFMA cluster its partner reads
+        // fragments and issues its pieces. The only wait on the vector-memory counter is phase 4's vmcnt(6): the three units issued in
+        // phases 2-4 stay in flight across the tile boundary (never 0 inside the loop), the unit issued in phase 1 and everything older --
+        // all of tile t+1 -- has landed for this wave, and the barrier behind the wait publishes that to the others before phase 1 of
+        // tile t+1 reads it (a read sits one phase AFTER the wait that retires the data). Write-after-read: a unit is restaged one
+        // phase (A half 0) or two phases (the others) after its last read; every phase retires its own fragment reads (lgkmcnt(0)) in
+        // front of its first barrier, so one phase is enough for both wave groups. Past the last tile the units are dummies (tap 31:
+        // zero fill; weights re-read slice 0) so that the counts stay uniform. Per accumulator the K order is the generic loop's:
+        // outputs are bit-identical to the TWO == 1 kernel.
+        const unsigned fo0 = (unsigned)((lane & 15) * 128 + ((((lane >> 4) ^ ((lane & 15) >> 1)) & 7) << 4));  // 32-wide K step 0; step 1: ^ 64
+        frag_t fa[2][2][2], fb0[2][2], fb1[2][2];  // [row tile of the half][16-row sub-tile][32-wide K step]; [16-column sub-tile][K step]
+#define P8_READ_A(qa_)                                                                                                              \
+        {                                                                                                                           \
+            _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)                                                                        \
+                _Pragma("unroll") for (int si = 0; si < 2; ++si)                                                                    \
+                    _Pragma("unroll") for (int k32 = 0; k32 < 2; ++k32)                                                             \
+                        fa[ii][si][k32] = *reinterpret_cast<const frag_t*>(sa + ((wr * 4 + (qa_) * 2 + ii) * 32 + si * 16) * 128 + (fo0 ^ (unsigned)(k32 * 64))); \
+        }
+#define P8_READ_B(dst_, qb_)                                                                                                        \
+        {                                                                                                                           \
+            _Pragma("unroll") for (int sj = 0; sj < 2; ++sj)                                                                        \
+                _Pragma("unroll") for (int k32 = 0; k32 < 2; ++k32)                                                                 \
+                    dst_[sj][k32] = *reinterpret_cast<const frag_t*>(sb + ((wc * 2 + (qb_)) * 32 + sj * 16) * 128 + (fo0 ^ (unsigned)(k32 * 64))); \
+        }
+#define P8_MFMA4(qa_, fb_, qb_, k32_, ii_)                                                                                          \
+        {                                                                                                                           \
+            _Pragma("unroll") for (int si = 0; si < 2; ++si)                                                                        \
+                _Pragma("unroll") for (int sj = 0; sj < 2; ++sj)                                                                    \
+                    acc[(qa_) * 2 + (ii_)][qb_][si][sj] = Frag64<TI>::mfma16(fa[ii_][si][k32_], fb_[sj][k32_], acc[(qa_) * 2 + (ii_)][qb_][si][sj]); \
+        }
+        // one phase's 16 MFMAs; MID is placed behind the 12th of them (phase 1: the scalar K-state advance, in the matrix pipe's shadow).
+        // Measured and dropped: the phase's pieces issued from inside the cluster (one / both of them: 3 % / 8 % slower), the waves of odd
+        // wave columns issuing their pieces in front of their reads (4 % slower), reads retired behind the phase's first barrier (+-0).
+#define P8_MFMA(qa_, fb_, qb_, st_, MID)                                                                                            \
+        {                                                                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                                      \
+            __builtin_amdgcn_s_setprio(1);                                                                                          \
+            P8_MFMA4(qa_, fb_, qb_, 0, 0);                                                                                          \
+            P8_MFMA4(qa_, fb_, qb_, 0, 1);                                                                                          \
+            P8_MFMA4(qa_, fb_, qb_, 1, 0);                                                                                          \
+            MID;                                                                                                                    \
+            P8_MFMA4(qa_, fb_, qb_, 1, 1);                                                                                          \
+            __builtin_amdgcn_s_setprio(0);                                                                                          \
+            P8_STAMP(st_);                                                                                                          \
+            __builtin_amdgcn_s_barrier();                                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                                      \
+        }
+#define P8_PIECE(stage_, q_)                                                                                                        \
+        {                                                                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                                      \
+            C64_ISSUE_PIECE(stage_, (q_));                                                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                                      \
+        }
+#define P8_ISSUE(stage_, q0_)                                                                                                       \
+        {                                                                                                                           \
+            P8_PIECE(stage_, (q0_));                                                                                                \
+            P8_PIECE(stage_, (q0_) + 1);                                                                                            \
+        }
+#define P8_ADV(tile_)                                                                                                               \
+        {                                                                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                                      \
+            C64_ADVANCE();                                                                                                          \
+            if ((tile_) >= nk) { tap = 31; kbyte = 0; }                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                                      \
+        }
+#define P8_UNIT_A0 0
+#define P8_UNIT_A1 2
+#define P8_UNIT_B0 (A_PIECES)
+#define P8_UNIT_B1 (A_PIECES + 2)
+        // prologue: tile 0 is in flight (C64_ISSUE(0) above, and the epilogue operands behind it); three units of tile 1 go out before the wait
+        P8_ADV(1);
+        P8_ISSUE(1, P8_UNIT_A0);
+        P8_ISSUE(1, P8_UNIT_B0);
+        P8_ISSUE(1, P8_UNIT_B1);
+        c64_wait_vm_lgkm_barrier<6>();  // tile 0 (and every older load) has landed, for every wave
+        C64_STAMP(1);
+#ifdef C64_STAMPS
+        unsigned long long p8s[24];
+        for (int i = 0; i < 24; ++i) p8s[i] = 0;
+#endif
+        if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one barrier behind
+        __builtin_amdgcn_sched_barrier(0);
+        for (int ks = 0; ks < nk; ++ks) {
+            const int cs = ks & 1, ns = cs ^ 1;
+            const unsigned char* sa = lds + cs * STAGE;
+            const unsigned char* sb = sa + BM * 128;
+            // phase 1 (the K state is one tile ahead: tile ks+1; it advances to tile ks+2 inside the cluster)
+            P8_STAMP(0);
+            P8_READ_A(0);
+            P8_READ_B(fb0, 0);
+            P8_STAMP(1);
+            P8_ISSUE(ns, P8_UNIT_A1);
+            P8_STAMP(2);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            P8_STAMP(3);
+            P8_MFMA(0, fb0, 0, 4, P8_ADV(ks + 2));
+            // phase 2
+            P8_STAMP(5);
+            P8_READ_B(fb1, 1);
+            P8_STAMP(6);
+            P8_ISSUE(cs, P8_UNIT_A0);  // tile ks+2: the rows phase 1 has just read (retired in front of its barrier)
+            P8_STAMP(7);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            P8_STAMP(8);
+            P8_MFMA(0, fb1, 1, 9, {});
+            // phase 3
+            P8_STAMP(10);
+            P8_READ_A(1);
+            P8_STAMP(11);
+            P8_ISSUE(cs, P8_UNIT_B0);
+            P8_STAMP(12);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            P8_STAMP(13);
+            P8_MFMA(1, fb1, 1, 14, {});
+            // phase 4
+            P8_STAMP(15);
+            P8_STAMP(16);
+            P8_ISSUE(cs, P8_UNIT_B1);
+            P8_STAMP(17);
+            c64_wait_vm_lgkm_barrier<6>();   // tile ks+1 complete (phase 1's unit and everything older); the later units stay in flight
+            P8_STAMP(18);
+            P8_MFMA(1, fb0, 0, 19, {});
+            P8_STAMP(20);
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();  // waves 0-3 take the barrier the others are one behind by
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy units have landed before LDS is reused
+#ifdef C64_STAMPS
+        if (a.p8 && (tid & 255) == 0)
+            for (int i = 0; i < 24; ++i) a.p8[((long long)blockIdx.x * 2 + (tid >> 8)) * 24 + i] = p8s[i];
+#endif
+#undef P8_READ_A
+#undef P8_READ_B
+#undef P8_MFMA
+#undef P8_MFMA4
+#undef P8_PIECE
+#undef P8_ADV
+#undef P8_ISSUE
+    } else if constexpr (TWO) {
         for (int ks = 0; ks < nk; ++ks) {
             if (ks == 0) { C64_FIRST_WAIT(); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             __syncthreads();  // tile ks landed for every wave; every wave is done reading the other stage
@@ -776,6 +942,9 @@ static int env_int(const char* name, int dflt) {
 #else
 #define OSR_KNOB(name, dflt) (dflt)
 #endif
+#ifdef OSR_EXPERIMENT
+static int ph8_enabled() { return env_int("OSR_CONV_PH8", 1); }  // (read at every launch: one process can compare the two K loops, scripts/exp_ph8.py)
+#endif
 static int rpn_big_min_tiles() { return OSR_KNOB("OSR_RPN_BIG_MIN_TILES", 512); }  // fused CF-RPN head: 256-row tiles from this many tiles on
 static int tap_minor_default() { return OSR_KNOB("OSR_CONV_TAP_MINOR", 1); }
 
@@ -797,7 +966,7 @@ static void conv64_launch_tile(Conv64Args& a, hipStream_t st) {
     if (a.ntile <= 0) { a.tile0 = 0; a.ntile = a.tiles_m * a.tiles_n; a.ksplit = 1; }  // the whole grid in one launch
     const size_t lds = conv64_lds_bytes(BM, BN, TWO, NW);
     if (lds > 64 * 1024) {
-        static osr_dev_mask attr{0};
+        static osr_dev_mask attr{0};  // (one per instantiation of this function template)
         osr_once_per_device(attr, [] { allow_big_lds(conv_igemm64_kernel<TI, TO, BM, BN, WM, WN, 0, TWO, SPLIT>); });
     }
     hipLaunchKernelGGL((conv_igemm64_kernel<TI, TO, BM, BN, WM, WN, 0, TWO, SPLIT>), dim3((unsigned)a.ntile * (SPLIT ? a.ksplit : 1)), dim3(NW * 64), lds, st, a);
@@ -940,7 +1109,7 @@ static osr_status conv64_launch(Conv64Args& a, hipStream_t st) {
         t.out = reinterpret_cast<float*>(a.p.workspace) - sp.m_tail0 * a.p.cout;  // the epilogue adds row * cout: slab row 0 = output row m_tail0
         t.p.relu = 0; t.p.out_dtype = OSR_F32;
         switch (sp.tile_id) {
-            case T256x256_2: conv64_launch_tile<TI, float, 256, 256, 2, 4, 1, 1>(t, st); break;
+            case T256x256_2: conv64_launch_tile<TI, float, 256, 256, 2, 4, 2, 1>(t, st); break;
             case T128x256_1: conv64_launch_tile<TI, float, 128, 256, 2, 2, 0, 1>(t, st); break;
             default: conv64_launch_tile<TI, float, 128, 128, 2, 2, 0, 1>(t, st); break;
         }
@@ -968,7 +1137,12 @@ static void conv64_dispatch_tile(int id, Conv64Args& a, hipStream_t st) {
 #ifdef C64_BIG_W4
         case T256x256_2: conv64_launch_tile<TI, TO, 256, 256, 2, 2, 1>(a, st); break;
 #else
-        case T256x256_2: conv64_launch_tile<TI, TO, 256, 256, 2, 4, 1>(a, st); break;
+        case T256x256_2:
+#ifdef OSR_EXPERIMENT
+            if (!ph8_enabled()) { conv64_launch_tile<TI, TO, 256, 256, 2, 4, 1>(a, st); break; }  // the round-4 K loop, for same-process comparisons
+#endif
+            conv64_launch_tile<TI, TO, 256, 256, 2, 4, 2>(a, st);
+            break;
 #endif
         case T128x256_1: conv64_launch_tile<TI, TO, 128, 256, 2, 2, 0>(a, st); break;
         case T256x128_1: conv64_launch_tile<TI, TO, 256, 128, 2, 2, 0>(a, st); break;
@@ -1018,8 +1192,17 @@ static osr_status cfrpn_fused_launch(Conv64Args& a, hipStream_t st) {
         a.tail_lds_off = (int)(t_bytes > stages ? t_bytes : stages);
         const size_t lds = (size_t)a.tail_lds_off + 5 * 256 * 4;
         static osr_dev_mask attr8{0};
-        osr_once_per_device(attr8, [] { allow_big_lds(conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1, 1>); });
-        hipLaunchKernelGGL((conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1, 1>), dim3((unsigned)a.tiles_m), dim3(512), lds, st, a);
+        osr_once_per_device(attr8, [] {
+            allow_big_lds(conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1, 2>);
+#ifdef OSR_EXPERIMENT
+            allow_big_lds(conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1, 1>);
+#endif
+        });
+#ifdef OSR_EXPERIMENT
+        if (!ph8_enabled()) hipLaunchKernelGGL((conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1, 1>), dim3((unsigned)a.tiles_m), dim3(512), lds, st, a);
+        else
+#endif
+        hipLaunchKernelGGL((conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1, 2>), dim3((unsigned)a.tiles_m), dim3(512), lds, st, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { osr_set_error("osr_cfrpn_head_fwd: launch failed: %s", hipGetErrorString(e)); return OSR_ERR_LAUNCH; }
         return OSR_OK;
@@ -1063,7 +1246,7 @@ osr_status osr_conv64_run(const osr_conv_params* p, const void* in, const void* 
     a.tail_w = a.tail_b = nullptr; a.tail_deltas = a.tail_ctr = nullptr;
     a.w3 = nullptr; a.bias3 = nullptr; a.cout3 = 0; a.w3_bytes = a.out_bytes = 0;
 #ifdef C64_STAMPS
-    a.dbg = g_c64_stamps;
+    a.dbg = g_c64_stamps; a.p8 = g_p8_stamps;
 #endif
     if (p->in_dtype == OSR_F16) {
         if (p->out_dtype == OSR_F16) return conv64_launch<f16_t, f16_t>(a, st);
@@ -1115,7 +1298,7 @@ extern "C" osr_status osr_cfrpn_head_fwd_ex(const osr_conv_params* p, const void
     a.tail_w = w_tail; a.tail_b = b_tail; a.tail_deltas = deltas; a.tail_ctr = ctr;
     a.w3 = nullptr; a.bias3 = nullptr; a.cout3 = 0; a.w3_bytes = a.out_bytes = 0;
 #ifdef C64_STAMPS
-    a.dbg = nullptr;
+    a.dbg = nullptr; a.p8 = g_p8_stamps;
 #endif
     hipStream_t st = (hipStream_t)stream;
     return p->in_dtype == OSR_F16 ? cfrpn_fused_launch<f16_t>(a, st) : cfrpn_fused_launch<bf16_t>(a, st);
@@ -1183,7 +1366,7 @@ extern "C" osr_status osr_conv2d_chain_fwd_ex(const osr_conv_params* p, const vo
     a.w3_bytes = (unsigned)((long long)cout3 * p->cout * 2); a.out_bytes = (unsigned)out_bytes;
     a.mid_out = mid_out;
 #ifdef C64_STAMPS
-    a.dbg = g_c64_stamps;
+    a.dbg = g_c64_stamps; a.p8 = g_p8_stamps;
 #endif
     hipStream_t st = (hipStream_t)stream;
     return p->in_dtype == OSR_F16 ? conv_chain_launch<f16_t, 128>(a, st) : conv_chain_launch<bf16_t, 128>(a, st);
