@@ -467,19 +467,21 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
     if constexpr (PH8) {
         // ---- 8-phase K loop (round 5; cdna_hip_programming.md section 5, "The 256^2 8-phase template", rebuilt here for the implicit-GEMM
         // gather). A K tile is four phases, one 64 x 32 quadrant of the wave's 128 x 64 outputs each (16 MFMAs), in the order
-        // (qa, qb) = (0,0) (0,1) (1,1) (1,0); every phase issues ONE staging unit (two LDS-DMA pieces per wave) and reads only the fragments
-        // that are new to it:
-        //     phase 1: read A half 0 + B half 0 | issue A half 1 of tile t+1        phase 3: read A half 1 | issue B half 0 of tile t+2
-        //     phase 2: read B half 1            | issue A half 0 of tile t+2        phase 4: (no read)     | issue B half 1 of tile t+2
+        // (qa, qb) = (0,0) (0,1) (1,1) (1,0); a phase reads only the fragments that are new to it and issues the staging units (two LDS-DMA
+        // pieces per wave and unit) whose LDS rows have just been freed:
+        //     phase 1: read A half 0 + B half 0 |  --                               phase 3: read A half 1 | issue B half 0 of tile t+2
+        //     phase 2: read B half 1            | issue A half 0 of tile t+2        phase 4: (no read)     | issue B half 1, A half 1 of tile t+2
         // Waves 4-7 (wr == 1) run one barrier behind waves 0-3: while one wave of a SIMD is in its 16-MFMA cluster its partner reads
-        // fragments and issues its pieces. The only wait on the vector-memory counter is phase 4's vmcnt(6): the three units issued in
-        // phases 2-4 stay in flight across the tile boundary (never 0 inside the loop), the unit issued in phase 1 and everything older --
-        // all of tile t+1 -- has landed for this wave, and the barrier behind the wait publishes that to the others before phase 1 of
-        // tile t+1 reads it (a read sits one phase AFTER the wait that retires the data). Write-after-read: a unit is restaged one
-        // phase (A half 0) or two phases (the others) after its last read; every phase retires its own fragment reads (lgkmcnt(0)) in
-        // front of its first barrier, so one phase is enough for both wave groups. Past the last tile the units are dummies (tap 31:
-        // zero fill; weights re-read slice 0) so that the counts stay uniform. Per accumulator the K order is the generic loop's:
-        // outputs are bit-identical to the TWO == 1 kernel.
+        // fragments and issues its pieces. The only wait on the vector-memory counter is phase 4's vmcnt(8): the four units of tile t+2
+        // stay in flight across the tile boundary (never 0 inside the loop; every unit has at least four phases to land), everything
+        // older -- all of tile t+1 -- has landed for this wave, and the barrier behind the wait publishes that to the others before
+        // phase 1 of tile t+1 reads it (a read sits one phase AFTER the wait that retires the data). Write-after-read: every phase
+        // retires its own fragment reads (lgkmcnt(0)) in front of its first barrier, so a unit may be restaged one phase after its
+        // last read by either wave group (A half 0: read in phase 1, restaged in 2; A half 1: 3 -> 4; the B halves two phases later).
+        // Past the last tile the units are dummies (tap 31: zero fill; weights re-read slice 0) so that the counts stay uniform. Per
+        // accumulator the K order is the generic loop's: outputs are bit-identical to the TWO == 1 kernel (tests/test_conv_8phase.py).
+        // Measured (scripts/exp_ph8.py, same process, random operands): FC1 1542 -> 1379 us, fpn_output2 1153 -> 1076 us; ablations
+        // (scripts/exp_ph8_ablate.patch): without the pieces 1100 us, pieces that always hit L2 1247 us, without fragment reads 1333 us.
         const unsigned fo0 = (unsigned)((lane & 15) * 128 + ((((lane >> 4) ^ ((lane & 15) >> 1)) & 7) << 4));  // 32-wide K step 0; step 1: ^ 64
         frag_t fa[2][2][2], fb0[2][2], fb1[2][2];  // [row tile of the half][16-row sub-tile][32-wide K step]; [16-column sub-tile][K step]
 #define P8_READ_A(qa_)                                                                                                              \
@@ -545,7 +547,8 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
         P8_ISSUE(1, P8_UNIT_A0);
         P8_ISSUE(1, P8_UNIT_B0);
         P8_ISSUE(1, P8_UNIT_B1);
-        c64_wait_vm_lgkm_barrier<6>();  // tile 0 (and every older load) has landed, for every wave
+        P8_ISSUE(1, P8_UNIT_A1);
+        c64_wait_vm_lgkm_barrier<8>();  // tile 0 (and every older load) has landed, for every wave
         C64_STAMP(1);
 #ifdef C64_STAMPS
         unsigned long long p8s[24];
@@ -562,7 +565,6 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
             P8_READ_A(0);
             P8_READ_B(fb0, 0);
             P8_STAMP(1);
-            P8_ISSUE(ns, P8_UNIT_A1);
             P8_STAMP(2);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             P8_STAMP(3);
@@ -589,8 +591,9 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
             P8_STAMP(15);
             P8_STAMP(16);
             P8_ISSUE(cs, P8_UNIT_B1);
+            P8_ISSUE(cs, P8_UNIT_A1);  // (its rows were read in phase 3 and retired in front of that phase's barrier)
             P8_STAMP(17);
-            c64_wait_vm_lgkm_barrier<6>();   // tile ks+1 complete (phase 1's unit and everything older); the later units stay in flight
+            c64_wait_vm_lgkm_barrier<8>();   // tile ks+1 complete; the four units of tile ks+2 stay in flight
             P8_STAMP(18);
             P8_MFMA(1, fb0, 0, 19, {});
             P8_STAMP(20);
@@ -979,7 +982,7 @@ static void conv64_launch_tile(Conv64Args& a, hipStream_t st) {
 // the matrix pipe (r residents x w) or by the L2 -> LDS latency (single buffer: L + w, double buffer: max(L, r x w)).
 //   time = full_rounds x tile(occ) + tile(residents of the last partial round),  tile(r) = fixed + nk x slice(r)
 // The 256-wide tiles read the residual in the epilogue (no prefetch under the K loop), which measured 1.6x slower on the
-// HBM-bound residual layers: they are not offered when there is a residual.
+// HBM-bound residual layers: they are not offered to a residual layer with fewer than 18 K slices.
 struct TileCfg { int id, bm, bn, two, occ, pre_res; double cap; };  // cap: per-CU MFMA rate under load, FLOP per us
 static const TileCfg kTileCfgs[] = {
     {T128x128_1, 128, 128, 0, 3, 1, 4.45e6}, {T128x128_2, 128, 128, 1, 2, 1, 4.45e6}, {T256x256_2, 256, 256, 1, 1, 0, 5.2e6},
@@ -1017,7 +1020,10 @@ static int conv64_pick_tile(const Conv64Args& a) {
     for (const TileCfg& c : kTileCfgs) {
         if (c.bn == 256 && cout % 256 != 0) continue;
         if (cout <= 64 && c.bn != 64) continue;          // narrow layers: no half-empty N tiles
-        if (res && !c.pre_res) continue;
+        // the 256-wide tiles read the residual in the epilogue, unprefetched: not for the short-K (HBM-bound) residual layers. From 18 K slices on
+        // (a 3 x 3 layer of >= 128 channels: the data gradients of fpn_output2/3 with their ReLU-mask / gradient-sum epilogues) the epilogue is
+        // a few per cent of the tile and the 256 x 256 8-phase loop wins (round 5: fpn_output2's dgrad 1.65 -> 1.2 ms)
+        if (res && !c.pre_res && nk < 18) continue;
         if (c.two && nk < 2) continue;
         const long long tiles = (a.M + c.bm - 1) / c.bm * ((cout + c.bn - 1) / c.bn), slots = 256ll * c.occ;
         const long long full = tiles / slots, rem = tiles % slots;

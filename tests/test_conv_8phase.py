@@ -74,6 +74,29 @@ def test_8phase_matches_torch_and_the_128_tile_kernel(osr, ops, case, dtype):
         assert (y32.view(-1, cout)[rows.to(DEV)].double() - r64).abs().max().item() <= 1e-4 * max(1.0, r64.abs().max().item())
 
 
+def test_8phase_residual_epilogues_on_deep_k_layers(osr, ops):
+    """From 18 K slices on a residual layer may take the 256 x 256 tile (the data gradients of the 3 x 3 FPN output convolutions: ReLU mask
+    of the layer below = res_mode 3, gradient sum = res_mode 1, osr_conv2d_fwd_masked's post-mask): the epilogue reads the residual
+    unprefetched; results equal the 128-row kernel's, which prefetches it under the K loop."""
+    n, h, w, c, k = 4, 100, 168, 256, 3
+    g = torch.Generator().manual_seed(31)
+    x = (torch.randn(n, h, w, c, generator=g) * 0.5).half().to(DEV)
+    wt = (torch.randn(c, k, k, c, generator=g) / 48).half().to(DEV)
+    b = torch.zeros(c, device=DEV)
+    res = torch.randn(n, h, w, c, generator=g).half().to(DEV)
+    mask = torch.randn(n, h, w, c, generator=g).half().to(DEV)
+    for mode in (1, 3):
+        pm = mask if mode == 1 else None  # (osr_conv2d_fwd_masked takes res_mode 0 / 1)
+        with ops.concurrent_streams(2):
+            big = ops.conv2d(x, wt, b, 1, 1, relu=False, residual=res, res_mode=mode, post_mask=pm)
+        small = ops.conv2d(x, wt, b, 1, 1, relu=False, residual=res, res_mode=mode, post_mask=pm)
+        torch.cuda.synchronize()
+        assert torch.equal(big, small), mode
+        y = F.conv2d(x.float().permute(0, 3, 1, 2), wt.float().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+        ref = torch.where(mask.float() > 0, y + res.float(), torch.zeros_like(y)) if mode == 1 else torch.where(res.float() > 0, y, torch.zeros_like(y))
+        assert (big.float() - ref).abs().max().item() <= 2e-2
+
+
 def test_8phase_ragged_row_lists_and_split_k_tail(osr, ops):
     """FC1 as the engine runs it: 16 padded lists of 4273 slots, tiles without a data row skipped; then the same layer with the
     partial last dispatch round cut along K (osr_conv2d_fwd + workspace): full rounds + split-K tail workgroups + reduce."""
