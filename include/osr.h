@@ -88,10 +88,6 @@ typedef struct osr_conv_params {
     int32_t row_seg_rows;          /* of row_seg_rows rows of which only the first row_seg_counts[s] carry data (a padded per-image
                                     * proposal list: the box head's FC layers). A tile of output rows without any such row is
                                     * skipped and its rows are left unwritten; all other rows are computed as usual. */
-    void* out2_planar16;           /* optional (may be null), out_dtype == in_dtype f16 / bf16, cout % 16 == 0: a second copy of the
-                                    * result in channel-slice-planar layout (n, cout / 16, ho, wo, 16), written from the same epilogue
-                                    * (osr_conv2d_fwd only; the input of osr_roi_align_fwd_tiled: a 16-channel slice of a run of
-                                    * pixels is then contiguous in memory). OSR_ERR_UNSUPPORTED outside the BK=64 kernel's envelope. */
 } osr_conv_params;
 
 /* Workspace with which osr_conv2d_fwd splits the tail round of this layer along K; 0 when the layer does not qualify (then a
@@ -297,31 +293,6 @@ osr_status osr_roi_align_fwd_ordered(const osr_pyramid* feats, int32_t feat_dtyp
                                      const int32_t* batch_idx, int64_t m, int32_t pooled, int32_t canonical_level,
                                      int32_t canonical_size, int32_t min_level, const int32_t* order,
                                      const int32_t* order_nvalid, void* out, int32_t out_dtype, void* stream);
-/* ---------------------------------------------------------------------------------------------------------
- * The same pooling, tile-centric (csrc/osr_roi_tiled.hip), for lists whose RoIs overlap many times over (the <= 4273 proposals per
- * image of inference, osrcnn_roi_heads.py:306): a workgroup stages a 50 x 96-pixel region of a level, 16 channels at a time, in
- * LDS ONCE and pools every RoI whose footprint lies inside it from there (x contraction on the matrix cores with fp16 hi + lo
- * weights, exact to 2^-22; fp32 accumulation) instead of every RoI re-reading its footprint through the vector memory pipe.
- * planes[l]: the level's features in channel-slice-planar layout (n, c / 16, h, w, 16), fp16 -- what osr_conv2d_fwd writes into
- * osr_conv_params.out2_planar16; feats supplies the geometry (h, w, scale, c; its data pointers are not read).
- * out rows are SLICE-MAJOR: out[roi][c / 16][ph][pw][c % 16] (a task writes 49 * 16 contiguous values per RoI); pooled must be 7.
- * RoIs outside the path's envelope (footprint wider than 64 columns or not inside one region, bins taller than 7 pixels, empty or
- * non-finite boxes) and padding rows (batch index -1) are NOT written: *rid_out (device, m int32, inside the workspace) holds
- * >= 0 for the rows this call pooled, -1 / -2 for those two kinds, and osr_roi_align_fwd_masked(skip = *rid_out, slice_major = 1)
- * completes the buffer with the wave-per-RoI kernel. workspace: osr_roi_align_tiled_workspace_bytes(feats, n, m) bytes, 16-byte
- * aligned. Numerics: within 1e-4 of the row maximum of osr_roi_align_fwd (summation order; 2^-22 weight rounding).
- * --------------------------------------------------------------------------------------------------------- */
-int64_t osr_roi_align_tiled_workspace_bytes(const osr_pyramid* feats, int32_t n, int64_t m);
-osr_status osr_roi_align_fwd_tiled(const osr_pyramid* feats, const void* const* planes, int32_t n, const float* boxes,
-                                   const int32_t* batch_idx, int64_t m, int32_t pooled, int32_t canonical_level,
-                                   int32_t canonical_size, int32_t min_level, void* out, int32_t out_dtype, int32_t** rid_out,
-                                   void* workspace, int64_t workspace_bytes, void* stream);
-/* osr_roi_align_fwd (list order) restricted to the rows with skip[r] < 0 (padding rows are zero-filled as always); slice_major 1
- * writes the row layout of osr_roi_align_fwd_tiled (c % 16 == 0), 0 the usual out[r][ph][pw][c]. */
-osr_status osr_roi_align_fwd_masked(const osr_pyramid* feats, int32_t feat_dtype, int32_t n, const float* boxes,
-                                    const int32_t* batch_idx, int64_t m, int32_t pooled, int32_t canonical_level,
-                                    int32_t canonical_size, int32_t min_level, const int32_t* skip, int32_t slice_major,
-                                    void* out, int32_t out_dtype, void* stream);
 /* osr_roi_align_fwd_ordered with flags. OSR_ROI_NO_PADDING_FILL: padding rows (batch index -1) are left UNWRITTEN instead of
  * zero-filled -- for a caller whose consumers never read them (the engine: the box head skips or ignores those rows; a fifth of the
  * benchmark's list, 0.37 GB of zeros per step). */

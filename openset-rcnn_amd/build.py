@@ -28,7 +28,6 @@ SOURCES = {
     "osr_stem_pool.hip": [],
     "osr_rpn.hip": ["-ffp-contract=off"],
     "osr_roi_align.hip": ["-ffp-contract=off"],
-    "osr_roi_tiled.hip": ["-ffp-contract=off"],
     "osr_det_tail.hip": ["-ffp-contract=off"],
     "osr_train_fwd.hip": ["-ffp-contract=off"],
     "osr_rpn_sparse.hip": ["-ffp-contract=off"],

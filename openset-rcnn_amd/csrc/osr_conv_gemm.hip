@@ -297,8 +297,6 @@ static osr_status conv2d_fwd_impl(const osr_conv_params* p, const void* in, cons
     OSR_REQUIRE(!(f32_mode && masked), OSR_ERR_UNSUPPORTED, "osr_conv2d_fwd_masked: f16/bf16 only");
     OSR_REQUIRE(p->res_mode >= 0 && p->res_mode <= 3 && (p->res_mode == 0 || residual), OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: bad res_mode / residual");
     OSR_REQUIRE(p->pad_mode == 0 || p->pad_mode == 1, OSR_ERR_INVALID_ARG, "osr_conv2d_fwd: bad pad_mode");
-    OSR_REQUIRE(!p->out2_planar16 || (!f32_mode && p->cout % 16 == 0 && (((uintptr_t)p->out2_planar16) & 15) == 0 && p->out_dtype == p->in_dtype),
-                OSR_ERR_UNSUPPORTED, "osr_conv2d_fwd: out2_planar16 needs f16 / bf16 storage, cout %% 16 == 0 and a 16-byte aligned pointer");
     if (p->pad_mode == 0) {
         // the computed output size must agree with the convolution arithmetic, so that every tap index the kernel
         // forms is either inside [0,hi)x[0,wi) or rejected by the bounds check
@@ -334,10 +332,6 @@ static osr_status conv2d_fwd_impl(const osr_conv_params* p, const void* in, cons
         const long long in_bytes = in_elems * 2, w_bytes = (long long)p->cout * K * 2;
         if (!force_bk32() && osr_conv64_eligible(p, in_bytes, w_bytes))
             return osr_conv64_run(p, in, weight, bias, residual, masked ? mask : nullptr, out, in_bytes, w_bytes, st);
-    }
-    if (p->out2_planar16) {
-        osr_set_error("osr_conv2d_fwd: out2_planar16 needs the BK=64 kernel (f16 / bf16, cin %% 64 == 0) and cout %% 16 == 0");
-        return OSR_ERR_UNSUPPORTED;
     }
     if (masked) {
         osr_set_error("osr_conv2d_fwd_masked: outside the BK=64 kernel's envelope (cin %% 64 != 0 or tensor too large)");

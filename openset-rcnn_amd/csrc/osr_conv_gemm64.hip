@@ -917,9 +917,6 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
                         for (int e = 0; e < 8; ++e) v[e] = (float)mv[e] > 0.f ? v[e] : 0.f;
                     }
                     store8_64<TO>(out + (long long)nimg * p.out_stride_n + (long long)oh * p.out_stride_h + (long long)ow * p.out_stride_w + co, v);
-                    if (EPI == 0 && SPLIT == 0 && p.out2_planar16)  // second copy, (n, cout / 16, ho, wo, 16): the tiled RoIAlign's input (osr_roi_tiled.hip)
-                        store8_64<TO>(reinterpret_cast<TO*>(p.out2_planar16) +
-                                      ((((long long)nimg * (p.cout >> 4) + (co >> 4)) * p.ho + oh) * p.wo + ow) * 16 + (co & 15), v);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -1099,7 +1096,7 @@ static osr_status conv64_launch(Conv64Args& a, hipStream_t st) {
     a.tail_lds_off = 0;
     a.tile0 = 0; a.ntile = 0; a.ksplit = 1; a.split_stride = 0;
     SplitPlan sp;
-    if (a.p.workspace && !a.p.out2_planar16 && conv64_plan_split(a, &sp) && a.p.workspace_bytes >= sp.ws_bytes && (((uintptr_t)a.p.workspace) & 15) == 0) {
+    if (a.p.workspace && conv64_plan_split(a, &sp) && a.p.workspace_bytes >= sp.ws_bytes && (((uintptr_t)a.p.workspace) & 15) == 0) {
         const TileCfg* c = nullptr;
         for (const TileCfg& k : kTileCfgs) if (k.id == sp.tile_id) c = &k;
         const int tiles_m = (int)((a.M + c->bm - 1) / c->bm), tiles_n = (a.p.cout + c->bn - 1) / c->bn;

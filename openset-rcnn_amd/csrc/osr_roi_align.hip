@@ -48,8 +48,6 @@ struct RoiAlignArgs {
     void* out;
     const int* order;  // processing order of the RoIs (a permutation of 0..m-1) or null: the result does not depend on it
     const int* order_nvalid;  // (with order) how many leading entries of it are real RoIs, the rest padding rows; null: unknown
-    const int* skip;   // optional (osr_roi_align_fwd_masked): RoI r is left alone when skip[r] >= 0 (the tiled kernel has pooled it)
-    int slice_major;   // 0: out[r][ph][pw][c]; 1: out[r][c / 16][ph][pw][c % 16] (the tiled kernel's row layout, osr_roi_tiled.hip)
     int no_pad_fill;   // 1: padding rows (batch index < 0) are left unwritten instead of zero-filled (osr_roi_align_fwd_ordered_ex)
 };
 
@@ -475,13 +473,10 @@ __global__ __launch_bounds__(RA_THREADS, RA_MINW) void roi_align_kernel(RoiAlign
     }
     if (r >= a.m) return;
     if (a.order) r = a.order[r];
-    if (a.skip && a.skip[r] >= 0) return;
     RaWaveLds& S = s_all[grp];
     const int P = a.pooled, C = a.c;
-    // element stride between two bins of a row and the offset of channel c0 inside the row (c0 is a multiple of 4 or 8: it never
-    // straddles a 16-channel slice)
-    const int CE = a.slice_major ? 16 : C;
-#define RA_CBASE(c0) (a.slice_major ? (size_t)((c0) >> 4) * P * P * 16 + ((c0) & 15) : (size_t)(c0))
+    const int CE = C;  // element stride between two bins of a row
+#define RA_CBASE(c0) ((size_t)(c0))
     TO* out = reinterpret_cast<TO*>(a.out) + (size_t)r * P * P * C;
 
     const int b = a.batch_idx[r];
@@ -704,8 +699,7 @@ static osr_status launch_out(const RoiAlignArgs& a, int out_dtype, hipStream_t s
 static osr_status roi_align_fwd_impl(const osr_pyramid* f, int32_t feat_dtype, int32_t n, const float* boxes,
                                      const int32_t* batch_idx, int64_t m, int32_t pooled, int32_t canonical_level,
                                      int32_t canonical_size, int32_t min_level, const int32_t* order,
-                                     const int32_t* order_nvalid, const int32_t* skip, int32_t slice_major, void* out, int32_t out_dtype, void* stream,
-                                     int32_t flags = 0) {
+                                     const int32_t* order_nvalid, void* out, int32_t out_dtype, void* stream, int32_t flags = 0) {
     OSR_REQUIRE(f && boxes && batch_idx && out, OSR_ERR_INVALID_ARG, "osr_roi_align_fwd: null pointer");
     OSR_REQUIRE(f->num_levels >= 1 && f->num_levels <= 4, OSR_ERR_INVALID_ARG, "osr_roi_align_fwd: 1..4 levels, got %d", f->num_levels);
     OSR_REQUIRE(pooled >= 1 && pooled <= 7, OSR_ERR_UNSUPPORTED, "osr_roi_align_fwd: pooled size 1..7, got %d", pooled);
@@ -723,8 +717,7 @@ static osr_status roi_align_fwd_impl(const osr_pyramid* f, int32_t feat_dtype, i
     a.num_levels = f->num_levels; a.c = f->c; a.boxes = boxes; a.batch_idx = batch_idx; a.m = m;
     a.pooled = pooled; a.canonical_level = canonical_level; a.canonical_size = canonical_size; a.min_level = min_level;
     a.out = out; a.order = order; a.order_nvalid = order ? order_nvalid : nullptr;
-    a.skip = skip; a.slice_major = slice_major; a.no_pad_fill = (flags & OSR_ROI_NO_PADDING_FILL) ? 1 : 0;
-    OSR_REQUIRE(!slice_major || f->c % 16 == 0, OSR_ERR_UNSUPPORTED, "osr_roi_align_fwd: the slice-major row layout needs channels % 16 == 0, got %d", f->c);
+    a.no_pad_fill = (flags & OSR_ROI_NO_PADDING_FILL) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     switch (feat_dtype) {
         case OSR_F32: return launch_out<float>(a, out_dtype, st);
@@ -738,7 +731,7 @@ extern "C" osr_status osr_roi_align_fwd_ordered(const osr_pyramid* f, int32_t fe
                                                 int32_t canonical_size, int32_t min_level, const int32_t* order,
                                                 const int32_t* order_nvalid, void* out, int32_t out_dtype, void* stream) {
     return roi_align_fwd_impl(f, feat_dtype, n, boxes, batch_idx, m, pooled, canonical_level, canonical_size, min_level, order, order_nvalid,
-                              nullptr, 0, out, out_dtype, stream);
+                              out, out_dtype, stream);
 }
 
 extern "C" osr_status osr_roi_align_fwd_ordered_ex(const osr_pyramid* f, int32_t feat_dtype, int32_t n, const float* boxes,
@@ -747,18 +740,7 @@ extern "C" osr_status osr_roi_align_fwd_ordered_ex(const osr_pyramid* f, int32_t
                                                    const int32_t* order_nvalid, int32_t flags, void* out, int32_t out_dtype, void* stream) {
     OSR_REQUIRE((flags & ~OSR_ROI_NO_PADDING_FILL) == 0, OSR_ERR_INVALID_ARG, "osr_roi_align_fwd_ordered_ex: unknown flag bits 0x%x", flags);
     return roi_align_fwd_impl(f, feat_dtype, n, boxes, batch_idx, m, pooled, canonical_level, canonical_size, min_level, order, order_nvalid,
-                              nullptr, 0, out, out_dtype, stream, flags);
-}
-
-// The wave-per-RoI kernel for the RoIs the tiled kernel left (skip[r] < 0: -1 = not on its path, -2 = padding row, zero-filled
-// here), writing the tiled kernel's slice-major rows into the same buffer.
-extern "C" osr_status osr_roi_align_fwd_masked(const osr_pyramid* f, int32_t feat_dtype, int32_t n, const float* boxes,
-                                               const int32_t* batch_idx, int64_t m, int32_t pooled, int32_t canonical_level,
-                                               int32_t canonical_size, int32_t min_level, const int32_t* skip, int32_t slice_major,
-                                               void* out, int32_t out_dtype, void* stream) {
-    OSR_REQUIRE(skip, OSR_ERR_INVALID_ARG, "osr_roi_align_fwd_masked: null pointer");
-    return roi_align_fwd_impl(f, feat_dtype, n, boxes, batch_idx, m, pooled, canonical_level, canonical_size, min_level, nullptr, nullptr,
-                              skip, slice_major, out, out_dtype, stream);
+                              out, out_dtype, stream, flags);
 }
 
 extern "C" osr_status osr_roi_align_fwd(const osr_pyramid* f, int32_t feat_dtype, int32_t n, const float* boxes,

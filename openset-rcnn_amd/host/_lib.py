@@ -35,7 +35,6 @@ class ConvParams(C.Structure):
         ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("concurrency", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("row_seg_counts", C.c_void_p), ("row_seg_rows", C.c_int32),
-        ("out2_planar16", C.c_void_p),
     ]
 
 
@@ -114,9 +113,6 @@ PROTOTYPES = {
     "osr_roi_align_fwd": (I32, [C.POINTER(Pyramid), I32, I32, P, P, I64, I32, I32, I32, I32, P, I32, P]),
     "osr_roi_align_fwd_ordered": (I32, [C.POINTER(Pyramid), I32, I32, P, P, I64, I32, I32, I32, I32, P, P, P, I32, P]),
     "osr_roi_align_fwd_ordered_ex": (I32, [C.POINTER(Pyramid), I32, I32, P, P, I64, I32, I32, I32, I32, P, P, I32, P, I32, P]),
-    "osr_roi_align_tiled_workspace_bytes": (I64, [C.POINTER(Pyramid), I32, I64]),
-    "osr_roi_align_fwd_tiled": (I32, [C.POINTER(Pyramid), P, I32, P, P, I64, I32, I32, I32, I32, P, I32, P, P, I64, P]),
-    "osr_roi_align_fwd_masked": (I32, [C.POINTER(Pyramid), I32, I32, P, P, I64, I32, I32, I32, I32, P, I32, P, I32, P]),
     "osr_roi_locality_order_workspace_bytes": (I64, [I32, I64]),
     "osr_roi_locality_order": (I32, [C.POINTER(Pyramid), I32, P, P, I64, I32, I32, I32, P, P, P, I64, P]),
     "osr_box_predictor_tail": (I32, [P, I64, I32, P, P, P, P, P, P, C.POINTER(C.c_float), I32, F32, P, P, P, P, P, P]),

@@ -75,8 +75,7 @@ class OpensetRCNNEngine:
     FP32_POINTS = ("backbone", "rpn_hidden", "pooled", "h1")
 
     def __init__(self, params: Dict[str, torch.Tensor], cfg: Optional[dict] = None, dtype: torch.dtype = torch.float16,
-                 device: str = "cuda", class_map: Optional[torch.Tensor] = None, fp32_points: Sequence[str] = (),
-                 tiled_roi: Optional[bool] = None):
+                 device: str = "cuda", class_map: Optional[torch.Tensor] = None, fp32_points: Sequence[str] = ()):
         """fp32_points (diagnostic; fast mode only): storage points of the fp16 path kept in fp32 instead, to measure what each one
         costs in agreement with the fp32 reference (tests/test_e2e_parity.py): "backbone" (stem .. FPN outputs computed by the
         fp32 kernels, the pyramid handed on in fp16), "rpn_hidden" (the CF-RPN hidden state: un-fused head, fp32 t), "pooled"
@@ -118,14 +117,6 @@ class OpensetRCNNEngine:
         self.chain_res3 = dtype != torch.float32
         # the stem's convolution, ReLU and max pool run as ONE launch (osr_stem_maxpool_fwd): fp16 / bf16 storage only
         self.fuse_stem = dtype != torch.float32
-        # RoIAlign tile-centric (ops.roi_align_tiled: regions of the pyramid staged once in LDS, x contraction on the matrix cores):
-        # OFF by default -- built, parity-green and measured SLOWER than the wave-per-RoI kernel on the benchmark's proposals (2.4 ms
-        # against 1.3 ms). fp16 storage only. It reads a channel-slice-planar copy of p2..p5 that the FPN output
-        # convolutions write beside the NHWC tensors, and hands FC1 SLICE-MAJOR rows, so fc1's K axis is packed in that order
-        # (pack_fc1_weight(slice_major=16)). The trainer always keeps the wave-per-RoI kernel and the (ph, pw, c) order its backward
-        # kernels read.
-        self.tiled_roi = bool(tiled_roi)
-        assert not self.tiled_roi or (dtype == torch.float16 and not self.fp32_points), "tiled RoIAlign: fp16 storage"
         self._init_rpn(params)
         self._init_roi_heads(params)
 
@@ -170,8 +161,7 @@ class OpensetRCNNEngine:
             return
         fc1_dt = torch.float32 if "pooled" in self.fp32_points else dtype
         fc2_dt = torch.float32 if "h1" in self.fp32_points else dtype
-        self.fc1_w = pack_fc1_weight(params["roi_heads.box_head.fc1.weight"], 256, c["pooler_resolution"], fc1_dt,
-                                     slice_major=16 if self.tiled_roi else 0).to(dev)
+        self.fc1_w = pack_fc1_weight(params["roi_heads.box_head.fc1.weight"], 256, c["pooler_resolution"], fc1_dt).to(dev)
         self.fc1_b = params["roi_heads.box_head.fc1.bias"].float().to(dev)
         self.fc2_w = params["roi_heads.box_head.fc2.weight"].to(fc2_dt).contiguous().to(dev)
         self.fc2_b = params["roi_heads.box_head.fc2.bias"].float().to(dev)
@@ -183,18 +173,17 @@ class OpensetRCNNEngine:
         self.cls_w, self.cls_b = f32("roi_heads.softmaxcls.cls_score.weight"), f32("roi_heads.softmaxcls.cls_score.bias")
 
     # ---- backbone -------------------------------------------------------------------------------------------
-    def _conv(self, x, name, stride=1, pad=0, relu=False, residual=None, res_mode=0, out=None, out_dtype=None, planes_out=None):
+    def _conv(self, x, name, stride=1, pad=0, relu=False, residual=None, res_mode=0, out=None, out_dtype=None):
         w = self.w[name + ".w"]
         if self.profile is None:
-            return ops.conv2d(x, w, self.w[name + ".b"], stride, pad, relu, residual, res_mode, out_dtype, out, planes_out=planes_out)
+            return ops.conv2d(x, w, self.w[name + ".b"], stride, pad, relu, residual, res_mode, out_dtype, out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        y = ops.conv2d(x, w, self.w[name + ".b"], stride, pad, relu, residual, res_mode, out_dtype, out, planes_out=planes_out)
+        y = ops.conv2d(x, w, self.w[name + ".b"], stride, pad, relu, residual, res_mode, out_dtype, out)
         e1.record()
         rows = y.numel() // w.shape[0]
         nbytes = x.numel() * x.element_size() + w.numel() * w.element_size() + y.numel() * y.element_size() + \
-            (residual.numel() * residual.element_size() if residual is not None else 0) + \
-            (planes_out.numel() * planes_out.element_size() if planes_out is not None else 0)
+            (residual.numel() * residual.element_size() if residual is not None else 0)
         flops = 2.0 * rows * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3]
         self.profile.append((name, flops, e0, e1, nbytes, flops))
         return y
@@ -290,44 +279,29 @@ class OpensetRCNNEngine:
             feats[f"res{si + 2}"] = x
         out = {}
 
-        def planes_of(t):  # the planar copy of a pyramid level, written by its output convolution's epilogue (tiled RoIAlign)
-            return torch.empty((t.shape[0], 256 // 16, t.shape[1], t.shape[2], 16), dtype=self.dtype, device=self.device) if self.tiled_roi else None
         prev = self._conv(feats["res5"], "backbone.fpn_lateral5")
-        pl = planes_of(prev)
-        out["p5"] = self._conv(prev, "backbone.fpn_output5", 1, 1, planes_out=pl)
-        if pl is not None:
-            out["p5_planes"] = pl
+        out["p5"] = self._conv(prev, "backbone.fpn_output5", 1, 1)
         for lvl in (4, 3, 2):
             prev = self._conv(feats[f"res{lvl}"], f"backbone.fpn_lateral{lvl}", residual=prev, res_mode=2)
-            pl = planes_of(prev)
-            out[f"p{lvl}"] = self._conv(prev, f"backbone.fpn_output{lvl}", 1, 1, planes_out=pl)
-            if pl is not None:
-                out[f"p{lvl}_planes"] = pl
+            out[f"p{lvl}"] = self._conv(prev, f"backbone.fpn_output{lvl}", 1, 1)
         out["p6"] = ops.subsample2(out["p5"])
         if keep is not None:
             keep.update(feats)
         return out
 
     def pool_rois(self, feats: Dict[str, torch.Tensor], boxes: torch.Tensor, batch_idx: torch.Tensor, out_dtype=None, fill_padding: bool = True) -> torch.Tensor:
-        """[d2] ROIPooler + torchvision roi_align on p2..p5 (osrcnn_roi_heads.py:306) -> (m, 49 * 256) rows in the K order self.fc1_w is
-        packed in: the tiled kernel's slice-major rows (planar copies of the levels from the backbone, or made here when the
-        pyramid came from elsewhere), or the wave-per-RoI kernel's (ph, pw, c) rows."""
+        """[d2] ROIPooler + torchvision roi_align on p2..p5 (osrcnn_roi_heads.py:306) -> (m, 49 * 256) rows in (ph, pw, c) order, the K
+        order self.fc1_w is packed in."""
         c = self.cfg
         fl = [feats[k] for k in ("p2", "p3", "p4", "p5")]
-        if self.tiled_roi:
-            pl = [feats[k + "_planes"] if k + "_planes" in feats else ops.to_planes(feats[k]) for k in ("p2", "p3", "p4", "p5")]
-            pooled = ops.roi_align_tiled(fl, pl, c["pooler_scales"], boxes, batch_idx, c["pooler_resolution"], out_dtype or self.dtype,
-                                         c["canonical_level"], c["canonical_size"], 2)
-        else:
-            pooled = ops.roi_align(fl, c["pooler_scales"], boxes, batch_idx, c["pooler_resolution"], out_dtype or self.dtype,
-                                   c["canonical_level"], c["canonical_size"], 2, fill_padding=fill_padding)
+        pooled = ops.roi_align(fl, c["pooler_scales"], boxes, batch_idx, c["pooler_resolution"], out_dtype or self.dtype,
+                               c["canonical_level"], c["canonical_size"], 2, fill_padding=fill_padding)
         return pooled.view(pooled.shape[0], -1)
 
     def pooled_bin_major(self, pooled: torch.Tensor) -> torch.Tensor:
-        """pool_rois' rows as (m, 7, 7, 256) whatever their K order (a view, or a permuted copy of slice-major rows): what `keep`
-        hands to tests and diagnostics."""
+        """pool_rois' rows as (m, 7, 7, 256): what `keep` hands to tests and diagnostics."""
         m, P = pooled.shape[0], self.cfg["pooler_resolution"]
-        return ops.slice_major_to_bin_major(pooled, 256, P) if self.tiled_roi else pooled.view(m, P, P, 256)
+        return pooled.view(m, P, P, 256)
 
     def _rpn_level_fused(self, f, deltas, ctr, hidden=None):
         w, b = self.w["proposal_generator.rpn_head.conv.w"], self.w["proposal_generator.rpn_head.conv.b"]

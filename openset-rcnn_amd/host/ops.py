@@ -91,10 +91,8 @@ def _new_conv_params() -> "ConvParams":
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, stride: int = 1, pad: int = 0, relu: bool = False,
            residual: Optional[torch.Tensor] = None, res_mode: int = 0, out_dtype: Optional[torch.dtype] = None,
            out: Optional[torch.Tensor] = None, post_mask: Optional[torch.Tensor] = None,
-           row_seg: Optional[Tuple[torch.Tensor, int]] = None, planes_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+           row_seg: Optional[Tuple[torch.Tensor, int]] = None) -> torch.Tensor:
     """NHWC implicit-GEMM convolution. x (n,h,w,cin) f16/bf16; weight (cout,kh,kw,cin) same dtype; bias f32.
-    planes_out (n, cout/16, ho, wo, 16), out's dtype: receives a second copy of the result in channel-slice-planar layout from the
-    same launch (osr_conv_params.out2_planar16: the input layout of roi_align_tiled).
     post_mask (n,ho,wo,cout), x's dtype: the result is zeroed where post_mask <= 0, in the same launch
     (osr_conv2d_fwd_masked; needs cin % 64 == 0, else the mask is applied by a second launch).
     row_seg = (counts int32 (s,), rows per segment): the output rows are s segments of which only the first counts[i] rows carry
@@ -144,13 +142,8 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, stride: in
         if st != _lib.ERR_UNSUPPORTED:
             check(st, "osr_conv2d_fwd_masked")
             return out
-    if planes_out is not None:
-        _need(planes_out, out_dtype, "planes_out")
-        if post_mask is not None or tuple(planes_out.shape) != (n, cout // 16, ho, wo, 16) or cout % 16:
-            raise OsrError(f"planes_out: expected shape {(n, cout // 16, ho, wo, 16)}, no post_mask")
-        p.out2_planar16 = planes_out.data_ptr()
     ws = None
-    if SPLIT_K_TAIL and post_mask is None and res_mode == 0 and stride == 1 and planes_out is None:
+    if SPLIT_K_TAIL and post_mask is None and res_mode == 0 and stride == 1:
         wsb = int(lib.osr_conv2d_fwd_workspace_bytes(C.byref(p)))  # > 0: a deep-K 1x1 / FC layer whose last dispatch round is mostly empty
         if wsb > 0:
             ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
@@ -557,54 +550,6 @@ def roi_align(feats: List[torch.Tensor], scales: Sequence[float], boxes: torch.T
     check(lib.osr_roi_align_fwd_ordered_ex(C.byref(py), _DT[feats[0].dtype], feats[0].shape[0], _p(boxes), _p(batch_idx), m, pooled,
                                            canonical_level, canonical_size, min_level, _p(order), nvalid, 0 if fill_padding else 1, _p(out),
                                            _DT[out_dtype], _stream()), "osr_roi_align_fwd")
-    return out
-
-
-def to_planes(f: torch.Tensor) -> torch.Tensor:
-    """(n, h, w, c) NHWC -> (n, c/16, h, w, 16): the channel-slice-planar layout roi_align_tiled reads (a torch copy: tests and callers
-    whose pyramid does not come from conv2d(planes_out=...))."""
-    n, h, w, c = f.shape
-    return f.view(n, h, w, c // 16, 16).permute(0, 3, 1, 2, 4).contiguous()
-
-
-def slice_major_to_bin_major(pooled: torch.Tensor, c: int, p: int = 7) -> torch.Tensor:
-    """(m, c/16, p, p, 16) rows of roi_align_tiled -> (m, p, p, c)."""
-    m = pooled.shape[0]
-    return pooled.view(m, c // 16, p, p, 16).permute(0, 2, 3, 1, 4).reshape(m, p, p, c)
-
-
-def roi_align_tiled(feats: List[torch.Tensor], planes: List[torch.Tensor], scales: Sequence[float], boxes: torch.Tensor, batch_idx: torch.Tensor,
-                    pooled: int = 7, out_dtype: Optional[torch.dtype] = None, canonical_level: int = 4, canonical_size: int = 224,
-                    min_level: int = 2, return_rid: bool = False):
-    """Tile-centric RoIAlign (osr_roi_align_fwd_tiled + osr_roi_align_fwd_masked for the RoIs outside its envelope and the padding
-    rows). feats: NHWC per level (read by the second kernel only); planes: the same levels as (n, c/16, h, w, 16) fp16. Returns
-    (m, c/16, pooled, pooled, 16): SLICE-MAJOR rows (slice_major_to_bin_major gives the usual (m, p, p, c))."""
-    lib = _lib.load()
-    _need(boxes, torch.float32, "boxes"); _need(batch_idx, torch.int32, "batch_idx")
-    py = _pyramid(feats, scales)
-    if feats[0].dtype != torch.float16 or pooled != 7 or py.c % 16:
-        raise OsrError("roi_align_tiled: fp16 features, pooled size 7, channels % 16 == 0")
-    m, n = boxes.shape[0], feats[0].shape[0]
-    out_dtype = out_dtype or feats[0].dtype
-    pl = (C.c_void_p * len(planes))()
-    for i, (f, q) in enumerate(zip(feats, planes)):
-        _need(q, torch.float16, f"planes[{i}]")
-        if tuple(q.shape) != (n, py.c // 16, f.shape[1], f.shape[2], 16):
-            raise OsrError(f"planes[{i}]: shape {tuple(q.shape)} != {(n, py.c // 16, f.shape[1], f.shape[2], 16)}")
-        pl[i] = q.data_ptr()
-    out = torch.empty((m, py.c // 16, pooled, pooled, 16), dtype=out_dtype, device=boxes.device)
-    if m == 0:
-        return (out, torch.empty((0,), dtype=torch.int32, device=boxes.device)) if return_rid else out
-    wsb = int(lib.osr_roi_align_tiled_workspace_bytes(C.byref(py), n, m))
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=boxes.device)
-    rid = C.c_void_p()
-    check(lib.osr_roi_align_fwd_tiled(C.byref(py), pl, n, _p(boxes), _p(batch_idx), m, pooled, canonical_level, canonical_size, min_level,
-                                      _p(out), _DT[out_dtype], C.byref(rid), _p(ws), wsb, _stream()), "osr_roi_align_fwd_tiled")
-    check(lib.osr_roi_align_fwd_masked(C.byref(py), _DT[feats[0].dtype], n, _p(boxes), _p(batch_idx), m, pooled, canonical_level,
-                                       canonical_size, min_level, rid, 1, _p(out), _DT[out_dtype], _stream()), "osr_roi_align_fwd_masked")
-    if return_rid:  # (a view of the workspace: valid while `ws` lives -- copied)
-        off = rid.value - ws.data_ptr()
-        return out, ws[off:off + 4 * m].view(torch.int32).clone()
     return out
 
 

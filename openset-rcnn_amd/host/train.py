@@ -75,7 +75,7 @@ class DynamicLossScale:
         if self.cuda:
             ev = torch.cuda.Event()
             ev.record()
-        self.queue.append((ev, slot))
+        self.queue.append((ev, slot, self.scale))  # the scale this update was issued with
 
     def poll(self, wait: bool = False, lag: int = 0) -> bool:
         """True when at least one of the drained updates had been skipped. lag: leave the newest `lag` updates in the queue
@@ -83,7 +83,7 @@ class DynamicLossScale:
         a deterministic set (the same on every rank of a data-parallel job), while the host keeps `lag` iterations of run-ahead."""
         any_overflow = False
         while len(self.queue) > lag:
-            ev, slot = self.queue[0]
+            ev, slot, issued_scale = self.queue[0]
             if ev is not None:
                 if wait:
                     ev.synchronize()
@@ -103,7 +103,11 @@ class DynamicLossScale:
                 any_overflow = True
                 self.overflow_steps += 1
                 self.clean_steps = 0
-                self.scale = max(1.0, self.scale * 0.5)
+                # One back-off per overflow EPISODE (GradScaler's behaviour): with a verdict lag the updates issued between the overflow
+                # and its verdict ran at the same, too-large scale and overflow as well; they count as skipped steps but do not halve the
+                # scale again (it is already below the scale they were issued with).
+                if issued_scale <= self.scale:
+                    self.scale = max(1.0, self.scale * 0.5)
         return any_overflow
 
 
@@ -117,7 +121,7 @@ class OpensetRCNNTrainer:
         is the un-folded weight (weight decay acts on it, the chain rule multiplies the kernel's gradient by the scale)."""
         self.frozen_bn = frozen_bn or {}
         self.row_scale: Dict[str, torch.Tensor] = {}
-        self.eng = OpensetRCNNEngine(params, cfg, dtype, device, class_map, tiled_roi=False)  # (the backward reads (ph, pw, c) rows)
+        self.eng = OpensetRCNNEngine(params, cfg, dtype, device, class_map)
         # the CF-RPN head's backward runs on the sampled anchors only and recomputes their hidden state (osr_rpn_sparse.hip); False:
         # the dense launches of rounds 1-3 (the fused head kernel then also writes the hidden state of every anchor: 0.7 GB)
         self.sparse_rpn_bwd = True
@@ -185,7 +189,7 @@ class OpensetRCNNTrainer:
         self._sgd_plan = None
         self._pack_plan = None
         self._pre: Optional[torch.cuda.Stream] = None  # stream of the next batch's frozen prefix (_prefetch_frozen)
-        self._prefetched = None                        # (images, (hp, wp), x, event)
+        self._prefetched = None                        # (images, (hp, wp), (x, feats), event, images._version)
         # blocks whose weight gradients ride on the main stream (measured with res3.0 / res3.0-1 / all of res3: 25.4-25.5 against 25.5-25.7 ms,
         # inside the run-to-run spread: the backward is bound by the sum of its kernels, not by which stream ends last) -- left empty
         self.wgrad_on_main: set = set()
@@ -288,7 +292,7 @@ class OpensetRCNNTrainer:
                 rpn_targets = e.rpn_targets_forward(lv, n, gt_boxes, gt_count, keys)
                 targets_ready = self._side.record_event()
         pref, self._prefetched = self._prefetched, None
-        if pref is not None and pref[0] is images and pref[1] == (hp, wp):
+        if pref is not None and pref[0] is images and pref[1] == (hp, wp) and pref[4] == images._version:
             # the frozen prefix of THIS batch was computed under the previous iteration's backward (step(next_images=...)): take it
             x, frozen_feats = pref[2]
             cur.wait_event(pref[3])
@@ -384,7 +388,11 @@ class OpensetRCNNTrainer:
             done = self._pre.record_event()
         for t in [x] + list(feats.values()):
             t.record_stream(cur)
-        self._prefetched = (images, (hp, wp), (x, feats), done)
+        images.record_stream(self._pre)  # (the caching allocator must not hand the batch's memory out while the side stream reads it)
+        # Keyed on the tensor OBJECT and its version counter: a loader that refills one device buffer in place hands the same object with
+        # a bumped version (recompute); next_images must not be written again before the step that consumes it. load_state_dict /
+        # set_freeze_at drop the prefetch (the prefix is a function of the frozen weights).
+        self._prefetched = (images, (hp, wp), (x, feats), done, images._version)
 
     # ---- backward -------------------------------------------------------------------------------------------------
     def _f32_linear_bwd(self, x, dy, wt, name, dy_pad=None):
@@ -467,7 +475,11 @@ class OpensetRCNNTrainer:
                 # gradient as three small GEMMs; the dense launches spent 2 x 1.7 TFLOP on zeros
                 lvl_keys = ("p2", "p3", "p4", "p5", "p6")
                 cap = n * 2 * int(c["rpn_batch_size"])
-                ids, rmap, _ = ops.rpn_sparse_rows(d5, cap)
+                ids, rmap, cnt2 = ops.rpn_sparse_rows(d5, cap)
+                # count2 = {listed, found}: rows beyond the cap are dropped by the list (the reference sampler bounds them by 2 x 256 per image;
+                # another sampler, or NaN spilling into unsampled rows, could exceed it). _update() skips the iteration's update when that
+                # happened, like a gradient overflow, instead of applying an update that misses the coarsest levels' gradients
+                self._sparse_rows_fit = (cnt2[1:2] <= cap).to(torch.int32)
                 cols, d5r = ops.rpn_gather_cols(sel["levels"], [p[k_] for k_ in lvl_keys], n, ids, d5)
                 w3 = e.w[rn + ".w"].view(256, 9 * 256)
                 t_rows = ops.linear(cols, w3, e.w[rn + ".b"], relu=True)
@@ -634,6 +646,10 @@ class OpensetRCNNTrainer:
         gs = 1.0 / (getattr(self, "_scale_used", self.loss_scale) * world)
         self._ok.fill_(1)
         ops.check_finite_(self.grad_flat, self._ok)
+        fit = getattr(self, "_sparse_rows_fit", None)
+        if fit is not None:  # the sparse CF-RPN backward listed every row with a gradient (see rpn_chain); else: skip, counted with the overflows
+            self._ok.mul_(fit)
+            self._sparse_rows_fit = None
         if self.multi_tensor_update:
             # every parameter tensor in ONE launch (osr_sgd_step_multi over a device-resident table), then every backward-data weight in
             # one more (_refresh_derived): ~145 launches of a few microseconds of work each became two; same bits per element
@@ -684,7 +700,12 @@ class OpensetRCNNTrainer:
     def export_optimizer_state(self) -> Dict[str, torch.Tensor]:
         """Momentum buffers (CPU copies) for a checkpoint that is resumed exactly ([d2] checkpoints carry the optimizer state)."""
         out = {k: v.detach().cpu().clone() for k, v in self.mom.items()}
-        self.poll_overflow(wait=True)  # every issued update's verdict is in the scale that is written
+        # One rank: every issued update's verdict goes into the scale that is written. Several ranks: the queue is left ALONE -- the ranks apply
+        # verdicts in lockstep inside step() (MULTI_RANK_LAG), and a drain here, on whichever ranks happen to write a checkpoint, would change
+        # one rank's scale 2-3 steps before its peers' (different scales multiplied into the same all-reduce). A collective checkpoint
+        # writer that wants the newest verdicts in the file calls poll_overflow(wait=True) on EVERY rank first (run_net.save_checkpoint).
+        if not parallel.is_dist():
+            self.poll_overflow(wait=True)
         out[self.SCALE_KEY] = torch.tensor([self.scaler.scale, float(self.scaler.clean_steps), float(self.scaler.overflow_steps), self.scaler.scale_max],
                                            dtype=torch.float64)
         return out

@@ -97,12 +97,9 @@ def pack_stem_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return v.view(cout, 8, 1, 32).contiguous().to(dtype)
 
 
-def pack_fc1_weight(w: torch.Tensor, channels: int, pooled: int, dtype: torch.dtype, slice_major: int = 0) -> torch.Tensor:
-    """fc1 (out, c*p*p) with the reference's (c,ph,pw) flatten order -> (out, p*p*c) matching RoIAlign's (ph,pw,c) output.
-    slice_major = 16: the K order of the tiled RoIAlign's rows instead, (c / 16, ph, pw, c % 16) (ops.roi_align_tiled)."""
+def pack_fc1_weight(w: torch.Tensor, channels: int, pooled: int, dtype: torch.dtype) -> torch.Tensor:
+    """fc1 (out, c*p*p) with the reference's (c,ph,pw) flatten order -> (out, p*p*c) matching RoIAlign's (ph,pw,c) output."""
     o = w.shape[0]
-    if slice_major:
-        return w.view(o, channels // slice_major, slice_major, pooled, pooled).permute(0, 1, 3, 4, 2).reshape(o, pooled * pooled * channels).contiguous().to(dtype)
     return w.view(o, channels, pooled, pooled).permute(0, 2, 3, 1).reshape(o, pooled * pooled * channels).contiguous().to(dtype)
 
 

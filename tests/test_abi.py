@@ -39,7 +39,7 @@ def test_binding_covers_header(osr):
 
 def test_struct_layouts_match_header(osr):
     L = osr._lib
-    assert ctypes.sizeof(L.ConvParams) == 13 * 4 + 4 + 9 * 8 + 6 * 4 + 8 + 8 + 8 + 8 + 8  # (+ out2_planar16) 13 int32 (+4 pad) + 9 int64 + 6 int32 + workspace pointer + its size + row_seg_counts + row_seg_rows (+4 pad)
+    assert ctypes.sizeof(L.ConvParams) == 13 * 4 + 4 + 9 * 8 + 6 * 4 + 8 + 8 + 8 + 8  # 13 int32 (+4 pad) + 9 int64 + 6 int32 + workspace pointer + its size + row_seg_counts + row_seg_rows (+4 pad)
     assert ctypes.sizeof(L.RpnLevels) == 8 + 3 * 8 * 4 + 8 * 8
     assert ctypes.sizeof(L.Pyramid) == 8 + 3 * 8 * 4 + 8 * 8
     assert ctypes.sizeof(L.BottleneckParams) == 8 * 4

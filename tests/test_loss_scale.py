@@ -17,10 +17,15 @@ def test_no_verdict_is_lost_when_the_host_runs_ahead(osr):
     assert sc.poll() is True
     assert sc.scale == 512.0 and sc.overflow_steps == 1 and sc.clean_steps == 1
     assert sc.poll() is False and sc.scale == 512.0  # reported once
-    # three more, two of them poisoned
+    # three more, two of them poisoned, all ISSUED at 512 before any of their verdicts was read: one overflow episode, one back-off
+    # (GradScaler's behaviour; the updates issued between an overflow and its verdict ran at the same, too-large scale)
     for ok in (False, True, False):
         sc.record(_flag(ok))
-    assert sc.poll(wait=True) is True and sc.scale == 128.0 and sc.overflow_steps == 3
+    assert sc.poll(wait=True) is True and sc.scale == 256.0 and sc.overflow_steps == 3
+    # an overflow issued AT the backed-off scale is a new episode
+    sc.record(_flag(False))
+    assert sc.poll(wait=True) is True and sc.scale == 128.0 and sc.overflow_steps == 4
+    sc.poll()
     # the pinned slots are recycled, not re-allocated per update
     assert len(sc.free) == 3 and not sc.queue
 
@@ -29,6 +34,7 @@ def test_scale_grows_back_after_clean_updates_and_stops_at_the_configured_scale(
     from openset_rcnn_amd.host.train import DynamicLossScale
     sc = DynamicLossScale(1024.0, growth_interval=4)
     sc.record(_flag(False))
+    sc.poll()
     sc.record(_flag(False))
     sc.poll()
     assert sc.scale == 256.0
@@ -55,7 +61,7 @@ def test_floor_of_the_scale(osr):
     sc = DynamicLossScale(2.0, growth_interval=0)
     for _ in range(3):
         sc.record(_flag(False))
-    sc.poll()
+        sc.poll()
     assert sc.scale == 1.0 and sc.overflow_steps == 3
 
 
@@ -87,5 +93,9 @@ def test_lagged_poll_applies_a_deterministic_set_of_verdicts(osr):
     assert sc.scale == 512.0 and sc.overflow_steps == 1 and len(sc.queue) == 2
     assert sc.poll(wait=True, lag=2) is False         # nothing older than the newest two
     sc.record(_flag(True))
-    assert sc.poll(wait=True, lag=2) is True and sc.scale == 256.0 and len(sc.queue) == 2  # update 2 (overflowed) is now old enough
+    # update 2 (overflowed) is now old enough: skipped and counted, but it was ISSUED at 1024, above the current scale -- the same
+    # overflow episode as update 0, no second back-off (one episode used to cost 3 skipped updates and an 8x drop)
+    assert sc.poll(wait=True, lag=2) is True and sc.scale == 512.0 and sc.overflow_steps == 2 and len(sc.queue) == 2
     assert sc.poll(wait=True) is False and not sc.queue
+    sc.record(_flag(False))                           # issued at 512: a new episode
+    assert sc.poll(wait=True) is True and sc.scale == 256.0
