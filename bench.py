@@ -485,6 +485,21 @@ def parity_leg(tdt, dev, images, image_hw, flops_per_step: float, steps: int = 1
     except Exception as e:  # noqa: BLE001
         out["config5_mode"] = {"error": repr(e)[:300]}
     torch.cuda.empty_cache()
+    # (4) `trained`: the same three precision modes scored by the open-set VOC evaluator (AP@K, pascal_voc_evaluation.py:192) on a checkpoint
+    # TRAINED here (tests/trained_parity.py: synthetic learnable VOC-layout set, 1000 iterations of the HIP training step): what the
+    # fast mode costs in accuracy where scores are spread by training, not decided by the near-ties of random-init weights
+    try:
+        from tests.trained_parity import run as trained_run
+        t = trained_run(str(dev))
+        out["trained"] = dict(APk_fp32=t["APk_fp32"], APk_fast=t["APk_fast"], APk_config5=t["APk_config5"],
+                              agreement_fast_vs_fp32=t["agreement_fast_vs_fp32"], agreement_config5_vs_fp32=t["agreement_config5_vs_fp32"],
+                              detections_fp32=t["detections_fp32"], known_detections_fp32=t["known_detections_fp32"],
+                              metrics_fp32=t["metrics_fp32"], metrics_fast=t["metrics_fast"], train=t["train"],
+                              note="AP@K of host/evaluation.py (restatement of openset_rcnn/evaluation/pascal_voc_evaluation.py) on 64 synthetic test images with "
+                                   "known and unknown objects; the released checkpoint / VOC-COCO images needed for README.md:98's 59.12 are not reachable offline")
+    except Exception as e:  # noqa: BLE001
+        out["trained"] = {"error": repr(e)[:300]}
+    torch.cuda.empty_cache()
     return out
 
 

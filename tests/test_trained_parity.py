@@ -1,0 +1,25 @@
+"""AP@K of the fp16 fast mode and of the config-5 mode against the fp32 parity mode on the SAME trained checkpoint (tests/trained_parity.py:
+synthetic learnable VOC-layout set, 1000 HIP training iterations, the open-set VOC evaluator). north_star's accuracy tolerance
+("mAP_k within 0.1 of the reference") applied to the only pair that can be run offline: the benchmarked precision modes against
+the precision the reference runs in."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fast_and_config5_modes_keep_ap_at_k_on_trained_weights(osr):
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    osr._lib.load()
+    from tests import trained_parity as tp
+    out = tp.run("cuda:0")
+    tr = out["train"]
+    assert tr["loss_last"] < 0.1 * tr["loss_first"], tr  # it trained
+    assert out["APk_fp32"] >= 50.0, out                  # ... to a detector whose known-class AP is not dominated by ties
+    assert out["known_detections_fp32"] > 50
+    assert abs(out["APk_fast"] - out["APk_fp32"]) <= 0.1, out
+    assert abs(out["APk_config5"] - out["APk_fp32"]) <= 0.1, out
+    # the strict per-detection agreement (IoU >= 0.99, |score difference| <= 1e-2) stays where it is on random weights: it counts
+    # last-digit box differences that AP@K (IoU 0.5, 1-decimal coordinates) does not see
+    assert out["agreement_fast_vs_fp32"] >= 0.80
