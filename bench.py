@@ -301,6 +301,110 @@ def train_step_leg(params, tdt, device, images, image_hw, steps: int, warmup: in
                                   "dense launches' 2 x 1.7 TFLOP on zero rows" if tr.sparse_rpn_bwd else "dense (every anchor row)")
 
 
+def config4_leg(tdt, device, steps: int, warmup: int, dist=None, rank: int = 0, world: int = 1):
+    """BASELINE.json config 4: GraspNet openset_rcnn_R50_FPN_128k.yaml (28 known of 88 classes, its loss weights and thresholds, from
+    configs/graspnet.yaml through the same yaml -> engine mapping run_net.py uses), 1280x720 frames, batch 8 per GPU (64 over 8 GPUs), one
+    training iteration = host frames -> upload + on-device ResizeShortestEdge(800, 1333) = 750x1333 -> pad 768x1344 -> forward + backward +
+    bucketed gradient all-reduce (RCCL, issued from inside the backward) + SGD. Also times ONE all-reduce of the whole flat gradient
+    buffer alone (166.5 MB fp32; /root/reference/train.py:201-205's DDP moves the same bytes), so that the fraction of it the
+    backward hides can be read off: hidden = 1 - (iteration time with - without the collective) / all-reduce time alone."""
+    import numpy as np
+    from openset_rcnn_amd.host.config import add_openset_rcnn_config, get_cfg
+    from openset_rcnn_amd.host.data import DeviceResizer
+    from openset_rcnn_amd.host.modeling import engine_cfg_from
+    from openset_rcnn_amd.host.train import OpensetRCNNTrainer
+    from openset_rcnn_amd.host.weights import random_params
+    cfg = get_cfg()
+    add_openset_rcnn_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "graspnet.yaml"))
+    ecfg = engine_cfg_from(cfg)
+    K = ecfg["num_known"]
+    class_map = (torch.arange(0, ecfg["num_classes"], 3)[:K].to(torch.int64) + 1)  # a sparse known-id table, like GraspNet's class_id (PLN :80-95)
+    n, fh, fw, h, w, hp, wp = 8, 720, 1280, 750, 1333, 768, 1344
+    params = random_params(0, num_known=K)
+    tr = OpensetRCNNTrainer(params, cfg=ecfg, dtype=tdt, device=device, lr=1e-5, loss_scale=512.0, class_map=class_map)
+    g = np.random.default_rng(100 + rank)
+    frames = [g.integers(0, 256, (fh, fw, 3), dtype=np.uint8) for _ in range(n)]  # decoded frames in host memory (each rank its own shard)
+    rz = DeviceResizer(device)
+    batch = torch.empty((n, 3, h, w), dtype=torch.uint8, device=device)
+    gt_g = torch.Generator().manual_seed(rank)
+    ngt = 6
+    ctr = torch.rand(n, ngt, 2, generator=gt_g) * torch.tensor([w * 0.8, h * 0.8]) + 40
+    size = torch.rand(n, ngt, 2, generator=gt_g) * 300 + 32
+    gt = torch.cat((ctr - size / 2, ctr + size / 2), dim=2)
+    gt[..., 0::2].clamp_(0, w); gt[..., 1::2].clamp_(0, h)
+    gcls = class_map[torch.randint(0, K, (n, ngt), generator=gt_g)]
+    gcnt = torch.full((n,), ngt, dtype=torch.int32)
+    shapes = tr.eng.pyramid_shapes(hp, wp)
+    r = sum(a * b for a, b in shapes)
+    cap = sum(min(2000, a * b) for a, b in shapes)
+    keys = {k: torch.rand(sz, generator=gt_g).to(device) for k, sz in (("rpn_reg", (n, r)), ("rpn_obj", (n, r)), ("roi", (n, cap + ngt)))}
+    hw = torch.tensor([(h, w)] * n, dtype=torch.int32, device=device)
+    dev_args = (hw, hp, wp, gt.to(device), gcls.to(device), gcnt.to(device), keys)
+
+    def load():
+        for i, f in enumerate(frames):
+            rz(f, (h, w), out=batch[i], wait=False)
+        torch.cuda.current_stream().wait_event(rz.done)
+        return batch
+
+    def run(k, with_collective=True):
+        for _ in range(k):
+            losses = tr.step(load(), *dev_args, update=with_collective)
+            if not with_collective:  # the same iteration without the gradient exchange: local update only
+                tr._update(1)
+                tr.buckets.reset()
+        return losses
+
+    def timed_iters(k, **kw):
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = run(k, **kw)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / k
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
+    run(warmup)
+    dt, losses = timed_iters(steps)
+    out = dict(config=f"GraspNet openset_rcnn_R50_FPN_128k.yaml (configs/graspnet.yaml), 1280x720 frames -> device resize 750x1333 -> pad 768x1344, batch 8 per GPU, "
+                      f"global batch {8 * world}, {world}xMI355X, train step (BASELINE.json config 4)",
+               ms_per_iter=round(dt * 1e3, 3), images_per_sec=round(n * world / dt, 2), n_gpus=world, steps=steps, warmup=warmup, batch_per_gpu=n,
+               num_known=K, num_classes=ecfg["num_classes"], unk_thr=ecfg["unk_thr"], pln_loss_weight=ecfg["pln_loss_weight"],
+               loss_total_last=round(float(sum(float(v) for v in losses.values())), 4), overflow_skipped_steps=tr.overflow_steps,
+               gradient_bytes=tr.num_params * 4, input="host frames (uint8 HWC) -> pinned staging -> device, resized on the device inside the timed region")
+    if dist is not None and world > 1:
+        # the collective alone: one all-reduce of the whole flat buffer, nothing else on the GPU
+        flat = tr.grad_flat
+        for _ in range(2):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        ar = (time.perf_counter() - t0) / reps
+        flat.zero_()
+        dt_local, _ = timed_iters(steps, with_collective=False)
+        exposed = max(0.0, dt - dt_local)
+        out.update(all_reduce_ms=round(ar * 1e3, 3), all_reduce_GBps_per_rank=round(tr.num_params * 4 / ar / 1e9, 1),
+                   ms_per_iter_without_all_reduce=round(dt_local * 1e3, 3), all_reduce_exposed_ms=round(exposed * 1e3, 3),
+                   all_reduce_hidden_fraction=round(max(0.0, 1.0 - exposed / ar), 3) if ar > 0 else None,
+                   all_reduce_note="whole flat fp32 gradient buffer in one call, idle GPU (the in-step exchange is the same bytes in >= 25 MB buckets issued "
+                                   "from inside the backward, host/parallel.py GradBuckets); hidden = 1 - (iteration with - without the collective) / this")
+    return out
+
+
 def train_step_child(args) -> dict:
     """The single-GPU train-step leg runs in a child process after the inference measurement. In one process the two disturb each
     other: the leg is an eager stream of ~500 launches per iteration and ran 8 % slower after the four-lane inference loop (38.0
@@ -584,7 +688,13 @@ def main(argv=None) -> int:
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
+    out_stream = sys.stdout
     if world > 1:
+        # stdout carries exactly ONE line, the JSON record: native libraries (c10d's "[Gloo] Rank ..." banners, RCCL's notices) print to
+        # file descriptor 1 behind Python's back, so descriptor 1 is pointed at stderr and the record goes to a duplicate of the original
+        sys.stdout.flush()
+        out_stream = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
@@ -858,8 +968,9 @@ def main(argv=None) -> int:
 
         def give_up():
             if rank == 0:
-                line["train_step"] = {"error": "the multi-rank train step did not finish within 300 s (hung collective?); headline unaffected, exit code 3"}
-                print(json.dumps(line), flush=True)
+                line.setdefault("train_step", {"error": "the multi-rank train step did not finish within 300 s (hung collective?); headline unaffected, exit code 3"})
+                line.setdefault("config4", {"error": "not reached / did not finish (see train_step)"})
+                print(json.dumps(line), file=out_stream, flush=True)
             os._exit(3)  # every rank: a hung collective must not read as a successful run (no restart, no exec: the GPU is initialised)
         guard = threading.Timer(300.0, give_up)
         guard.daemon = True
@@ -869,13 +980,25 @@ def main(argv=None) -> int:
         except Exception as e:  # noqa: BLE001  (reported in the line, the headline stands; the job fails)
             ts = {"error": repr(e)[:400]}
             rc = 3
-        guard.cancel()
         if rank == 0:
             line["train_step"] = ts
+        try:  # BASELINE.json config 4 (GraspNet heads, 1280x720 frames, batch 8 per GPU): every rank, same watchdog
+            c4 = config4_leg(tdt, dev, args.train_steps, 2, dist, rank, world)
+        except Exception as e:  # noqa: BLE001
+            c4 = {"error": repr(e)[:400]}
+            rc = 3
+        guard.cancel()
+        if rank == 0:
+            line["config4"] = c4
+    if world == 1 and not args.no_train_step:
+        try:
+            line["config4"] = config4_leg(tdt, dev, args.train_steps, 2)
+        except Exception as e:  # noqa: BLE001
+            line["config4"] = {"error": repr(e)[:400]}
     if rank == 0:
         if not args.no_cpu_baseline:  # host-only: rank 0 times it whatever N is (the other ranks wait at the closing barrier)
             line["cpu_baseline"] = cpu_baseline(params, args.cpu_batch, one_thread=world == 1)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=out_stream, flush=True)
     if dist is not None:
         dist.destroy_process_group()
     return rc

@@ -85,3 +85,50 @@ def test_n_rank_line_names_its_ranks_and_devices():
     assert out["device_names"] == ["AMD Instinct MI355X"]
     one = bench.rank_identity(None, 0, 1, 0.2, 4, 16, "GPU-x", "dev")
     assert one["ranks"] == 1 and one["distinct_gpus"] == 1 and one["per_rank_images_per_sec"] == [320.0]
+
+
+CONFIG4_FIELDS = {"config", "ms_per_iter", "images_per_sec", "n_gpus", "batch_per_gpu", "num_known", "num_classes", "gradient_bytes", "all_reduce_ms",
+                  "all_reduce_GBps_per_rank", "ms_per_iter_without_all_reduce", "all_reduce_exposed_ms", "all_reduce_hidden_fraction"}
+
+
+def check_n_rank_line(line: dict, world: int) -> None:
+    """What the first multi-GPU run must answer: BASELINE configs 2 / 3 / 4 in one record."""
+    assert line["n_gpus"] == world and line["config"]["ranks"] == world and line["scaling"] == "weak"
+    assert "roofline" in line and "train_step" in line and "config4" in line
+    c4 = line["config4"]
+    assert CONFIG4_FIELDS <= set(c4), sorted(CONFIG4_FIELDS - set(c4))
+    assert c4["n_gpus"] == world and c4["batch_per_gpu"] == 8 and c4["num_known"] == 28 and c4["num_classes"] == 88
+    assert c4["gradient_bytes"] == line["train_step"]["trainable_params"] * 4 or c4["gradient_bytes"] > 150e6
+    assert 0.0 <= c4["all_reduce_hidden_fraction"] <= 1.0 and c4["all_reduce_ms"] > 0
+    assert "1280x720" in c4["config"] and "GraspNet" in c4["config"]
+
+
+def test_committed_two_rank_rehearsal_line_has_the_config4_object():
+    """The record of the 2-rank rehearsal (gloo, both ranks on one MI355X; profiles/r05_rehearsal2_line.json, written by the GPU test
+    below on the GPU box) parses and answers configs 2, 3 and 4 -- a CPU-side check of the N > 1 record's schema."""
+    import json
+    path = os.path.join(ROOT, "profiles", "r05_rehearsal2_line.json")
+    line = json.loads(open(path).read())
+    check_n_rank_line(line, 2)
+    assert line["config"]["distinct_gpus"] == 1  # honest: a rehearsal, both ranks on one card
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_rehearsal_prints_exactly_one_json_line(tmp_path):
+    """`bench.py --gpus 2` with two gloo ranks sharing this GPU: stdout is ONE line (c10d's banners go to stderr), and that line carries
+    the headline, the multi-rank train step and the config-4 leg with the all-reduce measured alone."""
+    import json
+    import subprocess
+    env = dict(os.environ, OSR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--train-steps", "2", "--passes-in-flight", "1",
+           "--no-cpu-baseline", "--no-pmc"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    line = json.loads(lines[0])
+    check_n_rank_line(line, 2)
+    out = os.environ.get("OSR_REHEARSAL_OUT")
+    if out:
+        with open(out, "w") as fh:
+            fh.write(lines[0] + "\n")
