@@ -714,6 +714,12 @@ class GeneralizedRCNN(_EngineOwner):
         trainer.grads_ready = False
         return dict(zip(names, outs))
 
+    def event_scalars(self) -> Dict[str, float]:
+        """The ten scalars the reference's training forward puts into EventStorage (rpn/num_{pos,neg}_anchors, rpn/obj_num_{pos,neg}_anchors,
+        rpn/num_proposals, roi_head/num_{fg,bg}_samples, softmax_classifier/{cls_accuracy,fg_cls_accuracy,false_negative}) for the last
+        training-mode forward of this model (OpensetRCNNTrainer.event_scalars)."""
+        return self._trainer.event_scalars() if self._trainer is not None else {}
+
     def _grad_hook(self) -> torch.Tensor:
         """A 0-d leaf that requires grad: what makes torch call _ExplicitBackward.backward (it receives no gradient itself)."""
         if self._hook is None or self._hook.device != self.device:

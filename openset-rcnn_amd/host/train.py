@@ -351,7 +351,41 @@ class OpensetRCNNTrainer:
         s.update(roi_state)
         losses = dict(loss_rpn_loc=rpn[0], loss_rpn_ctr=rpn[1], loss_box_reg=roi["loss_box_reg"], loss_iou=roi["loss_iou"],
                       loss_dml=roi["loss_dml"], loss_cls=roi["loss_cls"])
+        # what event_scalars() reads (references only: nothing is computed or copied unless a logger asks)
+        self._last_forward = dict(n=n, rpn_counts=rpn[2:6], prop_counts=sel["counts"], roi_counts=roi["roi_counts"], logits=roi_state["logits"],
+                                  cls_k=roi_state["cls_k"], nck=roi_state["nck"], batch_idx=roi_state["smp"]["batch_idx"])
         return losses, s
+
+    def event_scalars(self) -> Dict[str, float]:
+        """The ten scalars the reference puts into detectron2's EventStorage during a training iteration, for the LAST forward of this
+        trainer (one small D2H copy; call it on logging iterations only):
+          rpn/num_pos_anchors, rpn/num_neg_anchors, rpn/obj_num_pos_anchors, rpn/obj_num_neg_anchors (classification_free_rpn.py:459-463),
+          rpn/num_proposals (:553-554), roi_head/num_fg_samples, roi_head/num_bg_samples (osrcnn_roi_heads.py:226-228: means over the
+          images of the sampled foreground / background proposals), softmax_classifier/cls_accuracy, /fg_cls_accuracy, /false_negative
+          (softmax_classifier.py:18-45 on the classifier's logits and the id-mapped targets; the last two only when a foreground row exists)."""
+        lf = getattr(self, "_last_forward", None)
+        if lf is None:
+            return {}
+        n, K = lf["n"], self.eng.cfg["num_known"]
+        t = lf["cls_k"]
+        if self.eng.id_map is None:  # VOC-COCO: known ids are 0..K-1 already, background = NUM_CLASSES -> K, every other class -> -1 (id_map, :224-229)
+            t = torch.where(t < K, t, torch.where(t == lf["nck"], torch.full_like(t, K), torch.full_like(t, -1)))
+        valid = lf["batch_idx"].view(-1) >= 0
+        pred = lf["logits"][:, :K + 1].argmax(dim=1)
+        fg = valid & (t >= 0) & (t < K)
+        stats = torch.stack([valid.sum(), (valid & (pred == t)).sum(), fg.sum(), (fg & (pred == t)).sum(), (fg & (pred == K)).sum()]).to(torch.float32)
+        host = torch.cat([lf["rpn_counts"].to(torch.float32).view(-1), lf["prop_counts"].to(torch.float32).view(-1), lf["roi_counts"].to(torch.float32).view(-1),
+                          stats]).cpu().tolist()
+        rc, pc, roi, st = host[:4], host[4:4 + n], host[4 + n:4 + n + 3 * n], host[4 + 4 * n:]
+        out = {"rpn/num_pos_anchors": rc[0] / n, "rpn/num_neg_anchors": rc[1] / n, "rpn/obj_num_pos_anchors": rc[2] / n, "rpn/obj_num_neg_anchors": rc[3] / n,
+               "rpn/num_proposals": sum(pc) / max(n, 1),
+               "roi_head/num_fg_samples": sum(roi[1::3]) / n, "roi_head/num_bg_samples": sum(roi[2::3]) / n}
+        if st[0] > 0:
+            out["softmax_classifier/cls_accuracy"] = st[1] / st[0]
+            if st[2] > 0:
+                out["softmax_classifier/fg_cls_accuracy"] = st[3] / st[2]
+                out["softmax_classifier/false_negative"] = st[4] / st[2]
+        return out
 
     def _frozen_prefix(self, images, hp, wp):
         """Stem (+ preprocessing) and the frozen residual stages: what depends on the batch and on frozen weights only -- the output of

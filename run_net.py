@@ -224,6 +224,9 @@ def do_train(cfg, args, model, D, start_iter: int, opt_state=None):
             logger.info("iter %d  total_loss %.4f  %s  lr %.6f%s", iteration + 1, losses_reduced,
                         "  ".join(f"{k} {v:.4f}" for k, v in loss_dict_reduced.items()), lr,
                         f"  (overflow-skipped steps: {trainer.overflow_steps}, loss scale {trainer.loss_scale:g})" if trainer.overflow_steps else "")
+            # the ten EventStorage scalars of the reference's training iteration (rpn/*, roi_head/*, softmax_classifier/*; train.py's
+            # CommonMetricPrinter / JSONWriter show them), this rank's values of the iteration just run
+            logger.info("        %s", "  ".join(f"{k} {v:.3f}" for k, v in trainer.event_scalars().items()))
         if cfg.TEST.EVAL_PERIOD > 0 and (iteration + 1) % cfg.TEST.EVAL_PERIOD == 0 and iteration != max_iter - 1:
             model.eval()  # writes the trained masters back into the module
             do_test(cfg, args, model, D, iteration=iteration + 1)

@@ -333,3 +333,28 @@ def test_prefetched_frozen_prefix_gives_the_same_steps(setup):
         assert res[mode][0] == res["plain"][0], mode
         for k, a in res[mode][1].items():
             assert torch.equal(a, res["plain"][1][k]), (mode, k)
+
+
+def test_event_scalars_follow_the_reference_definitions(setup):
+    """The ten EventStorage scalars of a training iteration (classification_free_rpn.py:459-463,553-554; osrcnn_roi_heads.py:226-228;
+    softmax_classifier.py:18-45) from OpensetRCNNTrainer.event_scalars(), recomputed here from the forward's saved tensors."""
+    tr, d, n = setup["tr"], setup["dev"], setup["n"]
+    _, saved = tr._forward(d["images"], d["hw"], setup["h"], setup["w"], d["gt"], d["gcls"], d["gcnt"], d["keys"])
+    sc = tr.event_scalars()
+    assert set(sc) == {"rpn/num_pos_anchors", "rpn/num_neg_anchors", "rpn/obj_num_pos_anchors", "rpn/obj_num_neg_anchors", "rpn/num_proposals",
+                       "roi_head/num_fg_samples", "roi_head/num_bg_samples", "softmax_classifier/cls_accuracy", "softmax_classifier/fg_cls_accuracy",
+                       "softmax_classifier/false_negative"}
+    labels, obj = saved["labels"].cpu(), saved["obj_labels"].cpu()
+    assert sc["rpn/num_pos_anchors"] == pytest.approx(float((labels == 1).sum()) / n) and sc["rpn/num_neg_anchors"] == pytest.approx(float((labels == 0).sum()) / n)
+    assert sc["rpn/obj_num_pos_anchors"] == pytest.approx(float((obj == 1).sum()) / n) and sc["rpn/obj_num_neg_anchors"] == pytest.approx(float((obj == 0).sum()) / n)
+    cnt = saved["smp"]["counts"].cpu().float()  # per image: sampled, foreground, background
+    assert sc["roi_head/num_fg_samples"] == pytest.approx(float(cnt[:, 1].mean())) and sc["roi_head/num_bg_samples"] == pytest.approx(float(cnt[:, 2].mean()))
+    assert sc["roi_head/num_fg_samples"] + sc["roi_head/num_bg_samples"] == pytest.approx(float(cnt[:, 0].mean()))
+    valid = saved["smp"]["batch_idx"].view(-1).cpu() >= 0
+    cls = saved["cls"].cpu()[valid]
+    t = torch.where(cls < 20, cls, torch.where(cls == 81, torch.full_like(cls, 20), torch.full_like(cls, -1)))  # id_map (softmax_classifier.py:224-229)
+    pred = saved["logits"].cpu()[valid].argmax(1)
+    fg = (t >= 0) & (t < 20)
+    assert sc["softmax_classifier/cls_accuracy"] == pytest.approx(float((pred == t).sum()) / len(t))
+    assert sc["softmax_classifier/fg_cls_accuracy"] == pytest.approx(float((pred[fg] == t[fg]).sum()) / int(fg.sum()))
+    assert sc["softmax_classifier/false_negative"] == pytest.approx(float((pred[fg] == 20).sum()) / int(fg.sum()))
