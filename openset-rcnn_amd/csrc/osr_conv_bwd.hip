@@ -64,6 +64,9 @@ struct WgradArgs {
 #ifndef WG_BM
 #define WG_BM 64  // rows (m) per pipeline step
 #endif
+#ifndef WG_P8_MIN_STEPS
+#define WG_P8_MIN_STEPS 48  // 64-row steps per split from which the 256 x 256 tile runs the 8-phase loop (measured: scripts/exp_wgrad8.py)
+#endif
 #ifndef WG_NST
 #define WG_NST 2  // staging buffers: the pieces of step s + WG_NST - 1 are in flight under step s
 #endif
@@ -76,7 +79,7 @@ struct WgradArgs {
 // (row s, chunk bit 0) and lane (row s ^ 1, chunk bit 1) met in the same banks -- rocprofv3: SQ_LDS_BANK_CONFLICT = half of
 // SQ_LDS_IDX_ACTIVE in both instantiations. Now the 32 lanes of a half-wave cover all 64 banks once.
 // The pieces of step s+1 are issued between the MFMAs of step s (as in the forward kernel).
-template <class TI, int TCO, int TCI, int WM, int WN>
+template <class TI, int TCO, int TCI, int WM, int WN, int P8 = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(WgradArgs a) {
     constexpr int NW = WM * WN;
     constexpr int SA = TCO / WM / 16, SB = TCI / WN / 16;       // 16-wide sub-tiles per wave
@@ -118,7 +121,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(WgradArgs a
     // sit a fixed number of rows further on and are derived with adds and one wrap. No division, no 32-bit multiply in the loop. ----
 #define WG_SW(r) ((((r) & 3) | ((((r) >> 3) & 1) << 2)) << 1)
     constexpr int CPRY = YB / 16, RPPY = 1024 / YB, CPRX = XB / 16, RPPX = 1024 / XB;
-    const int rowy0 = wid * YPW * RPPY + lane / CPRY, rowx0 = wid * XPW * RPPX + lane / CPRX;  // piece q: + q * RPP rows
+    static_assert(!P8 || (TCO == 256 && TCI == 256 && WM == 2 && WN == 4 && WG_BM == 64 && WG_NST == 2), "8-phase loop: 256 x 256 tile, 2 x 4 waves, 64-row steps, two stages");
+    // P8 (the 8-phase loop below): a step is staged in four UNITS of 32 pixel rows (dy rows / x rows of K half kk), 16 pieces each, two per
+    // wave: the wave's piece jj of K half kk holds rows kk * 32 + wid * 4 + jj * 2 + {0, 1}. Otherwise a wave's pieces are consecutive.
+    const int rowy0 = P8 ? wid * 4 + lane / CPRY : wid * YPW * RPPY + lane / CPRY;
+    const int rowx0 = P8 ? wid * 4 + lane / CPRX : wid * XPW * RPPX + lane / CPRX;  // piece q: + (row offset of piece q) rows
+    auto piece_rows = [&](int q, int rpp) -> int { return P8 ? (q >> 1) * 32 + (q & 1) * 2 : q * rpp; };  // rows between the lane's first piece and piece q
+    auto piece_slot = [&](int q, int ppw) -> int { return P8 ? (q >> 1) * 16 + wid * 2 + (q & 1) : wid * ppw + q; };  // 1-KiB slot of piece q in the tile
     // dy: offset of (row m, co0) grows by cout elements per row
     unsigned ybase = (unsigned)(((m_begin + rowy0) * p.cout + co0) * 2);
     const unsigned ystep = (unsigned)((long long)WG_BM * p.cout * 2), yrow = (unsigned)(p.cout * 2);
@@ -140,6 +149,31 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(WgradArgs a
     const unsigned x_wrap_h = (unsigned)((p.in_stride_n - (long long)p.ho * p.stride_h * p.in_stride_h) * 2);              // oh -= ho, image + 1
     const int iw_lim = p.wo * p.stride_w - p.pad_w + kw, ih_lim = p.ho * p.stride_h - p.pad_h + kh;
     const int iw_span = p.wo * p.stride_w, ih_span = p.ho * p.stride_h;
+    // P8: every one of the lane's four x pieces (rows +0, +2, +32, +34) keeps its own (ih, iw, offset) and moves on by WG_BM rows per step in
+    // CLOSED FORM -- WG_BM = dn images + dh output rows + dw output columns, then at most one column wrap and one row wrap. (The while-loop
+    // wraps of the old loop take wo-dependent trip counts: with one pixel per row -- the FC layers' (m, 1) view -- 64 trips per step and up to
+    // 34 per piece, which sat in this loop's load sections: FC1's weight gradient ran 2.5x slower.)
+    int xih4[P8 ? XPW : 1], xiw4[P8 ? XPW : 1];
+    unsigned xoff4[P8 ? XPW : 1];
+    int adv_iw = 0, adv_ih = 0;
+    unsigned adv_off = 0;
+    {
+        const unsigned dn = wdiv((unsigned)WG_BM, a.div_howo), rem = (unsigned)WG_BM - dn * a.div_howo.d;
+        const unsigned dh = wdiv(rem, a.div_wo), dw = rem - dh * a.div_wo.d;
+        adv_iw = (int)dw * p.stride_w; adv_ih = (int)dh * p.stride_h;
+        adv_off = (unsigned)(((long long)dn * p.in_stride_n + (long long)adv_ih * p.in_stride_h + (long long)adv_iw * p.in_stride_w) * 2);
+    }
+    if constexpr (P8) {
+#pragma unroll
+        for (int q = 0; q < XPW; ++q) {
+            const long long mq = mx + piece_rows(q, RPPX);
+            const long long mm = mq < a.M ? mq : 0;
+            const unsigned mu = (unsigned)mm, ni = wdiv(mu, a.div_howo), rm = mu - ni * a.div_howo.d;
+            const int oh0 = (int)wdiv(rm, a.div_wo), ow0 = (int)(rm - (unsigned)oh0 * a.div_wo.d);
+            xih4[q] = oh0 * p.stride_h - p.pad_h + kh; xiw4[q] = ow0 * p.stride_w - p.pad_w + kw;
+            xoff4[q] = (unsigned)(((long long)ni * p.in_stride_n + (long long)xih4[q] * p.in_stride_h + (long long)xiw4[q] * p.in_stride_w + ci0) * 2);
+        }
+    }
 
     // one staging piece: q < YPW -> dy rows, else x rows (gathered through the conv geometry)
 #define WG_PIECE(stage, step, q)                                                                                                \
@@ -147,20 +181,24 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(WgradArgs a
         unsigned char* sy_ = lds + (stage) * STAGE;                                                                             \
         if ((q) < YPW) {                                                                                                        \
             const int qq_ = (q) < YPW ? (q) : 0;                                                                                \
-            const int pc_ = wid * YPW + qq_;                                                                                    \
-            const int row_ = rowy0 + qq_ * RPPY;                                                                                \
+            const int pc_ = piece_slot(qq_, YPW);                                                                               \
+            const int dr_ = piece_rows(qq_, RPPY);                                                                              \
+            const int row_ = rowy0 + dr_;                                                                                       \
             const int chunk_ = (lane % CPRY) ^ WG_SW(row_);                                                                     \
-            const unsigned yoff_ = (my + qq_ * RPPY < m_end && co0 + chunk_ * 8 < p.cout) ? ybase + (unsigned)qq_ * RPPY * yrow + (unsigned)chunk_ * 16u : WG_OOB; \
+            const unsigned yoff_ = (my + dr_ < m_end && co0 + chunk_ * 8 < p.cout) ? ybase + (unsigned)dr_ * yrow + (unsigned)chunk_ * 16u : WG_OOB; \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_t*)(sy_ + pc_ * 1024), 16, yoff_, 0, 0, 0);                  \
         } else {                                                                                                                \
             const int qq_ = (q) >= YPW ? (q) - YPW : 0;                                                                         \
-            const int pc_ = wid * XPW + qq_;                                                                                    \
-            const int row_ = rowx0 + qq_ * RPPX;                                                                                \
+            const int pc_ = piece_slot(qq_, XPW);                                                                               \
+            const int dr_ = piece_rows(qq_, RPPX);                                                                              \
+            const int row_ = rowx0 + dr_;                                                                                       \
             const int chunk_ = (lane % CPRX) ^ WG_SW(row_);                                                                     \
-            int iw_ = xiw + qq_ * RPPX * p.stride_w, ih_ = xih;                                                                 \
-            unsigned off_ = xbase + (unsigned)(qq_ * RPPX) * x_dw;                                                              \
-            while (iw_ >= iw_lim) { iw_ -= iw_span; ih_ += p.stride_h; off_ += x_wrap_w; if (ih_ >= ih_lim) { ih_ -= ih_span; off_ += x_wrap_h; } } \
-            const bool ok_ = mx + qq_ * RPPX < m_end && ci0 + chunk_ * 8 < p.cin && (unsigned)ih_ < (unsigned)p.hi && (unsigned)iw_ < (unsigned)p.wi; \
+            int iw_ = P8 ? xiw4[P8 ? qq_ : 0] : xiw + dr_ * p.stride_w, ih_ = P8 ? xih4[P8 ? qq_ : 0] : xih;                    \
+            unsigned off_ = P8 ? xoff4[P8 ? qq_ : 0] : xbase + (unsigned)dr_ * x_dw;                                            \
+            if constexpr (!P8) {                                                                                                \
+                while (iw_ >= iw_lim) { iw_ -= iw_span; ih_ += p.stride_h; off_ += x_wrap_w; if (ih_ >= ih_lim) { ih_ -= ih_span; off_ += x_wrap_h; } } \
+            }                                                                                                                   \
+            const bool ok_ = mx + dr_ < m_end && ci0 + chunk_ * 8 < p.cin && (unsigned)ih_ < (unsigned)p.hi && (unsigned)iw_ < (unsigned)p.wi; \
             const unsigned xoff_ = ok_ ? off_ + (unsigned)chunk_ * 16u : WG_OOB;                                                 \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(sy_ + WG_BM * YB + pc_ * 1024), 16, xoff_, 0, 0, 0);    \
         }                                                                                                                       \
@@ -169,8 +207,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(WgradArgs a
 #define WG_ADVANCE()                                                                                                            \
     {                                                                                                                           \
         my += WG_BM; mx += WG_BM; ybase += ystep;                                                                               \
-        xiw += WG_BM * p.stride_w; xbase += (unsigned)WG_BM * x_dw;                                                             \
-        while (xiw >= iw_lim) { xiw -= iw_span; xih += p.stride_h; xbase += x_wrap_w; if (xih >= ih_lim) { xih -= ih_span; xbase += x_wrap_h; } } \
+        if constexpr (P8) {                                                                                                     \
+            _Pragma("unroll") for (int q_ = 0; q_ < XPW; ++q_) {                                                                \
+                int iw_ = xiw4[P8 ? q_ : 0] + adv_iw, ih_ = xih4[P8 ? q_ : 0] + adv_ih;                                         \
+                unsigned off_ = xoff4[P8 ? q_ : 0] + adv_off;                                                                   \
+                const bool cw_ = iw_ >= iw_lim;                                                                                 \
+                iw_ -= cw_ ? iw_span : 0; ih_ += cw_ ? p.stride_h : 0; off_ += cw_ ? x_wrap_w : 0u;                            \
+                const bool ch_ = ih_ >= ih_lim;                                                                                 \
+                ih_ -= ch_ ? ih_span : 0; off_ += ch_ ? x_wrap_h : 0u;                                                          \
+                xiw4[P8 ? q_ : 0] = iw_; xih4[P8 ? q_ : 0] = ih_; xoff4[P8 ? q_ : 0] = off_;                                    \
+            }                                                                                                                   \
+        } else {  /* the same closed form on the single state of the one-barrier loop (its pieces sit <= 6 rows further on: short while loops) */ \
+            xiw += adv_iw; xih += adv_ih; xbase += adv_off;                                                                     \
+            const bool cw_ = xiw >= iw_lim;                                                                                     \
+            xiw -= cw_ ? iw_span : 0; xih += cw_ ? p.stride_h : 0; xbase += cw_ ? x_wrap_w : 0u;                                \
+            const bool ch_ = xih >= ih_lim;                                                                                     \
+            xih -= ch_ ? ih_span : 0; xbase += ch_ ? x_wrap_h : 0u;                                                             \
+        }                                                                                                                       \
     }
 
     f32x4 acc[SA][SB];  // [co sub-tile][ci sub-tile]: rows = output channels, columns = input channels
@@ -185,6 +238,134 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(WgradArgs a
     constexpr int NMF = (WG_BM / 32) * SA * SB, PSTEP = (NMF / 2) / PPW > 0 ? (NMF / 2) / PPW : 1;  // pieces go out during the first half of a step
     // (pieces are issued for every step up to nsteps + WG_NST - 2: rows past m_end are zero fills into buffers nothing reads, and the
     // counted wait below stays exact)
+    if constexpr (P8) {
+        // ---- 8-phase loop (round 5; the forward kernel's schedule, osr_conv_gemm64.hip, with the units cut along the contraction axis: here
+        // BOTH operands are k-strided). A 64-row step is four phases of 16 MFMAs, (kk, qa) = (0,0) (0,1) (1,0) (1,1): K half kk (32 pixel
+        // rows) x output-channel half qa (64 of the wave's 128) x all of its 64 input channels. Units of a step: X0 Y0 X1 Y1 (x / dy rows
+        // of K half 0 / 1), read in phase 1 (X0, and the Y0 columns of qa 0), 2 (Y0 columns of qa 1), 3 (X1, Y1), 4 (Y1) -- each is
+        // restaged in the phase after its last read: X0 of step s+2 in phase 2, Y0 in 3, X1 in 4, Y1 in phase 1 of the next step. Every
+        // phase retires its own fragment reads (lgkmcnt(0)) in front of its first barrier; waves 4-7 run one barrier behind waves 0-3.
+        // Waits on the vector-memory counter: phases 2 and 4, vmcnt(10) -- FIVE units stay in flight; phase 4's wait retires the two K-half-0
+        // units of the next step (read from phase 1 on), phase 2's the two K-half-1 units of this step (read from phase 3 on): a read
+        // sits one phase behind the wait + barrier that retire its data. Steps past the last are zero-fill dummies (rows >= m_end). The
+        // accumulation order per output element is the old loop's: bit-identical results.
+        // The transposing reads are issued as inline asm: behind the builtin, hipcc (ROCm 7.2) waits vmcnt(0) in front of every group of
+        // reads while an LDS-DMA is in flight (it cannot prove the read does not alias the DMA's destination), which would drain the ring
+        // four times per step. The asm form leaves the ordering to this loop's own waits: lgkmcnt(0) in front of each phase's first barrier
+        // (one asm statement with the barrier) and a sched_barrier in front of the MFMAs that consume the registers.
+        // LDS byte address of (row g*8 + q4 [+ kk*32 + h*4], chunk c ^ sw, half pp & 1): sw depends on the lane only (row & 3 = q4, (row >> 3) & 1 = g & 1).
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)lds;
+        const int sw8 = WG_SW(g * 8 + q4);
+        const unsigned lane_row = (unsigned)((g * 8 + q4) * YB + (pp & 1) * 8);
+        static_assert(YB == XB, "one row pitch");
+        unsigned a_addr[2][SA / 2], b_addr[SB];  // [qa][i], [j]: stage 0, kk 0, h 0
+#pragma unroll
+        for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+            for (int i = 0; i < SA / 2; ++i) a_addr[qa][i] = lds0 + lane_row + (unsigned)((((wr * SA + qa * (SA / 2) + i) * 2 + (pp >> 1)) ^ sw8) * 16);
+#pragma unroll
+        for (int j = 0; j < SB; ++j) b_addr[j] = lds0 + (unsigned)(WG_BM * YB) + lane_row + (unsigned)((((wc * SB + j) * 2 + (pp >> 1)) ^ sw8) * 16);
+        u32x2 va[2][SA / 2], vb[2][SB];
+        frag_t fa[SA / 2], fb[SB];
+#define W8_TR(dst_, addr_, off_) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "n"(off_) : "memory")
+#define W8_READ_A(kk_, qa_)                                                                                                         \
+        {                                                                                                                           \
+            _Pragma("unroll") for (int i = 0; i < SA / 2; ++i) {                                                                    \
+                const unsigned ad_ = a_addr[qa_][i] + stage_off;                                                                    \
+                W8_TR(va[0][i], ad_, (kk_) * 32 * YB);                                                                              \
+                W8_TR(va[1][i], ad_, (kk_) * 32 * YB + 4 * YB);                                                                     \
+            }                                                                                                                       \
+        }
+#define W8_READ_B(kk_)                                                                                                              \
+        {                                                                                                                           \
+            _Pragma("unroll") for (int j = 0; j < SB; ++j) {                                                                        \
+                const unsigned ad_ = b_addr[j] + stage_off;                                                                         \
+                W8_TR(vb[0][j], ad_, (kk_) * 32 * XB);                                                                              \
+                W8_TR(vb[1][j], ad_, (kk_) * 32 * XB + 4 * XB);                                                                     \
+            }                                                                                                                       \
+        }
+#define W8_ISSUE(stage_, q0_)                                                                                                       \
+        {                                                                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                                      \
+            WG_PIECE(stage_, 0, (q0_));                                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                                      \
+            WG_PIECE(stage_, 0, (q0_) + 1);                                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                                      \
+        }
+#define W8_MFMA(qa_, NEWB, MID)                                                                                                     \
+        {                                                                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                                      \
+            typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));                                                            \
+            _Pragma("unroll") for (int i = 0; i < SA / 2; ++i) {                                                                    \
+                const u32x4_ ta = {va[0][i][0], va[0][i][1], va[1][i][0], va[1][i][1]};                                             \
+                fa[i] = __builtin_bit_cast(frag_t, ta);                                                                             \
+            }                                                                                                                       \
+            if (NEWB) {                                                                                                             \
+                _Pragma("unroll") for (int j = 0; j < SB; ++j) {                                                                    \
+                    const u32x4_ tb = {vb[0][j][0], vb[0][j][1], vb[1][j][0], vb[1][j][1]};                                         \
+                    fb[j] = __builtin_bit_cast(frag_t, tb);                                                                         \
+                }                                                                                                                   \
+            }                                                                                                                       \
+            __builtin_amdgcn_s_setprio(1);                                                                                          \
+            _Pragma("unroll") for (int i = 0; i < SA / 2; ++i) {                                                                    \
+                _Pragma("unroll") for (int j = 0; j < SB; ++j)                                                                      \
+                    acc[(qa_) * (SA / 2) + i][j] = FragW<TI>::mfma(fa[i], fb[j], acc[(qa_) * (SA / 2) + i][j]);                     \
+                if (i == SA / 2 - 2) { MID; }                                                                                       \
+            }                                                                                                                       \
+            __builtin_amdgcn_s_setprio(0);                                                                                          \
+            __builtin_amdgcn_s_barrier();                                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                                      \
+        }
+#define W8_WAIT_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define W8_WAITVM_BARRIER() asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+        // unit -> first piece index of WG_PIECE: dy pieces 0 .. YPW-1 (K half 0: 0, 1; K half 1: 2, 3), x pieces YPW .. YPW+XPW-1
+        constexpr int UY0 = 0, UY1 = 2, UX0 = YPW, UX1 = YPW + 2;
+        static_assert(YPW == 4 && XPW == 4, "two pieces per wave and unit");
+        if (nsteps > 0) {
+            // prologue: step 0 complete + X0, Y0, X1 of step 1; phase 1 of step 0 issues Y1 of step 1 (the steady-state slot of that unit)
+            W8_ISSUE(0, UX0); W8_ISSUE(0, UY0); W8_ISSUE(0, UX1); W8_ISSUE(0, UY1);
+            WG_ADVANCE();
+            W8_ISSUE(1, UX0); W8_ISSUE(1, UY0); W8_ISSUE(1, UX1);
+            asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");  // step 0 has landed, for every wave
+            if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one barrier behind
+            __builtin_amdgcn_sched_barrier(0);
+            for (int s = 0; s < nsteps; ++s) {
+                const int cs = s & 1, ns = cs ^ 1;
+                const unsigned stage_off = (unsigned)(cs * STAGE);
+                // phase 1: K half 0, output channels half 0 (the staging state is one step ahead: step s+1; it moves to s+2 inside the cluster)
+                W8_READ_B(0);
+                W8_READ_A(0, 0);
+                W8_ISSUE(ns, UY1);
+                W8_WAIT_BARRIER();
+                W8_MFMA(0, true, { __builtin_amdgcn_sched_barrier(0); WG_ADVANCE(); __builtin_amdgcn_sched_barrier(0); });
+                // phase 2: K half 0, half 1
+                W8_READ_A(0, 1);
+                W8_ISSUE(cs, UX0);
+                W8_WAITVM_BARRIER();  // X1, Y1 of this step have landed (read from phase 3 on)
+                W8_MFMA(1, false, {});
+                // phase 3: K half 1, half 0
+                W8_READ_B(1);
+                W8_READ_A(1, 0);
+                W8_ISSUE(cs, UY0);
+                W8_WAIT_BARRIER();
+                W8_MFMA(0, true, {});
+                // phase 4: K half 1, half 1
+                W8_READ_A(1, 1);
+                W8_ISSUE(cs, UX1);
+                W8_WAITVM_BARRIER();  // X0, Y0 of step s+1 have landed (read from its phase 1 on)
+                W8_MFMA(1, false, {});
+            }
+            if (wr == 0) __builtin_amdgcn_s_barrier();
+        }
+#undef W8_READ_A
+#undef W8_TR
+#undef W8_READ_B
+#undef W8_ISSUE
+#undef W8_MFMA
+#undef W8_WAIT_BARRIER
+#undef W8_WAITVM_BARRIER
+    } else {
     if (nsteps > 0) {
 #pragma unroll
         for (int ps = 0; ps < WG_NST - 1; ++ps) {
@@ -244,6 +425,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(WgradArgs a
                     }
                 }
         }
+    }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the tail's zero-fill pieces)
     // partial[split][co][tap][ci]: C/D layout col = lane&15 (ci), row = (lane>>4)*4 + r (co). (Offsets by additions: the 128 stores of
@@ -359,11 +541,23 @@ extern "C" osr_status osr_conv2d_wgrad(const osr_conv_params* p, const void* x, 
         const size_t ldsb = (size_t)WG_NST * WG_BM * (256 + 256) * 2;  // 128 KiB
         static osr_dev_mask attr{0};
         osr_once_per_device(attr, [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<f16_t, 256, 256, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<bf16_t, 256, 256, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<f16_t, 256, 256, 2, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<bf16_t, 256, 256, 2, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<f16_t, 256, 256, 2, 4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<bf16_t, 256, 256, 2, 4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         });
-        if (p->in_dtype == OSR_F16) hipLaunchKernelGGL((conv_wgrad_kernel<f16_t, 256, 256, 2, 4>), dim3((unsigned)grid), dim3(512), ldsb, st, a);
-        else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 256, 256, 2, 4>), dim3((unsigned)grid), dim3(512), ldsb, st, a);
+        // the 8-phase loop pays a longer prologue (two steps staged before the first MFMA): the one-barrier-per-step loop stays for short splits
+        const long long steps_per_split = a.rows_per_split / WG_BM;
+#ifdef OSR_EXPERIMENT
+        const bool use_p8 = wg_env_int("OSR_WGRAD_PH8", 1) != 0 && steps_per_split >= wg_env_int("OSR_WGRAD_PH8_MINSTEPS", WG_P8_MIN_STEPS);  // (scripts/exp_wgrad8.py)
+#else
+        const bool use_p8 = steps_per_split >= WG_P8_MIN_STEPS;
+#endif
+        if (!use_p8) {
+            if (p->in_dtype == OSR_F16) hipLaunchKernelGGL((conv_wgrad_kernel<f16_t, 256, 256, 2, 4, 0>), dim3((unsigned)grid), dim3(512), ldsb, st, a);
+            else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 256, 256, 2, 4, 0>), dim3((unsigned)grid), dim3(512), ldsb, st, a);
+        } else if (p->in_dtype == OSR_F16) hipLaunchKernelGGL((conv_wgrad_kernel<f16_t, 256, 256, 2, 4, 1>), dim3((unsigned)grid), dim3(512), ldsb, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 256, 256, 2, 4, 1>), dim3((unsigned)grid), dim3(512), ldsb, st, a);
     } else {
         const size_t ldsb = (size_t)WG_NST * WG_BM * (128 + 128) * 2;  // 64 KiB
         if (p->in_dtype == OSR_F16) hipLaunchKernelGGL((conv_wgrad_kernel<f16_t, 128, 128, 2, 2>), dim3((unsigned)grid), dim3(256), ldsb, st, a);
