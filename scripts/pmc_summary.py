@@ -14,7 +14,7 @@ def short(name):
     m = re.match(r"_Z\d+(conv_igemm64_kernel)I(DF16_|DF16b)(DF16_|DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E(?:Li(\d+)E)?", name)
     if m:
         split = ",split-K tail" if m.group(10) == "1" else ""
-        return f"conv_igemm64<{m.group(4)}x{m.group(5)},{m.group(6)}x{m.group(7)} waves,epi{m.group(8)},stages{1 + int(m.group(9))},out={'f32' if m.group(3) == 'f' else 'same'}{split}>"
+        return f"conv_igemm64<{m.group(4)}x{m.group(5)},{m.group(6)}x{m.group(7)} waves,epi{m.group(8)},{'8-phase' if m.group(9) == '2' else 'stages' + str(1 + int(m.group(9)))},out={'f32' if m.group(3) == 'f' else 'same'}{split}>"
     m = re.match(r"_Z\d+(bottleneck64_kernel)I(DF16_|DF16b)Li(\d+)ELi(\d)E", name)
     if m:
         return f"bottleneck64<cin {m.group(3)},{'projection' if m.group(4) == '1' else 'identity'}>"
