@@ -159,15 +159,50 @@ __device__ __forceinline__ void tr_bitonic_desc(unsigned long long* buf, int n) 
         }
 }
 
-// member(i) -> bool, keyf(i) -> float. Selects min(k, #members) entries; s_sel[j] low 32 bits = 0xffffffff - index, in
-// ascending (key, index) order. Returns the number selected (uniform). Must be called by the whole block.
-template <class MemberF, class KeyF>
+// One histogram increment per lane with `pred`, wave-aggregated: keys of a narrow range share their leading byte (uniform keys in [0.5, 1):
+// one exponent), so a plain LDS atomic per lane serialises 64 ways on one address. Up to four rounds elect a leader, count the lanes
+// that share its bin with one ballot and add the count once; whatever is left (the well-spread later bytes) goes out as plain atomics.
+__device__ __forceinline__ void tr_hist_add(int* s_hist, int bin, bool pred) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long act = __ballot(pred);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        if (!act) break;  // (wave-uniform)
+        const int leader = __ffsll((long long)act) - 1;
+        const int b = __shfl(bin, leader, 64);
+        const unsigned long long same = __ballot(pred && bin == b) & act;
+        if (lane == leader) atomicAdd(&s_hist[b], __popcll(same));
+        act &= ~same;
+    }
+    if ((act >> lane) & 1ull) atomicAdd(&s_hist[bin], 1);
+}
+
+// member(i) -> bool, keyf(i) -> float (both must be readable for every i < cnt). Selects min(k, #members) entries; s_sel[j] low 32 bits =
+// 0xffffffff - index, in ascending (key, index) order. Returns the number selected (uniform). Must be called by the whole block.
+// Round 5: every pass over the list keeps TR_UNROLL independent (member, key) loads per thread in flight -- the passes used to issue one
+// dependent 1-byte + 4-byte load pair per trip, ~15 passes x 88 trips of memory latency per image -- and the compaction ranks its candidates
+// with ONE block scan over per-thread counts of a blocked layout (thread t owns a contiguous run: thread order = index order, which is what
+// the tie rule needs) instead of one block scan per 1024 elements. Same selection bit for bit (tests/test_train_fwd.py, golden fixtures).
+template <int TR_UNROLL = 1, class MemberF, class KeyF>  // TR_UNROLL: (member, key) pairs a thread keeps in flight (8 for the 89 523-anchor lists; 1 where the accessors are heavy)
 __device__ int tr_select_smallest(MemberF member, KeyF keyf, int cnt, int k, unsigned long long* s_sel,
                                   int* s_hist, int* s_scan, unsigned int* s_bc) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    // batched walk, interleaved layout (coalesced): BODY(i, mem, v) for every i < cnt with mem = member(i), v = inverted monotone key
+#define TR_WALK(BODY)                                                                                          \
+    for (int i0_ = tid; i0_ < cnt; i0_ += nt * TR_UNROLL) {                                                     \
+        bool mem_[TR_UNROLL];                                                                                   \
+        unsigned int v_[TR_UNROLL];                                                                             \
+        _Pragma("unroll") for (int u_ = 0; u_ < TR_UNROLL; ++u_) {                                              \
+            const int i_ = i0_ + u_ * nt;                                                                       \
+            const int ic_ = i_ < cnt ? i_ : 0;                                                                  \
+            mem_[u_] = member(ic_) && i_ < cnt;                                                                 \
+            v_[u_] = ~osr_float_key(keyf(ic_));                                                                 \
+        }                                                                                                       \
+        _Pragma("unroll") for (int u_ = 0; u_ < TR_UNROLL; ++u_) { const int i = i0_ + u_ * nt; const bool mem = mem_[u_]; const unsigned int v = v_[u_]; (void)i; (void)v; BODY }  \
+    }
     // members
     int c = 0;
-    for (int i = tid; i < cnt; i += blockDim.x) c += member(i) ? 1 : 0;
+    TR_WALK({ c += mem ? 1 : 0; })
     int m;
     osr_block_excl_scan(c, s_scan, &m);
     if (k > m) k = m;
@@ -180,22 +215,31 @@ __device__ int tr_select_smallest(MemberF member, KeyF keyf, int cnt, int k, uns
     if (!all) {
         for (int pass = 0; pass < 4; ++pass) {
             const int shift = 24 - 8 * pass;
-            for (int i = tid; i < 256; i += blockDim.x) s_hist[i] = 0;
+            for (int i = tid; i < 256; i += nt) s_hist[i] = 0;
             __syncthreads();
-            for (int i = tid; i < cnt; i += blockDim.x)
-                if (member(i)) {
-                    const unsigned int v = ~osr_float_key(keyf(i));
-                    if ((v & mask) == prefix) atomicAdd(&s_hist[(v >> shift) & 255], 1);
-                }
+            TR_WALK({ tr_hist_add(s_hist, (int)((v >> shift) & 255), mem && (v & mask) == prefix); })
             __syncthreads();
-            if (tid == 0) {
-                int acc = 0, d = 255;
-                for (; d > 0; --d) {
-                    if (acc + s_hist[d] >= remaining) break;
-                    acc += s_hist[d];
+            if (tid < 64) {
+                // the digit d (from 255 down) at which the count of larger digits first reaches `remaining`: lane l owns digits 255 - 4 l .. 252 - 4 l
+                // (a serial walk by one thread was 256 dependent LDS reads per pass: ~12 us, eight times per call)
+                const int h0 = s_hist[255 - 4 * tid], h1 = s_hist[254 - 4 * tid], h2 = s_hist[253 - 4 * tid], h3 = s_hist[252 - 4 * tid];
+                const int mine = h0 + h1 + h2 + h3;
+                const int before = osr_wave_incl_scan(mine) - mine;  // digits larger than this lane's four
+                // first lane (lowest index = largest digits) whose inclusive count reaches `remaining`; digit 0 takes whatever is left
+                const bool hit = before + mine >= remaining;
+                const unsigned long long hits = __ballot(hit);
+                const int sel = hits ? __ffsll((long long)hits) - 1 : 63;
+                if (tid == sel) {
+                    int acc = before, d = 255 - 4 * tid;
+                    const int hh[4] = {h0, h1, h2, h3};
+                    int j = 0;
+                    for (; j < 3; ++j) {
+                        if (d - j == 0 || acc + hh[j] >= remaining) break;
+                        acc += hh[j];
+                    }
+                    s_bc[0] = prefix | ((unsigned int)(d - j) << shift);
+                    s_bc[1] = (unsigned int)(remaining - acc);
                 }
-                s_bc[0] = prefix | ((unsigned int)d << shift);
-                s_bc[1] = (unsigned int)(remaining - acc);
             }
             __syncthreads();
             prefix = s_bc[0];
@@ -205,30 +249,36 @@ __device__ int tr_select_smallest(MemberF member, KeyF keyf, int cnt, int k, uns
         }
     }
     const unsigned int T = prefix;
-    int ngt_total = 0;
-    if (!all) {
-        int g = 0;
-        for (int i = tid; i < cnt; i += blockDim.x) g += (member(i) && ~osr_float_key(keyf(i)) > T) ? 1 : 0;
-        osr_block_excl_scan(g, s_scan, &ngt_total);
+    // compaction, blocked layout: thread t owns [t * chunk, (t + 1) * chunk): its candidates greater than T and equal to T, counted, ranked by
+    // one block scan, then written in index order (candidates equal to T: the first `remaining` of them by index)
+    const int chunk = (cnt + nt - 1) / nt, lo = min(tid * chunk, cnt), hi = min(lo + chunk, cnt);
+#define TR_WALK_BLOCKED(BODY)                                                                                   \
+    for (int i0_ = lo; i0_ < hi; i0_ += TR_UNROLL) {                                                            \
+        bool mem_[TR_UNROLL];                                                                                   \
+        unsigned int v_[TR_UNROLL];                                                                             \
+        _Pragma("unroll") for (int u_ = 0; u_ < TR_UNROLL; ++u_) {                                              \
+            const int i_ = i0_ + u_;                                                                            \
+            const int ic_ = i_ < hi ? i_ : lo;                                                                  \
+            mem_[u_] = member(ic_) && i_ < hi;                                                                  \
+            v_[u_] = ~osr_float_key(keyf(ic_));                                                                 \
+        }                                                                                                       \
+        _Pragma("unroll") for (int u_ = 0; u_ < TR_UNROLL; ++u_) { const int i = i0_ + u_; const bool mem = mem_[u_]; const unsigned int v = v_[u_]; (void)i; BODY }  \
     }
-    int base_gt = 0, base_eq = 0;
-    for (int i0 = 0; i0 < cnt; i0 += blockDim.x) {
-        const int i = i0 + tid;
-        unsigned int v = 0;
-        int gt = 0, eq = 0;
-        if (i < cnt && member(i)) {
-            v = ~osr_float_key(keyf(i));
-            if (all) gt = 1; else { gt = v > T; eq = v == T; }
+    int gt = 0, eq = 0;
+    TR_WALK_BLOCKED({ if (mem) { if (all || v > T) ++gt; else if (v == T) ++eq; } })
+    int tot;
+    const int packed = osr_block_excl_scan(gt | (eq << 16), s_scan, &tot);
+    int pg = packed & 0xffff, pe = packed >> 16;
+    const int ngt_total = tot & 0xffff;
+    TR_WALK_BLOCKED({
+        if (mem) {
+            const unsigned long long comp = ((unsigned long long)v << 32) | (unsigned int)(0xffffffffu - (unsigned int)i);
+            if (all || v > T) { if (pg < TR_MAXK) s_sel[pg] = comp; ++pg; }
+            else if (v == T) { if (pe < remaining && ngt_total + pe < TR_MAXK) s_sel[ngt_total + pe] = comp; ++pe; }
         }
-        int tot;
-        const int packed = osr_block_excl_scan(gt | (eq << 16), s_scan, &tot);
-        const int pg = base_gt + (packed & 0xffff), pe = base_eq + (packed >> 16);
-        const unsigned long long comp = ((unsigned long long)v << 32) | (unsigned int)(0xffffffffu - (unsigned int)i);
-        if (gt && pg < TR_MAXK) s_sel[pg] = comp;
-        if (eq && pe < remaining && ngt_total + pe < TR_MAXK) s_sel[ngt_total + pe] = comp;
-        base_gt += tot & 0xffff;
-        base_eq += tot >> 16;
-    }
+    })
+#undef TR_WALK
+#undef TR_WALK_BLOCKED
     int kp = 1;
     while (kp < k) kp <<= 1;
     for (int i = k + tid; i < kp; i += blockDim.x) s_sel[i] = 0ull;
@@ -250,10 +300,10 @@ __global__ __launch_bounds__(TR_THREADS) void subsample_kernel(signed char* __re
     const float* ky = keys + (long long)img * R;
     const int cnt = (int)R;
     const int want_pos = (int)((float)num_samples * pos_fraction);
-    const int np = tr_select_smallest([&](int i) { return lab[i] == 1; }, [&](int i) { return ky[i]; }, cnt, want_pos, s_sel, s_hist, s_scan, s_bc);
+    const int np = tr_select_smallest<8>([&](int i) { return lab[i] == 1; }, [&](int i) { return ky[i]; }, cnt, want_pos, s_sel, s_hist, s_scan, s_bc);
     for (int j = tid; j < np; j += blockDim.x) s_pos[j] = (int)(0xffffffffu - (unsigned int)(s_sel[j] & 0xffffffffull));
     __syncthreads();
-    const int nn = tr_select_smallest([&](int i) { return lab[i] == 0; }, [&](int i) { return ky[i]; }, cnt, num_samples - np, s_sel, s_hist, s_scan, s_bc);
+    const int nn = tr_select_smallest<8>([&](int i) { return lab[i] == 0; }, [&](int i) { return ky[i]; }, cnt, num_samples - np, s_sel, s_hist, s_scan, s_bc);
     for (int j = tid; j < nn; j += blockDim.x) s_neg[j] = (int)(0xffffffffu - (unsigned int)(s_sel[j] & 0xffffffffull));
     __syncthreads();
     for (int i = tid; i < cnt; i += blockDim.x) lab[i] = -1;  // label.fill_(-1)
