@@ -1,6 +1,8 @@
 """GPU parity of the dense-layer backward kernels against torch autograd (fp32 on the same fp16-rounded operands).
 Tolerance: fp32 accumulation on both sides, different summation order -> 2e-3 of the tensor's max (weight gradients sum up to
 ~10^4 products of fp16-rounded factors); data gradients are stored in fp16 -> one rounding."""
+import ctypes
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -93,3 +95,36 @@ def test_wgrad_single_split_writes_dw_directly(ops):
     ops.conv2d_wgrad(x.to(DEV).view(1, m, 1, k), dy.to(DEV).view(1, m, 1, nout), 1, 1, dw=dw, accumulate=True)
     assert rel(dw, 2 * first) < 1e-6
     assert torch.equal(ops.linear_wgrad(x.to(DEV), dy.to(DEV)), first.view(nout, k))
+
+
+# (n, cin, cout, h, w, k, stride): splits of >= 48 sixty-four-row steps -> the 8-phase loop of the 256 x 256 weight-gradient tile (round 5); the
+# cases above are all short splits (the one-barrier loop). 3x3 with zero padding, a strided 1x1 (the gather's row / image wraps), the FC
+# layers' (m, 1) view (one pixel per row: a wrap at every row), bf16.
+P8_CASES = [(8, 256, 256, 100, 168, 3, 1, torch.float16), (16, 1024, 1024, 100, 168, 1, 2, torch.float16), (1, 12544, 1024, 8192, 1, 1, 1, torch.float16),
+            (8, 256, 256, 100, 168, 3, 1, torch.bfloat16), (3, 1024, 1024, 211, 97, 1, 1, torch.float16), (8, 1024, 1024, 157, 211, 1, 2, torch.float16)]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,k,stride,dtype", P8_CASES)
+def test_wgrad_8phase_loop_vs_fp32_reference(ops, osr, n, cin, cout, h, w, k, stride, dtype):
+    L = osr._lib
+    pad = k // 2
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    # the split the library will use: rows per split / 64 >= 48 selects the 8-phase loop (osr_conv_bwd.hip, WG_P8_MIN_STEPS)
+    p = L.ConvParams()
+    p.n, p.hi, p.wi, p.cin, p.ho, p.wo, p.cout = n, h, w, cin, ho, wo, cout
+    p.kh = p.kw = k; p.stride_h = p.stride_w = stride; p.pad_h = p.pad_w = pad
+    p.in_dtype = p.out_dtype = L.OSR_F16 if dtype == torch.float16 else L.OSR_BF16
+    splits = int(L.load().osr_conv2d_wgrad_workspace_bytes(ctypes.byref(p))) // (cout * k * k * cin * 4)
+    assert (n * ho * wo) // max(splits, 1) // 64 >= 48, "this case no longer reaches the 8-phase loop"
+    gg = torch.Generator(device=DEV).manual_seed(cin + h)
+    x = (torch.randn(n, h, w, cin, generator=gg, device=DEV) * 0.5).to(dtype)
+    dy = (torch.randn(n, ho, wo, cout, generator=gg, device=DEV) * 0.1).to(dtype)
+    dw = ops.conv2d_wgrad(x, dy, k, k, stride, pad)
+    assert torch.equal(ops.conv2d_wgrad(x, dy, k, k, stride, pad), dw), "not reproducible"
+    if k == 1:  # dw[co][ci] = sum over the (strided) pixels
+        xs = x[:, ::stride, ::stride].reshape(-1, cin).float()
+        ref = (dy.reshape(-1, cout).float().t() @ xs).view(cout, 1, 1, cin)
+    else:
+        ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (cout, cin, k, k), dy.float().permute(0, 3, 1, 2), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    err = float((dw - ref).abs().max() / ref.abs().max())
+    assert err < 2e-3, err  # fp32 accumulation in another order over up to 134 400 rows
