@@ -980,9 +980,12 @@ static void conv64_launch_tile(Conv64Args& a, hipStream_t st) {
 //   time = full_rounds x tile(occ) + tile(residents of the last partial round),  tile(r) = fixed + nk x slice(r)
 // The 256-wide tiles read the residual in the epilogue (no prefetch under the K loop), which measured 1.6x slower on the
 // HBM-bound residual layers: they are not offered to a residual layer with fewer than 18 K slices.
+#ifndef C64_BIG_CAP
+#define C64_BIG_CAP 5.2e6  // per-CU rate of the 256 x 256 tile under load, FLOP per us
+#endif
 struct TileCfg { int id, bm, bn, two, occ, pre_res; double cap; };  // cap: per-CU MFMA rate under load, FLOP per us
 static const TileCfg kTileCfgs[] = {
-    {T128x128_1, 128, 128, 0, 3, 1, 4.45e6}, {T128x128_2, 128, 128, 1, 2, 1, 4.45e6}, {T256x256_2, 256, 256, 1, 1, 0, 5.2e6},
+    {T128x128_1, 128, 128, 0, 3, 1, 4.45e6}, {T128x128_2, 128, 128, 1, 2, 1, 4.45e6}, {T256x256_2, 256, 256, 1, 1, 0, C64_BIG_CAP},
     {T128x256_1, 128, 256, 0, 2, 0, 4.45e6}, {T256x128_1, 256, 128, 0, 2, 0, 4.45e6}, {T128x64_1, 128, 64, 0, 4, 1, 4.45e6},
     {T128x64_2, 128, 64, 1, 3, 1, 4.45e6},
 };
