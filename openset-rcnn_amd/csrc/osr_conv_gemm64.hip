@@ -557,7 +557,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
         if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one barrier behind
         __builtin_amdgcn_sched_barrier(0);
         for (int ks = 0; ks < nk; ++ks) {
-            const int cs = ks & 1, ns = cs ^ 1;
+            const int cs = ks & 1;
             const unsigned char* sa = lds + cs * STAGE;
             const unsigned char* sb = sa + BM * 128;
             // phase 1 (the K state is one tile ahead: tile ks+1; it advances to tile ks+2 inside the cluster)
