@@ -523,6 +523,55 @@ def full_lists_leg(params, tdt, dev, images, image_hw, batch: int, passes: int, 
     return out
 
 
+def vendor_gemm_leg(dev, reps: int = 8, rounds: int = 3):
+    """Calibration, not the product: what the vendor's hand-written GEMM (hipBLASLt behind torch.matmul: `Custom_Cijk_..._MT256x256x64_MI16x16x1`,
+    the same 256 x 256 x 64 macro tile as conv_igemm64_kernel's) reaches on THIS box on the plain-GEMM restatement of the product's three largest
+    MFMA-bound layers, beside the product's kernels on the same operands. A library GEMM has no im2col gather, no halo and no fused epilogue (it
+    would need the 3 x 3 layers' im2col matrix materialised: 9x the activation bytes), so it is a reference for what the K loop can reach at the
+    clock the part holds under a dense MFMA load -- the practical roof next to the 2.5 PFLOP/s datasheet figure."""
+    import math
+    from openset_rcnn_amd.host import ops
+    g = torch.Generator().manual_seed(0)
+
+    def best_us(fn):
+        best = 1e30
+        for _ in range(rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / reps * 1e3)
+        return best
+    rows = []
+    for name, m, k, n, conv in (("roi_heads.box_head.fc1 (68368 x 12544 -> 1024)", 68368, 12544, 1024, None),
+                                ("backbone.fpn_output2 (3x3, 256 -> 256, 16 x 200 x 336; as a GEMM: 1075200 x 2304 -> 256)", 16 * 200 * 336, 2304, 256, (16, 200, 336, 256, 3)),
+                                ("backbone.fpn_output3 (16 x 100 x 168; as a GEMM: 268800 x 2304 -> 256)", 16 * 100 * 168, 2304, 256, (16, 100, 168, 256, 3))):
+        a = (torch.randn(m, k, generator=g) * 0.5).half().to(dev)
+        b = (torch.randn(n, k, generator=g) / math.sqrt(k)).half().to(dev)
+        out = torch.empty(m, n, dtype=torch.float16, device=dev)
+        bias = torch.zeros(n, device=dev)
+        t_lib = best_us(lambda: torch.matmul(a, b.t(), out=out))
+        if conv is None:
+            t_own = best_us(lambda: ops.linear(a, b, bias, relu=True))
+        else:
+            nb, h, w, cin, kk = conv
+            del a
+            x = (torch.randn(nb, h, w, cin, generator=g) * 0.5).half().to(dev)
+            wt = b.reshape(n, kk, kk, cin).contiguous()
+            t_own = best_us(lambda: ops.conv2d(x, wt, bias, 1, kk // 2, relu=True))
+            del x
+        fl = 2.0 * m * k * n
+        rows.append(dict(layer=name, hipblaslt_us=round(t_lib, 1), hipblaslt_tflops=round(fl / t_lib / 1e6, 1), product_us=round(t_own, 1),
+                         product_tflops=round(fl / t_own / 1e6, 1), product_over_hipblaslt=round(t_lib / t_own, 3)))
+        del b, out
+        torch.cuda.empty_cache()
+    return dict(rows=rows, timing=f"best of {rounds} rounds of {reps} back-to-back launches, HIP events, random operands",
+                note="hipBLASLt's kernel on these shapes is its hand-written 256x256x64 MFMA-16x16 macro-tile kernel (stream-K variant on the first two: "
+                     "scripts/exp_gemm_names.py under rocprofv3); the product's kernels compute the layer itself (implicit im2col + bias + ReLU)")
+
+
 def parity_leg(tdt, dev, images, image_hw, flops_per_step: float, steps: int = 10):
     """What the benchmarked fp16 path gives up against fp32, and what fp32 costs. (1) agreement of the fast path's final
     detections with the engine's fp32 PARITY MODE (every tensor and product in fp32; tests/test_e2e_parity.py pins that mode to
@@ -952,6 +1001,11 @@ def main(argv=None) -> int:
             line["parity"] = parity_leg(tdt, dev, images, image_hw, mfma_flops)
         except Exception as e:  # noqa: BLE001  (reported in the line; the headline stands)
             line["parity"] = {"error": repr(e)[:400]}
+        torch.cuda.empty_cache()
+        try:
+            line["roofline"]["vendor_gemm"] = vendor_gemm_leg(dev)
+        except Exception as e:  # noqa: BLE001
+            line["roofline"]["vendor_gemm"] = {"error": repr(e)[:300]}
         torch.cuda.empty_cache()
         if args.graph:
             try:

@@ -6,7 +6,7 @@
 // "view" convolution on the generic implicit-GEMM kernel (K padded 147 -> 256, 0.29 ms) and osr_maxpool3x3s2 (0.16 ms), with the
 // 550 MB stem output written to HBM and read back in between.
 //
-// Design (MI355X): one workgroup (4 waves, 51 KB of LDS: three per CU) = a 4 x 16 tile of POOLED pixels = a 9 x 33 region of stem
+// Design (MI355X): persistent workgroups (4 waves, 51 KB of LDS: three per CU; the weights stay in registers), one tile at a time = a 4 x 16 tile of POOLED pixels = a 9 x 33 region of stem
 // pixels (the pool's halo is recomputed: 297 / 256 = 1.16x) = a 23 x 72-pixel patch of the pre-padded NHWC4 image, staged in LDS
 // once (every input pixel feeds up to 16 stem pixels).
 //  * conv: v_mfma_f32_16x16x32 with the WEIGHTS as the A operand (m = 16 output channels: wave w owns channels 16 w .. 16 w + 15 and
@@ -39,6 +39,9 @@ template <> struct SpFrag<bf16_t> {
     static __device__ __forceinline__ sp_f32x4 mfma(sp_b8 a, sp_b8 b, sp_f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 
+#ifndef SP_ABL
+#define SP_ABL 0
+#endif
 #define SP_PH 4                     // pooled rows of a tile
 #define SP_PW 16                    // pooled columns
 #define SP_SH (2 * SP_PH + 1)       // 9 stem rows
@@ -59,7 +62,7 @@ struct StemPoolArgs {
     const void* w;       // (64, >= 7, 1, 32): stem view, row stride wrow elements
     const float* bias;   // (64)
     void* out;           // (n, hq, wq, 64)
-    int n, hd, wd, hs, ws, hq, wq, tiles_x, tiles_y, wrow;
+    int n, hd, wd, hs, ws, hq, wq, tiles_x, tiles_y, wrow, ntiles;
 };
 
 template <class T, int SRC>
@@ -68,18 +71,8 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(StemPoolArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[SP_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // XCD-aware walk: an XCD takes a contiguous run of tiles (row-major inside an image): the patch rows neighbouring tiles share hit one L2
-    int t;
-    {
-        const int nwg = gridDim.x, b = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
-        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, img = t / (a.tiles_x * a.tiles_y);
-    const int py0 = ty * SP_PH, px0 = tx * SP_PW;
-    const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;   // first stem row / column of the region (-1 on the top / left tiles: the pool's padding)
-    const int iy0 = 2 * sy0, ix0 = 2 * sx0;           // first patch row / column in the pre-padded image (stem pixel (y, x) reads rows 2y .. 2y + 6)
-
-    // ---- this wave's weight fragments (A operand: lane (m = lane & 15, kg = lane >> 4) holds w[16 wid + m][ky][8 kg .. 8 kg + 7]) and biases ----
+    // ---- this wave's weight fragments (A operand: lane (m = lane & 15, kg = lane >> 4) holds w[16 wid + m][ky][8 kg .. 8 kg + 7]) and biases,
+    //      loaded ONCE per workgroup: the workgroups are persistent (three per CU, each walks ~22 tiles at the bench's size) ----
     const int m16 = lane & 15, kg = lane >> 4;
     frag_t wf[7];
     {
@@ -88,6 +81,33 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(StemPoolArgs a) {
         for (int ky = 0; ky < 7; ++ky) wf[ky] = *reinterpret_cast<const frag_t*>(wp + ky * 32);
     }
     const float4 b4 = *reinterpret_cast<const float4*>(a.bias + 16 * wid + 4 * kg);  // the lane's D rows are channels 16 wid + 4 kg + 0..3
+    // Per pixel group, this lane's LDS offsets -- where its B fragment starts in the patch, where its four channels go in the stem image --
+    // do not depend on the tile: computed once per workgroup and kept in registers (the group loop of an interior tile is unrolled). The
+    // counters said the kernel was bound by vector-ALU issue (75 M VALU instructions per launch = 64 % of all issue cycles, the MFMAs 31 %),
+    // 40 of them per group and wave in the old loop: the pixel's row / column, both addresses and the inside-the-map test, then four adds,
+    // maxima, conversions, selects and two packs. An interior tile now spends 8: two packed adds, four maxima, two packed conversions.
+    unsigned short g_rd[SP_NGRP], g_wr[SP_NGRP];
+#pragma unroll
+    for (int grp = 0; grp < SP_NGRP; ++grp) {
+        const int q = 16 * grp + m16, qc = q < SP_NPIX ? q : SP_NPIX - 1;  // (the last group's lanes past pixel 296 re-read pixel 296 and write slots the pool never reads)
+        const int r = (qc * 1986) >> 16, c = qc - r * 33;
+        g_rd[grp] = (unsigned short)((2 * r) * SP_IPITCH + (2 * c + 2 * kg) * 8);
+        g_wr[grp] = (unsigned short)(SP_TILE_OFF + q * 128 + (((2 * wid + (kg >> 1)) ^ ((c >> 1) & 7)) << 4) + (kg & 1) * 8);
+    }
+
+    // XCD-aware walk: workgroup b runs on XCD b % 8 (round-robin dispatch); an XCD takes a contiguous run of tiles (row-major inside an image)
+    // and its workgroups walk that run side by side -- the patch rows neighbouring tiles share hit one L2. (A grid of fewer than 8
+    // workgroups is one group.)
+    const int ngrp = gridDim.x >= 8 ? 8 : 1, wpg = gridDim.x / ngrp;            // (the host launches a multiple of 8 workgroups from 8 on)
+    const int xg = blockIdx.x % ngrp, tq = a.ntiles / ngrp, tr = a.ntiles % ngrp;
+    const int run0 = xg * tq + (xg < tr ? xg : tr), run_len = tq + (xg < tr ? 1 : 0);
+#pragma unroll 1
+    for (int tl = blockIdx.x / ngrp; tl < run_len; tl += wpg) {
+    const int t = run0 + tl;
+    const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, img = t / (a.tiles_x * a.tiles_y);
+    const int py0 = ty * SP_PH, px0 = tx * SP_PW;
+    const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;   // first stem row / column of the region (-1 on the top / left tiles: the pool's padding)
+    const int iy0 = 2 * sy0, ix0 = 2 * sx0;           // first patch row / column in the pre-padded image (stem pixel (y, x) reads rows 2y .. 2y + 6)
 
     // ---- stage the patch. SRC 1 / 2: straight from the raw NCHW image -- (value - mean) / std rounded to the storage dtype, zero in
     //      the 3-pixel halo, the /32 padding and the 4th channel: the bits osr_preprocess writes, without the 139 MB round trip ----
@@ -142,6 +162,25 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(StemPoolArgs a) {
 
     // ---- conv + bias + ReLU -> LDS image of the stem region: pixel q = 33 row + column, 128 bytes, piece j (8 channels) at slot j ^ ((column >> 1) & 7) ----
     unsigned char* tile = lds + SP_TILE_OFF;
+    // interior tile: every pixel of the 9 x 33 region lies inside the stem map (all but the top row and the left column of tiles at the bench's size)
+    const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + SP_SH <= a.hs && sx0 + SP_SW <= a.ws;
+    if (interior) {
+        typedef float f32x4v __attribute__((ext_vector_type(4)));
+        typedef T t4 __attribute__((ext_vector_type(4)));
+        const f32x4v bv = {b4.x, b4.y, b4.z, b4.w}, zv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int grp = 0; grp < SP_NGRP; ++grp) {
+            const unsigned char* pb = lds + g_rd[grp];
+            frag_t xb[7];
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky) xb[ky] = *reinterpret_cast<const frag_t*>(pb + ky * SP_IPITCH);
+            sp_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky) acc = SpFrag<T>::mfma(wf[ky], xb[ky], acc);
+            const f32x4v v = __builtin_elementwise_max((f32x4v)acc + bv, zv);  // (same operations, same order as below: fp32 add, fp32 max, one rounding)
+            *reinterpret_cast<t4*>(lds + g_wr[grp]) = __builtin_convertvector(v, t4);
+        }
+    } else
 #pragma unroll 1
     for (int grp = 0; grp < SP_NGRP; ++grp) {  // (two groups per turn -- two independent accumulator chains -- measured slower: 305 against 250 us)
         const int q = 16 * grp + m16, qc = q < SP_NPIX ? q : SP_NPIX - 1;
@@ -168,33 +207,32 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(StemPoolArgs a) {
     }
     __syncthreads();
 
-    // ---- 3x3 / s2 max pool out of the LDS image: thread = (pooled pixel, 16 channels) ----
+    // ---- 3x3 / s2 max pool out of the LDS image: thread = (pooled pixel, 16 channels). The stem pixels are post-ReLU (>= 0, or a zero
+    //      standing in for the pool's padding): non-negative f16 / bf16 values order like their bit patterns read as signed 16-bit integers
+    //      (-0.0 = 0x8000 is the smallest of them and loses to the +0 the maximum starts from, as it did to fmaxf's 0.f), so the maximum is
+    //      taken on the raw halves, two per v_pk_max_i16 -- 72 packed operations per thread instead of 144 conversions + 144 fp32 maxima ----
     {
         const int pix = tid >> 2, cq = tid & 3;
         const int py = pix >> 4, px = pix & 15;
-        float mx[16];
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 m0 = {0, 0, 0, 0, 0, 0, 0, 0}, m1 = m0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) mx[k] = 0.f;
-        typedef T t8 __attribute__((ext_vector_type(8)));
+        for (int dy = 0; dy < (SP_ABL == 3 ? 1 : 3); ++dy)
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
+            for (int dx = 0; dx < (SP_ABL == 3 ? 1 : 3); ++dx) {
                 const int c = 2 * px + dx, q = (2 * py + dy) * 33 + c, f = (c >> 1) & 7;
-                const t8 v0 = *reinterpret_cast<const t8*>(tile + q * 128 + (((2 * cq) ^ f) << 4));
-                const t8 v1 = *reinterpret_cast<const t8*>(tile + q * 128 + (((2 * cq + 1) ^ f) << 4));
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { mx[k] = fmaxf(mx[k], (float)v0[k]); mx[8 + k] = fmaxf(mx[8 + k], (float)v1[k]); }
+                m0 = __builtin_elementwise_max(m0, *reinterpret_cast<const s16x8*>(tile + q * 128 + (((2 * cq) ^ f) << 4)));
+                m1 = __builtin_elementwise_max(m1, *reinterpret_cast<const s16x8*>(tile + q * 128 + (((2 * cq + 1) ^ f) << 4)));
             }
         const int oy = py0 + py, ox = px0 + px;
-        if (oy < a.hq && ox < a.wq) {
-            t8 o0, o1;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { o0[k] = (T)mx[k]; o1[k] = (T)mx[8 + k]; }
+        if (oy < a.hq && ox < a.wq && (SP_ABL != 4 || m0[0] == 12345)) {
             T* op = reinterpret_cast<T*>(a.out) + (((size_t)img * a.hq + oy) * a.wq + ox) * 64 + 16 * cq;
-            *reinterpret_cast<t8*>(op) = o0;
-            *reinterpret_cast<t8*>(op + 8) = o1;
+            *reinterpret_cast<s16x8*>(op) = m0;
+            *reinterpret_cast<s16x8*>(op + 8) = m1;
         }
+    }
+    // (no barrier here: the next tile's staging writes the PATCH, which nobody reads after the barrier in front of the pool; its conv writes
+    // the stem image only behind the next barrier, which every wave reaches after its pool reads)
     }
 }
 
@@ -206,7 +244,10 @@ static osr_status stem_pool_launch(StemPoolArgs& a, int32_t n, int32_t hp, int32
     a.wrow = w_rows;
     const long long tiles = (long long)n * a.tiles_x * a.tiles_y;
     OSR_REQUIRE(tiles < (1ll << 31), OSR_ERR_UNSUPPORTED, "osr_stem_maxpool_fwd: too many tiles");
-    const dim3 grid((unsigned)tiles), block(256);
+    a.ntiles = (int)tiles;
+    long long g = tiles < 768 ? tiles : 768;  // persistent workgroups: three per CU (51 KB of LDS each) on 256 CUs
+    if (g >= 8) g &= ~7ll;
+    const dim3 grid((unsigned)g), block(256);
 #define SP_LAUNCH(T, K) hipLaunchKernelGGL((stem_pool_kernel<T, K>), grid, block, 0, st, a)
     if (dtype == OSR_F16) { if (src_kind == 0) SP_LAUNCH(f16_t, 0); else if (src_kind == 1) SP_LAUNCH(f16_t, 1); else SP_LAUNCH(f16_t, 2); }
     else                  { if (src_kind == 0) SP_LAUNCH(bf16_t, 0); else if (src_kind == 1) SP_LAUNCH(bf16_t, 1); else SP_LAUNCH(bf16_t, 2); }
