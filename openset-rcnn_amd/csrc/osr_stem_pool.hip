@@ -53,6 +53,7 @@ template <> struct SpFrag<bf16_t> {
 #define SP_IPITCH (SP_IC * 8)          // 576 bytes
 #define SP_PATCH_BYTES (SP_IR * SP_IPITCH)                 // 13 248
 #define SP_TILE_OFF ((SP_PATCH_BYTES + 255) / 256 * 256)   // 13 312
+#define SP_NIT ((SP_IR * SP_IC + 255) / 256)                // 7 patch pixels per thread
 #define SP_LDS (SP_TILE_OFF + SP_NGRP * 16 * 128)          // + 38 912 = 52 224
 
 struct StemPoolArgs {
@@ -71,29 +72,43 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(StemPoolArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[SP_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // ---- this wave's weight fragments (A operand: lane (m = lane & 15, kg = lane >> 4) holds w[16 wid + m][ky][8 kg .. 8 kg + 7]) and biases,
-    //      loaded ONCE per workgroup: the workgroups are persistent (three per CU, each walks ~22 tiles at the bench's size) ----
+    // ---- work split inside the workgroup (round 5): wave w owns the 32 channels of half w & 1 (two 16-channel MFMA row groups) and every
+    //      second group of 16 stem pixels (w >> 1: groups 0, 2, .. 18 or 1, 3, .. 17). Until then a wave owned 16 channels over ALL pixels:
+    //      every pixel fragment was read from LDS by all four waves, and the counters (scripts/exp_stem_pmc.sh) showed the LDS pipe busy 84 %
+    //      of the kernel's cycles, 94 % of that in those reads. Two channel groups per wave halve them, within the register budget of three
+    //      waves per SIMD (all four groups per wave: 28 weight fragments + 16 biases, 190 registers).
+    //      Weight fragments (A operand): lane (m = lane & 15, kg = lane >> 4) holds w[16 cg + m][ky][8 kg .. 8 kg + 7]; loaded ONCE per
+    //      workgroup: the workgroups are persistent (three per CU, each walks ~22 tiles at the bench's size) ----
     const int m16 = lane & 15, kg = lane >> 4;
-    frag_t wf[7];
-    {
-        const T* wp = reinterpret_cast<const T*>(a.w) + (size_t)(16 * wid + m16) * a.wrow * 32 + 8 * kg;
+    const int ch = wid & 1, ph = wid >> 1;
+    frag_t wf[2][7];
+    float4 b4[2];  // the lane's D rows of group cg are channels 16 cg + 4 kg + 0..3
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky) wf[ky] = *reinterpret_cast<const frag_t*>(wp + ky * 32);
-    }
-    const float4 b4 = *reinterpret_cast<const float4*>(a.bias + 16 * wid + 4 * kg);  // the lane's D rows are channels 16 wid + 4 kg + 0..3
-    // Per pixel group, this lane's LDS offsets -- where its B fragment starts in the patch, where its four channels go in the stem image --
-    // do not depend on the tile: computed once per workgroup and kept in registers (the group loop of an interior tile is unrolled). The
-    // counters said the kernel was bound by vector-ALU issue (75 M VALU instructions per launch = 64 % of all issue cycles, the MFMAs 31 %),
-    // 40 of them per group and wave in the old loop: the pixel's row / column, both addresses and the inside-the-map test, then four adds,
-    // maxima, conversions, selects and two packs. An interior tile now spends 8: two packed adds, four maxima, two packed conversions.
-    unsigned short g_rd[SP_NGRP], g_wr[SP_NGRP];
+    for (int j = 0; j < 2; ++j) {
+        const int cg = 2 * ch + j;
+        const T* wp = reinterpret_cast<const T*>(a.w) + (size_t)(16 * cg + m16) * a.wrow * 32 + 8 * kg;
 #pragma unroll
-    for (int grp = 0; grp < SP_NGRP; ++grp) {
-        const int q = 16 * grp + m16, qc = q < SP_NPIX ? q : SP_NPIX - 1;  // (the last group's lanes past pixel 296 re-read pixel 296 and write slots the pool never reads)
-        const int r = (qc * 1986) >> 16, c = qc - r * 33;
-        g_rd[grp] = (unsigned short)((2 * r) * SP_IPITCH + (2 * c + 2 * kg) * 8);
-        g_wr[grp] = (unsigned short)(SP_TILE_OFF + q * 128 + (((2 * wid + (kg >> 1)) ^ ((c >> 1) & 7)) << 4) + (kg & 1) * 8);
+        for (int ky = 0; ky < 7; ++ky) wf[j][ky] = *reinterpret_cast<const frag_t*>(wp + ky * 32);
+        b4[j] = *reinterpret_cast<const float4*>(a.bias + 16 * cg + 4 * kg);
     }
+    // Per pixel group, this lane's LDS offsets -- where its B fragment starts in the patch, where its channels go in the stem image -- do not
+    // depend on the tile: computed once per workgroup, one packed register per group (the group loop is unrolled). The counters had shown
+    // the first bound to be vector-ALU issue (75 M VALU instructions per launch = 64 % of all issue cycles, the MFMAs 31 %): 40 per group
+    // and wave -- the pixel's row / column, both addresses, the inside-the-map test, then adds, maxima, conversions, selects, packs one value
+    // at a time. Now: three to unpack, and per channel group one address, two packed adds, four maxima, two packed conversions; the
+    // inside-the-map selects only on the tiles that touch the map's border.
+    constexpr int SP_GPW = (SP_NGRP + 1) / 2;  // 10 group slots per wave (the last one of the odd pixel half is empty)
+    unsigned g_rd[SP_GPW];  // patch offset of the lane's B fragment | row << 14 | column << 18 | (stem-image slot swizzle of the lane) << 24
+#pragma unroll
+    for (int i = 0; i < SP_GPW; ++i) {
+        const int grp = ph + 2 * i;
+        const int q = 16 * grp + m16, qc = q < SP_NPIX ? q : SP_NPIX - 1;  // (lanes past pixel 296 re-read pixel 296 and write slots the pool never reads)
+        const int r = (qc * 1986) >> 16, c = qc - r * 33;                  // qc / 33 for qc < 2048 (1986 = ceil(65536 / 33))
+        // B operand: lane (n = lane & 15 -> pixel q, kg) reads patch row 2 r + ky, pixels 2 c + 2 kg, 2 c + 2 kg + 1 (16 bytes).
+        // D: four channels (8 bytes) of pixel q go to piece 2 cg + (kg >> 1) at slot piece ^ ((c >> 1) & 7), half kg & 1
+        g_rd[i] = (unsigned)((2 * r) * SP_IPITCH + (2 * c + 2 * kg) * 8) | ((unsigned)r << 14) | ((unsigned)c << 18) | ((unsigned)(((kg >> 1) ^ (c >> 1)) & 7) << 24);
+    }
+    const unsigned wr_lane = (unsigned)(SP_TILE_OFF + m16 * 128 + (kg & 1) * 8);  // + 2048 per pixel group (wave-uniform)
 
     // XCD-aware walk: workgroup b runs on XCD b % 8 (round-robin dispatch); an XCD takes a contiguous run of tiles (row-major inside an image)
     // and its workgroups walk that run side by side -- the patch rows neighbouring tiles share hit one L2. (A grid of fewer than 8
@@ -113,30 +128,31 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(StemPoolArgs a) {
     //      the 3-pixel halo, the /32 padding and the 4th channel: the bits osr_preprocess writes, without the 139 MB round trip ----
     if constexpr (SRC != 0) {
         typedef typename std::conditional<SRC == 1, unsigned char, float>::type S;
-        const S* src = reinterpret_cast<const S*>(a.x) + (size_t)img * 3 * a.ih * a.iw;
         const size_t plane = (size_t)a.ih * a.iw;
+        const S* src0 = reinterpret_cast<const S*>(a.x) + (size_t)img * 3 * plane;  // (wave-uniform plane bases + one 32-bit offset per pixel:
+        const S* src1 = src0 + plane;                                                 //  a per-load 64-bit address costs two registers each)
+        const S* src2 = src1 + plane;
         typedef T t4 __attribute__((ext_vector_type(4)));
         const bool unit_std = a.s0 == 1.0f && a.s1 == 1.0f && a.s2 == 1.0f;  // (x / 1.0f == x exactly: both Openset yaml files; skips three divisions per pixel)
         // All of a thread's loads go out before the first is used: the rolled loop waited for its three one-byte loads in every one of its
-        // seven trips -- seven dependent round trips to L2 / HBM per tile, most of the kernel's 0.28 ms (round 5: stamps-free reading of
-        // the ISA: `s_waitcnt vmcnt(0)` inside the loop). Same values, same rounding.
-        constexpr int NIT = (SP_IR * SP_IC + 255) / 256;  // 7
-        S raw[NIT][3];
-        bool inside[NIT];
+        // seven trips -- seven dependent round trips to L2 / HBM per tile (round 5: `s_waitcnt vmcnt(0)` inside the loop). Same values, same
+        // rounding. A patch that lies inside the raw image as a whole (wave-uniform test) skips the per-pixel border tests.
+        const int yb = iy0 - 3, xb = ix0 - 3;
+        const bool whole = yb >= 0 && xb >= 0 && yb + SP_IR <= a.ih && xb + SP_IC <= a.iw;
+        S raw[SP_NIT][3];
+        bool inside[SP_NIT];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 256;
-            const int r = i / SP_IC, px = i - r * SP_IC;
-            const int y = iy0 + r - 3, x = ix0 + px - 3;
-            inside[it] = i < SP_IR * SP_IC && y >= 0 && y < a.ih && x >= 0 && x < a.iw;
-            const size_t o = inside[it] ? (size_t)y * a.iw + x : 0;
-            raw[it][0] = src[o]; raw[it][1] = src[o + plane]; raw[it][2] = src[o + 2 * plane];  // (element 0 of each plane when outside: a valid address, value unused)
+        for (int it = 0; it < SP_NIT; ++it) {
+            const int i = tid + it * 256, r = i / SP_IC, px = i - r * SP_IC;
+            const int y = yb + r, x = xb + px;
+            inside[it] = (it < SP_NIT - 1 || tid + it * 256 < SP_IR * SP_IC) && (whole || (y >= 0 && y < a.ih && x >= 0 && x < a.iw));
+            const unsigned o = inside[it] ? (unsigned)(y * a.iw + x) : 0u;  // (a plane is < 2^31 pixels: checked on the host)
+            raw[it][0] = src0[o]; raw[it][1] = src1[o]; raw[it][2] = src2[o];  // (element 0 of each plane when outside: a valid address, value unused)
         }
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 256;
-            if (i < SP_IR * SP_IC) {
-                const int r = i / SP_IC, px = i - r * SP_IC;
+        for (int it = 0; it < SP_NIT; ++it) {
+            if (it < SP_NIT - 1 || tid + it * 256 < SP_IR * SP_IC) {
+                const int i = tid + it * 256, r = i / SP_IC, px = i - r * SP_IC;
                 float v0 = 0.f, v1 = 0.f, v2 = 0.f;
                 if (inside[it]) {
                     v0 = (float)raw[it][0] - a.m0; v1 = (float)raw[it][1] - a.m1; v2 = (float)raw[it][2] - a.m2;
@@ -164,46 +180,43 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(StemPoolArgs a) {
     unsigned char* tile = lds + SP_TILE_OFF;
     // interior tile: every pixel of the 9 x 33 region lies inside the stem map (all but the top row and the left column of tiles at the bench's size)
     const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + SP_SH <= a.hs && sx0 + SP_SW <= a.ws;
-    if (interior) {
+    {
         typedef float f32x4v __attribute__((ext_vector_type(4)));
         typedef T t4 __attribute__((ext_vector_type(4)));
-        const f32x4v bv = {b4.x, b4.y, b4.z, b4.w}, zv = {0.f, 0.f, 0.f, 0.f};
+        const f32x4v zv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int grp = 0; grp < SP_NGRP; ++grp) {
-            const unsigned char* pb = lds + g_rd[grp];
+        for (int i = 0; i < SP_GPW; ++i) {
+            if (i == SP_GPW - 1 && ph + 2 * i >= SP_NGRP) break;  // (wave-uniform: the odd pixel half has nine groups)
+            unsigned rd = g_rd[i];
+            asm volatile("" : "+v"(rd));  // (opaque: the compiler otherwise hoists the unpacked fields of all ten groups out of the tile loop -- 30 registers, spills)
+            const unsigned char* pb = lds + (rd & 0x3fffu);
             frag_t xb[7];
 #pragma unroll
             for (int ky = 0; ky < 7; ++ky) xb[ky] = *reinterpret_cast<const frag_t*>(pb + ky * SP_IPITCH);
-            sp_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            sp_f32x4 acc[2];
 #pragma unroll
-            for (int ky = 0; ky < 7; ++ky) acc = SpFrag<T>::mfma(wf[ky], xb[ky], acc);
-            const f32x4v v = __builtin_elementwise_max((f32x4v)acc + bv, zv);  // (same operations, same order as below: fp32 add, fp32 max, one rounding)
-            *reinterpret_cast<t4*>(lds + g_wr[grp]) = __builtin_convertvector(v, t4);
+            for (int j = 0; j < 2; ++j) acc[j] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky)  // (kernel rows ascending per accumulator: the K order of the separate launches)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = SpFrag<T>::mfma(wf[j][ky], xb[ky], acc[j]);
+            bool in = true;
+            if (!interior) {  // (wave-uniform) pixels outside the stem map are written as 0: the pool's padding
+                const int r = (int)((rd >> 14) & 15u), c = (int)((rd >> 18) & 63u);
+                const int sy = sy0 + r, sx = sx0 + c;
+                in = sy >= 0 && sy < a.hs && sx >= 0 && sx < a.ws;
+            }
+            unsigned char* tq = lds + wr_lane + (unsigned)(ph + 2 * i) * 2048u;
+            const unsigned fk4 = (rd >> 20) & 0x70u;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4v bv = {b4[j].x, b4[j].y, b4[j].z, b4[j].w};
+                f32x4v v = __builtin_elementwise_max((f32x4v)acc[j] + bv, zv);  // fp32 add, fp32 max, one rounding: as the separate launches
+                if (!interior) v = in ? v : zv;
+                *reinterpret_cast<t4*>(tq + (((unsigned)(2 * ch + j) << 5) ^ fk4)) = __builtin_convertvector(v, t4);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // (one group's fragments at a time: hoisting the next group's reads costs the third wave per SIMD its registers)
         }
-    } else
-#pragma unroll 1
-    for (int grp = 0; grp < SP_NGRP; ++grp) {  // (two groups per turn -- two independent accumulator chains -- measured slower: 305 against 250 us)
-        const int q = 16 * grp + m16, qc = q < SP_NPIX ? q : SP_NPIX - 1;
-        const int r = (qc * 1986) >> 16;  // qc / 33 for qc < 2048 (1986 = ceil(65536 / 33))
-        const int c = qc - r * 33;
-        // B operand: lane (n = lane & 15 -> pixel q, kg) reads patch row 2 r + ky, pixels 2 c + 2 kg, 2 c + 2 kg + 1 (16 bytes)
-        const unsigned char* pb = lds + (2 * r) * SP_IPITCH + (2 * c + 2 * kg) * 8;
-        frag_t xb[7];
-#pragma unroll
-        for (int ky = 0; ky < 7; ++ky) xb[ky] = *reinterpret_cast<const frag_t*>(pb + ky * SP_IPITCH);
-        sp_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ky = 0; ky < 7; ++ky) acc = SpFrag<T>::mfma(wf[ky], xb[ky], acc);
-        const int sy = sy0 + r, sx = sx0 + c;
-        const bool in = q < SP_NPIX && sy >= 0 && sy < a.hs && sx >= 0 && sx < a.ws;
-        typedef T t4 __attribute__((ext_vector_type(4)));
-        t4 o;
-        o[0] = (T)(in ? fmaxf(acc[0] + b4.x, 0.f) : 0.f);
-        o[1] = (T)(in ? fmaxf(acc[1] + b4.y, 0.f) : 0.f);
-        o[2] = (T)(in ? fmaxf(acc[2] + b4.z, 0.f) : 0.f);
-        o[3] = (T)(in ? fmaxf(acc[3] + b4.w, 0.f) : 0.f);
-        const int piece = 2 * wid + (kg >> 1);
-        *reinterpret_cast<t4*>(tile + q * 128 + ((piece ^ ((c >> 1) & 7)) << 4) + (kg & 1) * 8) = o;
     }
     __syncthreads();
 
