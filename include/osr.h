@@ -214,6 +214,36 @@ osr_status osr_cfrpn_head_tail(const void* t, int32_t t_dtype, int64_t rows, int
  * envelope: run osr_conv2d_fwd + osr_cfrpn_head_tail instead. */
 osr_status osr_cfrpn_head_fwd(const osr_conv_params* p, const void* in, const void* weight, const float* bias,
                               const float* w_tail, const float* b_tail, float* deltas, float* ctr, void* stream);
+/* One pyramid level of a multi-level launch: a dense NHWC input (n, hi, wi, cin) of the storage dtype and where its results go. */
+typedef struct osr_conv_level {
+    const void* in;   /* (n, hi, wi, cin), dense */
+    void* out;        /* osr_conv2d_fwd_levels: (n, hi, wi, cout), dense, storage dtype. osr_cfrpn_head_fwd_levels: the hidden state
+                       * t = relu(conv + bias), (n*hi*wi, 256) rows, or NULL */
+    float* deltas;    /* osr_cfrpn_head_fwd_levels: (n*hi*wi, 4) ltrb deltas (osr_conv2d_fwd_levels: ignored) */
+    float* ctr;       /* osr_cfrpn_head_fwd_levels: (n*hi*wi) centerness */
+    const void* weight; /* the level's own (cout, kh, kw, cin) weights and (cout) fp32 bias -- the FPN has one output conv per level --, */
+    const float* bias;  /* or NULL: the shared `weight` / `bias` arguments of the call */
+    int32_t n, hi, wi;
+    int32_t reserved;
+} osr_conv_level;
+#define OSR_MAX_CONV_LEVELS 6
+/* Stride-1, same-padding K x K convolutions of ONE shape (kernel size, cin, cout) applied to several feature maps in ONE launch, each
+ * level with its own weights (osr_conv_level.weight / .bias) or the shared `weight` / `bias` (may be NULL when every level brings its
+ * own): [d2] FPN.forward's `output_conv(prev_features)` per level (the backbone build_resnet_fpn_backbone selected by
+ * /root/reference/configs/Base-RCNN-FPN.yaml:3-8). p gives kh == kw (odd), pad == kh / 2, stride 1, cin, cout (multiple of 256),
+ * dtypes (f16 / bf16 in and out) and relu; its n / hi / wi / ho / wo / strides / residual fields are ignored: every level is a dense
+ * tensor described by its osr_conv_level. Outputs are bit-identical to osr_conv2d_fwd per level whenever that picks its 256 x 256 tile
+ * (and equal within fp32 summation order otherwise: the split-K tail of a single-level launch adds its K ranges separately).
+ * Why: at batch 16 the levels p2..p5 are 4200 + 1050 + 263 + 66 tiles of 256 x 256 rows x channels; launched one by one each level pays
+ * its own partial last dispatch round on 256 CUs and the small levels leave most of the chip idle; one grid pays one. */
+osr_status osr_conv2d_fwd_levels(const osr_conv_params* p, int32_t nlevels, const osr_conv_level* levels, const void* weight,
+                                 const float* bias, void* stream);
+/* ClsFreeRPNHead.forward over ALL pyramid levels in ONE launch (classification_free_rpn.py:157-161: `for x in features:` applies the
+ * same conv / anchor_deltas / centerness weights to every level): osr_cfrpn_head_fwd's fused kernel on the 256-row tile with a level
+ * table. Same envelope as osr_cfrpn_head_fwd (cout == 256, cin %% 64 == 0, >= 8 K slices); bit-identical to it per level whenever it
+ * runs its 256-row tile (levels of >= 512 tiles), equal within fp32 summation order to its 128-row tile otherwise. */
+osr_status osr_cfrpn_head_fwd_levels(const osr_conv_params* p, int32_t nlevels, const osr_conv_level* levels, const void* weight,
+                                     const float* bias, const float* w_tail, const float* b_tail, void* stream);
 /* The same, also writing the hidden state t = relu(conv + bias) in the storage dtype, (n*ho*wo, 256) rows (hidden_out may be
  * NULL): the training step keeps it for the head's backward (osr_cfrpn_tail_bwd, the 3x3 conv's weight gradient) instead of
  * running the un-fused pair that writes t and reads it back. */

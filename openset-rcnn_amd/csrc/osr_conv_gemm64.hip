@@ -62,11 +62,12 @@ __device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv& f) {
 // row index -> image, output row, output column
 #define C64_ROW_TO_NHW(m_, nimg_, oh_, ow_)                          \
     const unsigned mu_##nimg_ = (unsigned)(m_);                      \
-    const int nimg_ = (int)fastdiv(mu_##nimg_, a.div_howo);          \
-    const unsigned rem_##nimg_ = mu_##nimg_ - (unsigned)nimg_ * a.div_howo.d; \
-    const int oh_ = (int)fastdiv(rem_##nimg_, a.div_wo);             \
-    const int ow_ = (int)(rem_##nimg_ - (unsigned)oh_ * a.div_wo.d);
+    const int nimg_ = (int)fastdiv(mu_##nimg_, e_div_howo);          \
+    const unsigned rem_##nimg_ = mu_##nimg_ - (unsigned)nimg_ * e_div_howo.d; \
+    const int oh_ = (int)fastdiv(rem_##nimg_, e_div_wo);             \
+    const int ow_ = (int)(rem_##nimg_ - (unsigned)oh_ * e_div_wo.d);
 
+#define C64_MAX_LEVELS 6
 struct Conv64Args {
     osr_conv_params p;
     const void* in;
@@ -100,6 +101,19 @@ struct Conv64Args {
     int cout3;
     unsigned w3_bytes, out_bytes;  // buffer sizes of w3 and of out / res (dense rows of cout3 elements)
     void* mid_out;         // nullable: the parked relu(conv + bias) tile also goes to HBM, dense (rows, 128): the training step keeps it for the backward
+    // Multi-level launch (osr_conv2d_fwd_levels / osr_cfrpn_head_fwd_levels: the 256 x 256 8-phase instantiations only): the same
+    // convolution over several dense NHWC inputs -- the FPN output convs, the CF-RPN head over p2..p6 -- as ONE grid. The M tiles of
+    // level l are the linear tiles [lv[l].tile_begin, lv[l + 1].tile_begin); a workgroup looks its level up and takes the fields below
+    // from it instead of from the single-problem fields above. nlevels == 0: a single problem.
+    int nlevels = 0;
+    struct Level {
+        const void* in; void* out; float* tail_deltas; float* tail_ctr;
+        const void* w; const float* bias;  // the level's own weights / bias (the FPN's output convs), or the shared ones
+        long long M, in_stride_n, in_stride_h, out_stride_n, out_stride_h;
+        int tile_begin, hi, wi;
+        unsigned in_bytes;
+        FastDiv div_howo, div_wo;
+    } lv[C64_MAX_LEVELS];
 #ifdef C64_STAMPS
     unsigned long long* dbg;
     unsigned long long* p8;
@@ -167,6 +181,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // max(stages * STAGE, EPI_BYTES), see conv64_launch
 
     typedef typename Frag64<TI>::type frag_t;
+    constexpr bool PH8 = (TWO == 2);  // the 8-phase K loop (below)
     const osr_conv_params& p = a.p;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -182,11 +197,34 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
     }
     int ksp = 0;  // which K range of the tile (split-K tail launches only)
     if constexpr (SPLIT) { ksp = t / a.ntile; t = a.tile0 + t % a.ntile; }
-    const int tile_n = t % a.tiles_n, tile_m = t / a.tiles_n;
+    const int tile_n = t % a.tiles_n;
+    int tile_m = t / a.tiles_n;
+    // the level-dependent fields of the problem (wave-uniform: scalar registers)
+    long long e_M = a.M, e_isn = p.in_stride_n, e_ish = p.in_stride_h, e_osn = p.out_stride_n, e_osh = p.out_stride_h;
+    const void* e_in = a.in;
+    const void* e_w = a.w;
+    const float* e_bias = a.bias;
+    void* e_out = a.out;
+    float* e_tail_deltas = a.tail_deltas;
+    float* e_tail_ctr = a.tail_ctr;
+    int e_hi = p.hi, e_wi = p.wi;
+    unsigned e_in_bytes = a.in_bytes;
+    FastDiv e_div_howo = a.div_howo, e_div_wo = a.div_wo;
+    if constexpr (PH8 && SPLIT == 0) {
+        if (a.nlevels > 0) {
+            int l = 0;
+            for (int i = 1; i < a.nlevels; ++i) l = tile_m >= a.lv[i].tile_begin ? i : l;
+            const Conv64Args::Level& L = a.lv[l];
+            e_M = L.M; e_isn = L.in_stride_n; e_ish = L.in_stride_h; e_osn = L.out_stride_n; e_osh = L.out_stride_h;
+            e_in = L.in; e_w = L.w; e_bias = L.bias; e_out = L.out; e_tail_deltas = L.tail_deltas; e_tail_ctr = L.tail_ctr;
+            e_hi = L.hi; e_wi = L.wi; e_in_bytes = L.in_bytes; e_div_howo = L.div_howo; e_div_wo = L.div_wo;
+            tile_m -= L.tile_begin;
+        }
+    }
     const long long m0 = (long long)tile_m * BM;
     const int n0 = tile_n * BN;
     if (p.row_seg_counts) {  // segmented rows (padded per-image lists): a tile without a single data row has nothing to do (wave-uniform)
-        const long long sr = p.row_seg_rows, mend = m0 + BM < a.M ? m0 + BM : a.M;
+        const long long sr = p.row_seg_rows, mend = m0 + BM < e_M ? m0 + BM : e_M;
         bool any = false;
         for (long long sg = m0 / sr; sg * sr < mend; ++sg) {
             const long long lo = m0 > sg * sr ? m0 : sg * sr, hi = sg * sr + p.row_seg_counts[sg];
@@ -195,8 +233,8 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
         if (!any) return;
     }
 
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, a.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(e_in), 0, e_in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(e_w), 0, a.w_bytes, 0x00020000);
 
     // ---- per-lane gather descriptors: this lane serves row (piece*8 + lane/8), LDS slot lane%8.
     //      a_off0 = byte offset of element (n, ih0, iw0, chunk) -- wraps below zero where the window starts in the padding --
@@ -207,7 +245,6 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
     // TWO == 2 (the 8-phase K loop below): the 256 x 256 tile is staged in four UNITS of 16 pieces, the rows that one phase's fragment reads
     // cover: activation rows of row half qa of both wave rows, weight rows of column half qb of all four wave columns; a wave issues
     // two pieces of every unit (descriptor j = 2 q + jj). Otherwise a wave's pieces are consecutive.
-    constexpr bool PH8 = (TWO == 2);
     static_assert(!PH8 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && EPI != 2), "8-phase K loop: 256 x 256 tile, 2 x 4 waves");
     auto a_piece = [&](int j) -> int {
         if constexpr (PH8) { const int lp = wid * 2 + (j & 1); return (lp >> 3) * 16 + (j >> 1) * 8 + (lp & 7); }
@@ -222,21 +259,21 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
     for (int j = 0; j < A_PIECES; ++j) {
         const int row = a_piece(j) * 8 + lrow;
         const long long m = m0 + row;
-        const bool ok = m < a.M;
+        const bool ok = m < e_M;
         const long long mm = ok ? m : 0;
         C64_ROW_TO_NHW(mm, nimg, oh, ow);
         const int ih0 = oh * p.stride_h - p.pad_h, iw0 = ow * p.stride_w - p.pad_w;
         const int chunk = slot ^ ((row >> 1) & 7);
         // stem view: two 32-wide taps per K slice, chunks 0-3 -> tap kh, 4-7 -> tap kh+1
-        const long long coff = a.stem ? (long long)(chunk >> 2) * p.in_stride_h + (chunk & 3) * 8 : (long long)chunk * 8;
-        a_off0[j] = (unsigned)(((long long)nimg * p.in_stride_n + (long long)ih0 * p.in_stride_h + (long long)iw0 * p.in_stride_w + coff) * 2);
+        const long long coff = a.stem ? (long long)(chunk >> 2) * e_ish + (chunk & 3) * 8 : (long long)chunk * 8;
+        a_off0[j] = (unsigned)(((long long)nimg * e_isn + (long long)ih0 * e_ish + (long long)iw0 * p.in_stride_w + coff) * 2);
         unsigned mk = 0x7fffffffu;
         if (p.pad_mode == 0) {
-            const int wlo = iw0 < 0 ? -iw0 : 0, whi = p.wi - iw0 < p.kw ? p.wi - iw0 : p.kw;
+            const int wlo = iw0 < 0 ? -iw0 : 0, whi = e_wi - iw0 < p.kw ? e_wi - iw0 : p.kw;
             const unsigned wm = whi > wlo ? ((1u << whi) - 1u) & ~((1u << wlo) - 1u) : 0u;
             mk = 0u;
             for (int t = 0; t < p.kh; ++t)
-                if ((unsigned)(ih0 + t) < (unsigned)p.hi) mk |= wm << (t * p.kw);
+                if ((unsigned)(ih0 + t) < (unsigned)e_hi) mk |= wm << (t * p.kw);
         }
         a_mask[j] = ok ? mk : 0u;
     }
@@ -281,18 +318,18 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
     // per XCD later). The weight rows stay [kh][kw][cin]: only the scalar offset sequence of the B loads changes.
 #define C64_ADVANCE()                                                                                 \
     {                                                                                                 \
-        if (a.stem) { kbyte += 128; kh += 2; tap_off = (unsigned)(kh * p.in_stride_h * 2); }          \
+        if (a.stem) { kbyte += 128; kh += 2; tap_off = (unsigned)(kh * e_ish * 2); }          \
         else if (a.tap_minor) {                                                                       \
             if (++kw >= p.kw) { kw = 0; if (++kh >= p.kh) { kh = 0; c0 += 64; } }                     \
             tap = kh * p.kw + kw;                                                                     \
-            tap_off = (unsigned)((kh * p.in_stride_h + kw * p.in_stride_w + c0) * 2);                 \
+            tap_off = (unsigned)((kh * e_ish + kw * p.in_stride_w + c0) * 2);                 \
             kbyte = (tap * p.cin + c0) * 2;                                                           \
         } else {                                                                                      \
             kbyte += 128;                                                                             \
             c0 += 64;                                                                                 \
             if (c0 >= p.cin) { c0 = 0; if (++kw >= p.kw) { kw = 0; ++kh; } }                          \
             tap = kh * p.kw + kw;                                                                     \
-            tap_off = (unsigned)((kh * p.in_stride_h + kw * p.in_stride_w + c0) * 2);                 \
+            tap_off = (unsigned)((kh * e_ish + kw * p.in_stride_w + c0) * 2);                 \
         }                                                                                             \
     }
 
@@ -315,7 +352,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
         const int taps = p.kh * p.kw, spt = p.cin / 64;  // taps; channel slices per tap
         const int tp = a.tap_minor ? k_lo % taps : k_lo / spt, cs = a.tap_minor ? k_lo / taps : k_lo % spt;
         kh = tp / p.kw; kw = tp - kh * p.kw; c0 = cs * 64; tap = tp;
-        tap_off = (unsigned)((kh * p.in_stride_h + kw * p.in_stride_w + c0) * 2);
+        tap_off = (unsigned)((kh * e_ish + kw * p.in_stride_w + c0) * 2);
         kbyte = (tap * p.cin + c0) * 2;
         nk = k_hi - k_lo;
     }
@@ -337,8 +374,8 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
             const int co = n0 + (wc * TN + jp * 2) * 32 + cseg;
             const int cb = co < p.cout ? co : 0;
             const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 b0 = SPLIT ? zero4 : *reinterpret_cast<const float4*>(a.bias + cb);
-            const float4 b1 = SPLIT ? zero4 : *reinterpret_cast<const float4*>(a.bias + cb + 4);
+            const float4 b0 = SPLIT ? zero4 : *reinterpret_cast<const float4*>(e_bias + cb);
+            const float4 b1 = SPLIT ? zero4 : *reinterpret_cast<const float4*>(e_bias + cb + 4);
             bias8[jp][0] = b0.x; bias8[jp][1] = b0.y; bias8[jp][2] = b0.z; bias8[jp][3] = b0.w;
             bias8[jp][4] = b1.x; bias8[jp][5] = b1.y; bias8[jp][6] = b1.z; bias8[jp][7] = b1.w;
         }
@@ -350,7 +387,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
 #pragma unroll
                     for (int pass = 0; pass < NPASS; ++pass) {
                         const long long m = m0 + (wr * TM + i) * 32 + pass * RPP + (lane >> 3);
-                        const bool ok = m < a.M && co < p.cout;
+                        const bool ok = m < e_M && co < p.cout;
                         const long long mm = ok ? m : 0;
                         C64_ROW_TO_NHW(mm, nimg, oh, ow);
                         const int rh = p.res_mode == 2 ? (oh >> 1) : oh, rw = p.res_mode == 2 ? (ow >> 1) : ow;
@@ -364,7 +401,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
     if constexpr (EPI == 2) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const float* bp = a.bias + (wc * TN + j) * 32 + (lane >> 4) * 8;
+            const float* bp = e_bias + (wc * TN + j) * 32 + (lane >> 4) * 8;
             const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
             cb2[j][0] = b0.x; cb2[j][1] = b0.y; cb2[j][2] = b0.z; cb2[j][3] = b0.w;
             cb2[j][4] = b1.x; cb2[j][5] = b1.y; cb2[j][6] = b1.z; cb2[j][7] = b1.w;
@@ -377,8 +414,8 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
         for (int i = tid; i < 5 * 256; i += NT) s_tw[i] = a.tail_w[i];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            tbias[j][0] = a.bias[(wc * TN + j) * 32 + C64_COL(0)];
-            tbias[j][1] = a.bias[(wc * TN + j) * 32 + C64_COL(4)];
+            tbias[j][0] = e_bias[(wc * TN + j) * 32 + C64_COL(0)];
+            tbias[j][1] = e_bias[(wc * TN + j) * 32 + C64_COL(4)];
         }
     }
     // 16x16x32: a fragment = 16 rows x 32 K; lane l holds row l&15, K chunk (l>>4) of the 32-wide step.
@@ -678,12 +715,12 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
                     *reinterpret_cast<frag_t*>(lds + CH_A + wc * CH_SL + r * 128 + ((chunk ^ ((r >> 1) & 7)) << 4)) = t;
                     if (a.mid_out) {  // (uniform) the same eight channels of pixel m0 + r, as the separate launch would have written them
                         const long long m = m0 + r;
-                        if (m < a.M) *reinterpret_cast<frag_t*>(reinterpret_cast<TI*>(a.mid_out) + m * 128 + wc * 64 + chunk * 8) = t;
+                        if (m < e_M) *reinterpret_cast<frag_t*>(reinterpret_cast<TI*>(a.mid_out) + m * 128 + wc * 64 + chunk * 8) = t;
                     }
                 }
         const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w3), 0, a.w3_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res), 0, a.out_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(e_out, 0, a.out_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_b3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias3), 0, (unsigned)a.cout3 * 4u, 0x00020000);
         unsigned w3_off[CH_PW];  // this lane's share of a stage: pieces wid * CH_PW + j of 16 (piece = K half (pc >> 3), rows (pc & 7) * 8 ..)
 #pragma unroll
@@ -698,7 +735,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
 #pragma unroll
             for (int si = 0; si < 2; ++si) {
                 const long long m = m0 + (wr * TM + i) * 32 + si * 16 + l15;
-                o_off[i][si] = m < a.M ? (unsigned)((m * a.cout3 + wc * 32 + g * 8) * 2) : OOB_OFF;
+                o_off[i][si] = m < e_M ? (unsigned)((m * a.cout3 + wc * 32 + g * 8) * 2) : OOB_OFF;
             }
         const unsigned b3_off = (unsigned)((wc * 32 + g * 8) * 4);
         FU rr[3][TM][2];
@@ -824,12 +861,12 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
                     if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // a few accumulators at a time: keeps the VGPR budget of the K loop
                 }
         __syncthreads();
-        if (a.out) {  // the training step keeps the hidden state for the head's backward: the tile's rows, 16 bytes per thread and store
-            TI* __restrict__ tout = reinterpret_cast<TI*>(a.out);
+        if (e_out) {  // the training step keeps the hidden state for the head's backward: the tile's rows, 16 bytes per thread and store
+            TI* __restrict__ tout = reinterpret_cast<TI*>(e_out);
             for (int q = tid; q < BM * 32; q += NT) {
                 const int row = q >> 5, ch8 = (q & 31) * 8;
                 const long long m = m0 + row;
-                if (m < a.M) *reinterpret_cast<frag_t*>(tout + m * 256 + ch8) = *reinterpret_cast<const frag_t*>(s_t + row * LDT + ch8);
+                if (m < e_M) *reinterpret_cast<frag_t*>(tout + m * 256 + ch8) = *reinterpret_cast<const frag_t*>(s_t + row * LDT + ch8);
             }
         }
         const float* s_tw = reinterpret_cast<const float*>(lds + a.tail_lds_off);
@@ -852,11 +889,11 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
 #pragma unroll
         for (int q = 0; q < 5; ++q) d[q] += __shfl_xor(d[q], 1, 64);
         const long long m = m0 + row;
-        if (hf == 0 && m < a.M) {
+        if (hf == 0 && m < e_M) {
             const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-            *reinterpret_cast<float4*>(a.tail_deltas + m * 4) = make_float4(d[0] * inv + a.tail_b[0], d[1] * inv + a.tail_b[1],
+            *reinterpret_cast<float4*>(e_tail_deltas + m * 4) = make_float4(d[0] * inv + a.tail_b[0], d[1] * inv + a.tail_b[1],
                                                                             d[2] * inv + a.tail_b[2], d[3] * inv + a.tail_b[3]);
-            a.tail_ctr[m] = 1.0f / (1.0f + expf(-(d[4] * inv + a.tail_b[4])));
+            e_tail_ctr[m] = 1.0f / (1.0f + expf(-(d[4] * inv + a.tail_b[4])));
         }
         return;
     }
@@ -864,7 +901,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
     // ---- epilogue: wave-private fp32 slab (32 rows x 64 columns, one pair of N tiles at a time) -> 8 channels per lane:
     //      bias + residual / FPN 2x upsample-add + ReLU + convert on 16-byte row segments, coalesced along channels ----
     float* slab = reinterpret_cast<float*>(lds) + wid * 32 * EPI_LD;
-    TO* __restrict__ out = reinterpret_cast<TO*>(a.out) + (SPLIT ? (long long)ksp * a.split_stride : 0ll);
+    TO* __restrict__ out = reinterpret_cast<TO*>(e_out) + (SPLIT ? (long long)ksp * a.split_stride : 0ll);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -882,7 +919,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
             for (int pass = 0; pass < NPASS; ++pass) {
                 const int row = pass * RPP + (lane >> 3);
                 const long long m = m0 + (wr * TM + i) * 32 + row;
-                if (m < a.M && co < p.cout) {
+                if (m < e_M && co < p.cout) {
                     const float4 v0 = *reinterpret_cast<const float4*>(slab + row * EPI_LD + cseg);
                     const float4 v1 = *reinterpret_cast<const float4*>(slab + row * EPI_LD + cseg + 4);
                     float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -911,12 +948,12 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
                         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                     }
                     if (a.mask) {
-                        const frag_t mv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const TI*>(a.mask) + (long long)nimg * p.out_stride_n +
-                                                                          (long long)oh * p.out_stride_h + (long long)ow * p.out_stride_w + co);
+                        const frag_t mv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const TI*>(a.mask) + (long long)nimg * e_osn +
+                                                                          (long long)oh * e_osh + (long long)ow * p.out_stride_w + co);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = (float)mv[e] > 0.f ? v[e] : 0.f;
                     }
-                    store8_64<TO>(out + (long long)nimg * p.out_stride_n + (long long)oh * p.out_stride_h + (long long)ow * p.out_stride_w + co, v);
+                    store8_64<TO>(out + (long long)nimg * e_osn + (long long)oh * e_osh + (long long)ow * p.out_stride_w + co, v);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -1308,6 +1345,123 @@ extern "C" osr_status osr_cfrpn_head_fwd_ex(const osr_conv_params* p, const void
 #endif
     hipStream_t st = (hipStream_t)stream;
     return p->in_dtype == OSR_F16 ? cfrpn_fused_launch<f16_t>(a, st) : cfrpn_fused_launch<bf16_t>(a, st);
+}
+
+// ---- multi-level launches (include/osr.h: osr_conv2d_fwd_levels, osr_cfrpn_head_fwd_levels) ------------------------------------
+// The FPN's output convolutions ([d2] FPN.forward: `output_conv(prev_features)` per level, selected by Base-RCNN-FPN.yaml:3-8) and
+// ClsFreeRPNHead.forward's `for x in features` (classification_free_rpn.py:157-161) apply ONE set of weights to every pyramid level.
+// As separate launches the small levels leave most of the chip idle and every level pays its own partial last dispatch round
+// (at batch 16: p2 4200 tiles of 256 x 256 = 16.4 rounds, p3 1050 = 4.1, p4 263 = 1.03, p5 66, p6 18: 25 tile times); as one
+// grid of 5597 tiles it is 21.9 rounds. Every tile runs the very code of the single-level launch on its level's fields: outputs
+// are bit-identical to the per-level launches on the 256 x 256 tile.
+static osr_status conv64_fill_levels(Conv64Args& a, const osr_conv_params* p, int32_t nlevels, const osr_conv_level* levels, bool head, const char* who) {
+    OSR_REQUIRE(nlevels >= 1 && nlevels <= C64_MAX_LEVELS && levels, OSR_ERR_INVALID_ARG, "%s: 1..%d levels", who, C64_MAX_LEVELS);
+    OSR_REQUIRE(p->stride_h == 1 && p->stride_w == 1 && p->kh == p->kw && (p->kh & 1) && p->pad_h == p->kh / 2 && p->pad_w == p->kw / 2 && p->pad_mode == 0 &&
+                    p->res_mode == 0 && !p->row_seg_counts, OSR_ERR_UNSUPPORTED, "%s: stride-1 same-padding convolution without residual / row segments", who);
+    OSR_REQUIRE(p->cout % 256 == 0 && p->cin % 64 == 0 && p->kh * p->kw <= 31 && p->kh * p->kw * p->cin / 64 >= 2, OSR_ERR_UNSUPPORTED,
+                "%s: cout %% 256 == 0, cin %% 64 == 0, at least two 64-wide K slices", who);
+    long long tiles = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        const osr_conv_level& v = levels[l];
+        OSR_REQUIRE(v.in && v.n >= 1 && v.hi >= 1 && v.wi >= 1, OSR_ERR_INVALID_ARG, "%s: level %d: null input or bad size", who, l);
+        OSR_REQUIRE(head ? (v.deltas && v.ctr) : v.out != nullptr, OSR_ERR_INVALID_ARG, "%s: level %d: null output", who, l);
+        OSR_REQUIRE((((uintptr_t)v.in | (uintptr_t)v.out | (uintptr_t)v.deltas) & 15) == 0, OSR_ERR_INVALID_ARG, "%s: level %d: pointers must be 16-byte aligned", who, l);
+        const long long rows = (long long)v.n * v.hi * v.wi, in_bytes = rows * p->cin * 2;
+        OSR_REQUIRE(rows < (1ll << 31) - 1024 && in_bytes < (1ll << 31) - 4096, OSR_ERR_UNSUPPORTED, "%s: level %d too large for 32-bit buffer offsets", who, l);
+        Conv64Args::Level& L = a.lv[l];
+        L.in = v.in; L.out = v.out; L.tail_deltas = v.deltas; L.tail_ctr = v.ctr;
+        OSR_REQUIRE((v.weight || a.w) && (v.bias || a.bias), OSR_ERR_INVALID_ARG, "%s: level %d: no weight / bias (neither its own nor a shared one)", who, l);
+        OSR_REQUIRE((((uintptr_t)v.weight | (uintptr_t)v.bias) & 15) == 0, OSR_ERR_INVALID_ARG, "%s: level %d: pointers must be 16-byte aligned", who, l);
+        L.w = v.weight ? v.weight : a.w; L.bias = v.bias ? v.bias : a.bias;
+        L.M = rows; L.hi = v.hi; L.wi = v.wi; L.in_bytes = (unsigned)in_bytes;
+        L.in_stride_h = (long long)v.wi * p->cin; L.in_stride_n = (long long)v.hi * L.in_stride_h;
+        L.out_stride_h = (long long)v.wi * p->cout; L.out_stride_n = (long long)v.hi * L.out_stride_h;
+        L.div_howo = fastdiv_make((unsigned)(v.hi * v.wi)); L.div_wo = fastdiv_make((unsigned)v.wi);
+        L.tile_begin = (int)tiles;
+        tiles += (rows + 255) / 256;
+        OSR_REQUIRE(tiles * (p->cout / 256) < (1ll << 30), OSR_ERR_UNSUPPORTED, "%s: too many tiles", who);
+    }
+    a.nlevels = nlevels;
+    a.tiles_m = (int)tiles;
+    return OSR_OK;
+}
+
+extern "C" osr_status osr_conv2d_fwd_levels(const osr_conv_params* p, int32_t nlevels, const osr_conv_level* levels, const void* weight, const float* bias,
+                                            void* stream) {
+    OSR_REQUIRE(p, OSR_ERR_INVALID_ARG, "osr_conv2d_fwd_levels: null pointer");
+    OSR_REQUIRE((p->in_dtype == OSR_F16 || p->in_dtype == OSR_BF16) && p->out_dtype == p->in_dtype, OSR_ERR_UNSUPPORTED, "osr_conv2d_fwd_levels: f16 / bf16 storage in and out");
+    OSR_REQUIRE((((uintptr_t)weight | (uintptr_t)bias) & 15) == 0, OSR_ERR_INVALID_ARG, "osr_conv2d_fwd_levels: pointers must be 16-byte aligned");
+    Conv64Args a;
+    a.p = *p; a.p.in_stride_w = p->cin; a.p.out_stride_w = p->cout;
+    a.in = nullptr; a.w = weight; a.bias = bias; a.res = nullptr; a.mask = nullptr; a.out = nullptr;
+    a.M = 0; a.K = p->kh * p->kw * p->cin;
+    a.div_howo = a.div_wo = fastdiv_make(1u);
+    a.in_bytes = 0; a.w_bytes = (unsigned)((long long)p->cout * a.K * 2);
+    OSR_REQUIRE((long long)p->cout * a.K * 2 < (1ll << 31) - 4096, OSR_ERR_UNSUPPORTED, "osr_conv2d_fwd_levels: weights too large for 32-bit buffer offsets");
+    a.stem = 0; a.tap_minor = p->kh * p->kw > 1 ? tap_minor_default() : 0;
+    a.tail_w = a.tail_b = nullptr; a.tail_deltas = a.tail_ctr = nullptr;
+    a.w3 = nullptr; a.bias3 = nullptr; a.cout3 = 0; a.w3_bytes = a.out_bytes = 0;
+    a.tail_lds_off = 0;
+#ifdef C64_STAMPS
+    a.dbg = nullptr; a.p8 = nullptr;
+#endif
+    const osr_status s = conv64_fill_levels(a, p, nlevels, levels, false, "osr_conv2d_fwd_levels");
+    if (s != OSR_OK) return s;
+    a.tiles_n = p->cout / 256;
+    a.tile0 = 0; a.ntile = a.tiles_m * a.tiles_n; a.ksplit = 1; a.split_stride = 0;
+    a.two_stage = 2;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = conv64_lds_bytes(256, 256, 2, 8);
+    static osr_dev_mask attr{0};
+    osr_once_per_device(attr, [] {
+        allow_big_lds(conv_igemm64_kernel<f16_t, f16_t, 256, 256, 2, 4, 0, 2, 0>);
+        allow_big_lds(conv_igemm64_kernel<bf16_t, bf16_t, 256, 256, 2, 4, 0, 2, 0>);
+    });
+    if (p->in_dtype == OSR_F16) hipLaunchKernelGGL((conv_igemm64_kernel<f16_t, f16_t, 256, 256, 2, 4, 0, 2, 0>), dim3((unsigned)a.ntile), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((conv_igemm64_kernel<bf16_t, bf16_t, 256, 256, 2, 4, 0, 2, 0>), dim3((unsigned)a.ntile), dim3(512), lds, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { osr_set_error("osr_conv2d_fwd_levels: launch failed: %s", hipGetErrorString(e)); return OSR_ERR_LAUNCH; }
+    return OSR_OK;
+}
+
+template <class TI>
+static osr_status cfrpn_levels_launch(Conv64Args& a, hipStream_t st) {
+    a.two_stage = 1;
+    a.tiles_n = 1; a.tile0 = 0; a.ntile = a.tiles_m; a.ksplit = 1; a.split_stride = 0;
+    const size_t t_bytes = (size_t)256 * (256 + 8) * 2, stages = (size_t)2 * (256 + 256) * 128;
+    a.tail_lds_off = (int)(t_bytes > stages ? t_bytes : stages);
+    const size_t lds = (size_t)a.tail_lds_off + 5 * 256 * 4;
+    static osr_dev_mask attr{0};
+    osr_once_per_device(attr, [] { allow_big_lds(conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1, 2>); });
+    hipLaunchKernelGGL((conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1, 2>), dim3((unsigned)a.tiles_m), dim3(512), lds, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { osr_set_error("osr_cfrpn_head_fwd_levels: launch failed: %s", hipGetErrorString(e)); return OSR_ERR_LAUNCH; }
+    return OSR_OK;
+}
+
+extern "C" osr_status osr_cfrpn_head_fwd_levels(const osr_conv_params* p, int32_t nlevels, const osr_conv_level* levels, const void* weight, const float* bias,
+                                                const float* w_tail, const float* b_tail, void* stream) {
+    OSR_REQUIRE(p && weight && bias && w_tail && b_tail, OSR_ERR_INVALID_ARG, "osr_cfrpn_head_fwd_levels: null pointer");
+    OSR_REQUIRE(p->in_dtype == OSR_F16 || p->in_dtype == OSR_BF16, OSR_ERR_UNSUPPORTED, "osr_cfrpn_head_fwd_levels: in_dtype must be f16/bf16");
+    OSR_REQUIRE(p->cout == 256, OSR_ERR_UNSUPPORTED, "osr_cfrpn_head_fwd_levels: cout must be 256");
+    OSR_REQUIRE((((uintptr_t)weight | (uintptr_t)bias) & 15) == 0, OSR_ERR_INVALID_ARG, "osr_cfrpn_head_fwd_levels: pointers must be 16-byte aligned");
+    Conv64Args a;
+    a.p = *p; a.p.in_stride_w = p->cin; a.p.out_stride_w = p->cout;
+    a.in = nullptr; a.w = weight; a.bias = bias; a.res = nullptr; a.mask = nullptr; a.out = nullptr;
+    a.M = 0; a.K = p->kh * p->kw * p->cin;
+    a.div_howo = a.div_wo = fastdiv_make(1u);
+    a.in_bytes = 0; a.w_bytes = (unsigned)((long long)p->cout * a.K * 2);
+    a.stem = 0; a.tap_minor = p->kh * p->kw > 1 ? tap_minor_default() : 0;
+    a.tail_w = w_tail; a.tail_b = b_tail; a.tail_deltas = a.tail_ctr = nullptr;
+    a.w3 = nullptr; a.bias3 = nullptr; a.cout3 = 0; a.w3_bytes = a.out_bytes = 0;
+#ifdef C64_STAMPS
+    a.dbg = nullptr; a.p8 = nullptr;
+#endif
+    const osr_status s = conv64_fill_levels(a, p, nlevels, levels, true, "osr_cfrpn_head_fwd_levels");
+    if (s != OSR_OK) return s;
+    OSR_REQUIRE(a.K / 64 >= 8, OSR_ERR_UNSUPPORTED, "osr_cfrpn_head_fwd_levels: at least eight K slices");
+    hipStream_t st = (hipStream_t)stream;
+    return p->in_dtype == OSR_F16 ? cfrpn_levels_launch<f16_t>(a, st) : cfrpn_levels_launch<bf16_t>(a, st);
 }
 
 // A bottleneck's conv2 -> conv3 in one launch (include/osr.h: osr_conv2d_chain_fwd):

@@ -38,6 +38,15 @@ class ConvParams(C.Structure):
     ]
 
 
+class ConvLevel(C.Structure):
+    """include/osr.h osr_conv_level: one pyramid level of a multi-level launch."""
+    _fields_ = [("in_", C.c_void_p), ("out", C.c_void_p), ("deltas", C.c_void_p), ("ctr", C.c_void_p), ("weight", C.c_void_p), ("bias", C.c_void_p),
+                ("n", C.c_int32), ("hi", C.c_int32), ("wi", C.c_int32), ("reserved", C.c_int32)]
+
+
+MAX_CONV_LEVELS = 6
+
+
 class BottleneckParams(C.Structure):
     _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin", C.c_int32), ("cmid", C.c_int32), ("cout", C.c_int32),
                 ("dtype", C.c_int32), ("has_proj", C.c_int32)]
@@ -105,6 +114,8 @@ PROTOTYPES = {
     "osr_cfrpn_head_tail": (I32, [P, I32, I64, I32, P, P, P, P, P, P, P]),
     "osr_cfrpn_head_fwd": (I32, [C.POINTER(ConvParams), P, P, P, P, P, P, P, P]),
     "osr_cfrpn_head_fwd_ex": (I32, [C.POINTER(ConvParams), P, P, P, P, P, P, P, P, P]),
+    "osr_conv2d_fwd_levels": (I32, [C.POINTER(ConvParams), I32, C.POINTER(ConvLevel), P, P, P]),
+    "osr_cfrpn_head_fwd_levels": (I32, [C.POINTER(ConvParams), I32, C.POINTER(ConvLevel), P, P, P, P, P]),
     "osr_rpn_select_capacity": (I32, [C.POINTER(RpnLevels), I32]),
     "osr_rpn_select_workspace_bytes": (I64, [C.POINTER(RpnLevels), I32, I32]),
     "osr_rpn_select": (I32, [C.POINTER(RpnLevels), P, P, P, I32, P, I32, F32, P, P, P, P, P, P, P, I64, P]),

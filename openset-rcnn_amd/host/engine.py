@@ -117,6 +117,9 @@ class OpensetRCNNEngine:
         self.chain_res3 = dtype != torch.float32
         # the stem's convolution, ReLU and max pool run as ONE launch (osr_stem_maxpool_fwd): fp16 / bf16 storage only
         self.fuse_stem = dtype != torch.float32
+        # the FPN's four output convs run as ONE launch, and so does the CF-RPN head over p2..p6 (osr_conv2d_fwd_levels,
+        # osr_cfrpn_head_fwd_levels: a level table in the 256 x 256 kernel): fp16 / bf16 storage only
+        self.fuse_levels = dtype != torch.float32
         self._init_rpn(params)
         self._init_roi_heads(params)
 
@@ -279,11 +282,15 @@ class OpensetRCNNEngine:
             feats[f"res{si + 2}"] = x
         out = {}
 
-        prev = self._conv(feats["res5"], "backbone.fpn_lateral5")
-        out["p5"] = self._conv(prev, "backbone.fpn_output5", 1, 1)
+        # [d2] FPN.forward: the lateral 1x1 convs + top-down sums form a chain (p5 -> p2); the four 3x3 output convs only read its results, so
+        # they run behind it as ONE launch over the four levels (ops.conv2d_levels: one partial last dispatch round instead of four, and the
+        # p4 / p5 convs no longer leave most of the chip idle), bit-identical to the per-level launches
+        lat = {5: self._conv(feats["res5"], "backbone.fpn_lateral5")}
         for lvl in (4, 3, 2):
-            prev = self._conv(feats[f"res{lvl}"], f"backbone.fpn_lateral{lvl}", residual=prev, res_mode=2)
-            out[f"p{lvl}"] = self._conv(prev, f"backbone.fpn_output{lvl}", 1, 1)
+            lat[lvl] = self._conv(feats[f"res{lvl}"], f"backbone.fpn_lateral{lvl}", residual=lat[lvl + 1], res_mode=2)
+        outs = self._fpn_outputs_one_launch([lat[l] for l in (2, 3, 4, 5)]) if self.fuse_levels else None
+        for i, lvl in enumerate((2, 3, 4, 5)):
+            out[f"p{lvl}"] = outs[i] if outs is not None else self._conv(lat[lvl], f"backbone.fpn_output{lvl}", 1, 1)
         out["p6"] = ops.subsample2(out["p5"])
         if keep is not None:
             keep.update(feats)
@@ -302,6 +309,36 @@ class OpensetRCNNEngine:
         """pool_rois' rows as (m, 7, 7, 256): what `keep` hands to tests and diagnostics."""
         m, P = pooled.shape[0], self.cfg["pooler_resolution"]
         return pooled.view(m, P, P, 256)
+
+    def _fpn_outputs_one_launch(self, lats):
+        ws = [self.w[f"backbone.fpn_output{l}.w"] for l in (2, 3, 4, 5)]
+        bs = [self.w[f"backbone.fpn_output{l}.b"] for l in (2, 3, 4, 5)]
+        if self.profile is None:
+            return ops.conv2d_levels(lats, ws, bs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        outs = ops.conv2d_levels(lats, ws, bs)
+        e1.record()
+        if outs is not None:
+            flops = sum(2.0 * (x.numel() // x.shape[-1]) * w_.numel() for x, w_ in zip(lats, ws))
+            nbytes = sum(x.numel() + o.numel() + w_.numel() for x, o, w_ in zip(lats, outs, ws)) * lats[0].element_size()
+            self.profile.append(("backbone.fpn_output2-5 (four levels, one launch)", flops, e0, e1, nbytes, flops))
+        return outs
+
+    def _rpn_levels_fused(self, fl, deltas, ctrs, hiddens):
+        w, b = self.w["proposal_generator.rpn_head.conv.w"], self.w["proposal_generator.rpn_head.conv.b"]
+        if self.profile is None:
+            return ops.cfrpn_head_fused_levels(fl, w, b, self.rpn_wtail, self.rpn_btail, deltas, ctrs, hiddens)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ok = ops.cfrpn_head_fused_levels(fl, w, b, self.rpn_wtail, self.rpn_btail, deltas, ctrs, hiddens)
+        e1.record()
+        if ok:
+            rows = sum(d.shape[0] for d in deltas)
+            flops = 2.0 * rows * 256 * (2304 + 5)
+            self.profile.append(("proposal_generator.rpn_head.conv+tail (p2-p6, one launch)", flops, e0, e1,
+                                 sum(f.numel() for f in fl) * 2 + w.numel() * 2 + rows * 20, flops))
+        return ok
 
     def _rpn_level_fused(self, f, deltas, ctr, hidden=None):
         w, b = self.w["proposal_generator.rpn_head.conv.w"], self.w["proposal_generator.rpn_head.conv.b"]
@@ -354,10 +391,12 @@ class OpensetRCNNEngine:
             ctr = torch.empty((sum(rows),), dtype=torch.float32, device=self.device)
             # (rpn_keep_hidden: the trainer's engine also wants the hidden state, for the head's backward)
             t_all = torch.empty((sum(rows), 256), dtype=self.dtype, device=self.device) if self.rpn_keep_hidden else None
-            off = 0
-            for f, r in zip(fl, rows):
-                self._rpn_level_fused(f, deltas[off:off + r], ctr[off:off + r], None if t_all is None else t_all[off:off + r])
-                off += r
+            offs = [sum(rows[:i]) for i in range(len(rows))]
+            # ClsFreeRPNHead.forward's `for x in features` (classification_free_rpn.py:157-161) as ONE launch over the five levels
+            if not (self.fuse_levels and self._rpn_levels_fused(fl, [deltas[o:o + r] for o, r in zip(offs, rows)], [ctr[o:o + r] for o, r in zip(offs, rows)],
+                                                                None if t_all is None else [t_all[o:o + r] for o, r in zip(offs, rows)])):
+                for f, o, r in zip(fl, offs, rows):
+                    self._rpn_level_fused(f, deltas[o:o + r], ctr[o:o + r], None if t_all is None else t_all[o:o + r])
         else:
             t_dt = torch.float32 if "rpn_hidden" in self.fp32_points else self.dtype
             t_all = torch.empty((sum(rows), 256), dtype=t_dt, device=self.device)

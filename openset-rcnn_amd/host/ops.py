@@ -416,6 +416,97 @@ def cfrpn_head_fused(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, 
     return deltas, ctr
 
 
+def _conv_levels(xs: Sequence[torch.Tensor], outs, deltas=None, ctrs=None, weights=None, biases=None):
+    assert 1 <= len(xs) <= _lib.MAX_CONV_LEVELS
+    arr = (_lib.ConvLevel * len(xs))()
+    for i, x in enumerate(xs):
+        n, hi, wi, _ = x.shape
+        arr[i].in_ = x.data_ptr()
+        arr[i].out = outs[i].data_ptr() if outs is not None and outs[i] is not None else None
+        arr[i].deltas = deltas[i].data_ptr() if deltas is not None else None
+        arr[i].ctr = ctrs[i].data_ptr() if ctrs is not None else None
+        arr[i].weight = weights[i].data_ptr() if weights is not None else None
+        arr[i].bias = biases[i].data_ptr() if biases is not None else None
+        arr[i].n, arr[i].hi, arr[i].wi = n, hi, wi
+    return arr
+
+
+def _levels_params(x0: torch.Tensor, weight: torch.Tensor, relu: bool):
+    cout, kh, kw, cin = weight.shape
+    assert kh == kw and kh % 2 == 1 and x0.shape[3] == cin
+    p = _new_conv_params()
+    p.cin, p.cout, p.kh, p.kw, p.stride_h, p.stride_w, p.pad_h, p.pad_w = cin, cout, kh, kw, 1, 1, kh // 2, kw // 2
+    p.in_stride_w, p.out_stride_w = cin, cout
+    p.relu, p.res_mode, p.pad_mode = 1 if relu else 0, 0, 0
+    p.in_dtype = p.out_dtype = _DT[x0.dtype]
+    return p
+
+
+def conv2d_levels(xs: Sequence[torch.Tensor], weight, bias, relu: bool = False, outs: Optional[Sequence[torch.Tensor]] = None):
+    """Stride-1, same-padding convolutions of one shape on several NHWC feature maps in ONE launch (osr_conv2d_fwd_levels: the FPN's output
+    convs). weight / bias: one tensor shared by all levels, or a list with one per level. Returns the list of outputs, or None when the
+    shape is outside the launch's envelope (cout % 256, cin % 64, f16 / bf16): the caller then runs conv2d per level."""
+    lib = _lib.load()
+    ws = list(weight) if isinstance(weight, (list, tuple)) else None
+    bs = list(bias) if isinstance(bias, (list, tuple)) else None
+    w0 = ws[0] if ws is not None else weight
+    cout, kh, kw, cin = w0.shape
+    if cout % 256 or cin % 64 or kh != kw or kh % 2 == 0 or kh * kw * cin // 64 < 2 or xs[0].dtype not in (torch.float16, torch.bfloat16) or len(xs) > _lib.MAX_CONV_LEVELS:
+        return None
+    assert (ws is None) == (bs is None) and (ws is None or (len(ws) == len(xs) and len(bs) == len(xs)))
+    for w_, b_ in zip(ws if ws is not None else [weight], bs if bs is not None else [bias]):
+        _need(w_, xs[0].dtype, "weight"); _need(b_, torch.float32, "bias")
+        assert tuple(w_.shape) == (cout, kh, kw, cin) and b_.numel() == cout
+    for x in xs:
+        _need(x, xs[0].dtype, "x")
+        assert x.shape[3] == cin
+    if outs is None:
+        outs = [torch.empty(tuple(x.shape[:3]) + (cout,), dtype=x.dtype, device=x.device) for x in xs]
+    for x, o in zip(xs, outs):
+        _need(o, x.dtype, "out")
+        assert tuple(o.shape) == tuple(x.shape[:3]) + (cout,)
+    if FLOP_COUNT is not None:
+        FLOP_COUNT["conv"] += sum(2.0 * x.shape[0] * x.shape[1] * x.shape[2] * cout * kh * kw * cin for x in xs)
+    p = _levels_params(xs[0], w0, relu)
+    arr = _conv_levels(xs, outs, weights=ws, biases=bs)
+    st = lib.osr_conv2d_fwd_levels(C.byref(p), len(xs), arr, None if ws is not None else _p(weight), None if bs is not None else _p(bias), _stream())
+    if st == _lib.ERR_UNSUPPORTED:
+        return None
+    check(st, "osr_conv2d_fwd_levels")
+    return list(outs)
+
+
+def cfrpn_head_fused_levels(xs: Sequence[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor, w_tail: torch.Tensor, b_tail: torch.Tensor,
+                            deltas_outs: Sequence[torch.Tensor], ctr_outs: Sequence[torch.Tensor],
+                            hidden_outs: Optional[Sequence[Optional[torch.Tensor]]] = None) -> bool:
+    """ClsFreeRPNHead.forward over all the given levels in ONE launch (osr_cfrpn_head_fwd_levels). deltas_outs[i] (n*h*w, 4) / ctr_outs[i]
+    (n*h*w) fp32 receive level i's outputs (views of the level-major buffers rpn_select reads). Returns False -- nothing launched -- outside
+    the fused kernel's envelope."""
+    lib = _lib.load()
+    cout, kh, kw, cin = weight.shape
+    if cout != 256 or cin % 64 or kh != kw or kh % 2 == 0 or kh * kw * cin // 64 < 8 or xs[0].dtype not in (torch.float16, torch.bfloat16) or len(xs) > _lib.MAX_CONV_LEVELS:
+        return False
+    _need(weight, xs[0].dtype, "weight"); _need(bias, torch.float32, "bias")
+    _need(w_tail, torch.float32, "w_tail"); _need(b_tail, torch.float32, "b_tail")
+    for i, x in enumerate(xs):
+        _need(x, xs[0].dtype, "x")
+        rows = x.shape[0] * x.shape[1] * x.shape[2]
+        _need(deltas_outs[i], torch.float32, "deltas"); _need(ctr_outs[i], torch.float32, "ctr")
+        assert deltas_outs[i].numel() == rows * 4 and ctr_outs[i].numel() == rows and x.shape[3] == cin
+        if hidden_outs is not None and hidden_outs[i] is not None:
+            _need(hidden_outs[i], x.dtype, "hidden_out")
+            assert hidden_outs[i].numel() == rows * 256
+    if FLOP_COUNT is not None:
+        FLOP_COUNT["conv"] += sum(2.0 * x.shape[0] * x.shape[1] * x.shape[2] * cout * (kh * kw * cin + 5) for x in xs)
+    p = _levels_params(xs[0], weight, True)
+    arr = _conv_levels(xs, hidden_outs, deltas_outs, ctr_outs)
+    st = lib.osr_cfrpn_head_fwd_levels(C.byref(p), len(xs), arr, _p(weight), _p(bias), _p(w_tail), _p(b_tail), _stream())
+    if st == _lib.ERR_UNSUPPORTED:
+        return False
+    check(st, "osr_cfrpn_head_fwd_levels")
+    return True
+
+
 def make_rpn_levels(shapes: Sequence[Tuple[int, int]], strides: Sequence[int], n: int, num_anchors: int = 1) -> RpnLevels:
     lv = RpnLevels()
     lv.num_levels, lv.num_anchors = len(shapes), num_anchors

@@ -321,14 +321,13 @@ class OpensetRCNNTrainer:
                 x = y
             feats[f"res{si + 2}"] = frozen_feats[f"res{si + 2}"] if si + 2 <= self.freeze_at else x
         s["blocks"], s["res"] = blocks, feats
-        out, lat = {}, {}
-        prev = e._conv(feats["res5"], "backbone.fpn_lateral5")
-        lat[5] = prev
-        out["p5"] = e._conv(prev, "backbone.fpn_output5", 1, 1)
+        out = {}
+        lat = {5: e._conv(feats["res5"], "backbone.fpn_lateral5")}
         for lvl in (4, 3, 2):
-            prev = e._conv(feats[f"res{lvl}"], f"backbone.fpn_lateral{lvl}", residual=prev, res_mode=2)
-            lat[lvl] = prev
-            out[f"p{lvl}"] = e._conv(prev, f"backbone.fpn_output{lvl}", 1, 1)
+            lat[lvl] = e._conv(feats[f"res{lvl}"], f"backbone.fpn_lateral{lvl}", residual=lat[lvl + 1], res_mode=2)
+        outs = e._fpn_outputs_one_launch([lat[l] for l in (2, 3, 4, 5)]) if e.fuse_levels else None  # (the four output convs as one launch: engine._backbone)
+        for i, lvl in enumerate((2, 3, 4, 5)):
+            out[f"p{lvl}"] = outs[i] if outs is not None else e._conv(lat[lvl], f"backbone.fpn_output{lvl}", 1, 1)
         out["p6"] = ops.subsample2(out["p5"])
         s["lat"], s["p"] = lat, out
         # CF-RPN head (unfused: the hidden state t is kept), targets, losses

@@ -10,6 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 
 pkg = ge.load_package()
+if os.environ.get("OSR_VARIANT_LIB"):
+    pkg._lib.LIB_PATH = os.environ["OSR_VARIANT_LIB"]
 lib = pkg._lib.load()
 from openset_rcnn_amd.host import ops
 from openset_rcnn_amd.host.weights import pack_conv_weight
