@@ -68,6 +68,7 @@ __device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv& f) {
     const int ow_ = (int)(rem_##nimg_ - (unsigned)oh_ * e_div_wo.d);
 
 #define C64_MAX_LEVELS 6
+static_assert(C64_MAX_LEVELS == OSR_MAX_CONV_LEVELS, "include/osr.h: OSR_MAX_CONV_LEVELS");
 struct Conv64Args {
     osr_conv_params p;
     const void* in;

@@ -43,6 +43,7 @@ def test_struct_layouts_match_header(osr):
     assert ctypes.sizeof(L.RpnLevels) == 8 + 3 * 8 * 4 + 8 * 8
     assert ctypes.sizeof(L.Pyramid) == 8 + 3 * 8 * 4 + 8 * 8
     assert ctypes.sizeof(L.BottleneckParams) == 8 * 4
+    assert ctypes.sizeof(L.ConvLevel) == 6 * 8 + 4 * 4 and L.MAX_CONV_LEVELS == 6  # osr_conv_level: six pointers + n, hi, wi, reserved; OSR_MAX_CONV_LEVELS
     assert ctypes.sizeof(L.SgdTensor) == 5 * 8 + 2 * 8 + 2 * 4 and ctypes.sizeof(L.PackTensor) == 2 * 8 + 6 * 4
 
 
