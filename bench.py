@@ -1037,7 +1037,7 @@ def main(argv=None) -> int:
         if rank == 0:
             line["train_step"] = ts
         try:  # BASELINE.json config 4 (GraspNet heads, 1280x720 frames, batch 8 per GPU): every rank, same watchdog
-            c4 = config4_leg(tdt, dev, args.train_steps, 2, dist, rank, world)
+            c4 = config4_leg(tdt, dev, max(args.train_steps, 8), 4, dist, rank, world)
         except Exception as e:  # noqa: BLE001
             c4 = {"error": repr(e)[:400]}
             rc = 3
@@ -1046,7 +1046,7 @@ def main(argv=None) -> int:
             line["config4"] = c4
     if world == 1 and not args.no_train_step:
         try:
-            line["config4"] = config4_leg(tdt, dev, args.train_steps, 2)
+            line["config4"] = config4_leg(tdt, dev, max(args.train_steps, 8), 4)
         except Exception as e:  # noqa: BLE001
             line["config4"] = {"error": repr(e)[:400]}
     if rank == 0:
