@@ -84,6 +84,8 @@ struct Conv64Args {
     int stem;              // 1: cin == 32 view, two taps per K slice
     int two_stage;         // 1: double-buffered staging (K-heavy layers); 0: one staging buffer, more workgroups per CU
     int tap_minor;         // 1: K runs channel-slice-major / tap-minor (L2-friendly for KH*KW > 1), 0: tap-major
+    int pw_dense = 0;      // 1: 1 x 1, stride 1, no padding, input / output / residual / mask all dense rows (row m at m * channels, < 2^31 elements):
+                           //    the row -> (image, y, x) decomposition and the strided addresses drop out of the prologue and the epilogue
     // fused CF-RPN tail (EPI == 1): 1x1 weights [5][256] (rows 0-3 ltrb deltas, row 4 centerness), biases, outputs
     const float* tail_w;
     const float* tail_b;
@@ -261,10 +263,15 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
         const int row = a_piece(j) * 8 + lrow;
         const long long m = m0 + row;
         const bool ok = m < e_M;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        if (a.pw_dense) {  // (wave-uniform) a dense 1 x 1 layer: row m starts at m * cin, its only tap is always inside
+            a_off0[j] = ok ? ((unsigned)m * (unsigned)p.cin + (unsigned)chunk * 8u) * 2u : 0u;
+            a_mask[j] = ok ? 1u : 0u;
+            continue;
+        }
         const long long mm = ok ? m : 0;
         C64_ROW_TO_NHW(mm, nimg, oh, ow);
         const int ih0 = oh * p.stride_h - p.pad_h, iw0 = ow * p.stride_w - p.pad_w;
-        const int chunk = slot ^ ((row >> 1) & 7);
         // stem view: two 32-wide taps per K slice, chunks 0-3 -> tap kh, 4-7 -> tap kh+1
         const long long coff = a.stem ? (long long)(chunk >> 2) * e_ish + (chunk & 3) * 8 : (long long)chunk * 8;
         a_off0[j] = (unsigned)(((long long)nimg * e_isn + (long long)ih0 * e_ish + (long long)iw0 * p.in_stride_w + coff) * 2);
@@ -389,6 +396,10 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
                     for (int pass = 0; pass < NPASS; ++pass) {
                         const long long m = m0 + (wr * TM + i) * 32 + pass * RPP + (lane >> 3);
                         const bool ok = m < e_M && co < p.cout;
+                        if (a.pw_dense) {  // (wave-uniform) dense rows: the residual of row m starts at m * cout
+                            rres[i][pass] = *reinterpret_cast<const frag_t*>(res + (ok ? (unsigned)m * (unsigned)p.cout + (unsigned)co : 0u));
+                            continue;
+                        }
                         const long long mm = ok ? m : 0;
                         C64_ROW_TO_NHW(mm, nimg, oh, ow);
                         const int rh = p.res_mode == 2 ? (oh >> 1) : oh, rw = p.res_mode == 2 ? (ow >> 1) : ow;
@@ -926,15 +937,25 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
                     float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += bias8[jp][e];
-                    C64_ROW_TO_NHW(m, nimg, oh, ow);
+                    // element offsets of this lane's eight channels in the output (= the ReLU mask's layout) and in the residual. Dense rows
+                    // everywhere (pw_dense, wave-uniform): ONE 32-bit offset m * cout + co serves all three; else row -> (image, y, x) and strides
+                    long long o_out, o_res = 0;
+                    if (a.pw_dense) {
+                        o_out = o_res = (long long)((unsigned)m * (unsigned)p.cout + (unsigned)co);
+                    } else {
+                        C64_ROW_TO_NHW(m, nimg, oh, ow);
+                        o_out = (long long)nimg * e_osn + (long long)oh * e_osh + (long long)ow * p.out_stride_w + co;
+                        if (!PRE_RES && p.res_mode != 0) {
+                            const int rh = p.res_mode == 2 ? (oh >> 1) : oh, rw = p.res_mode == 2 ? (ow >> 1) : ow;
+                            o_res = (long long)nimg * p.res_stride_n + (long long)rh * p.res_stride_h + (long long)rw * p.res_stride_w + co;
+                        }
+                    }
                     if (p.res_mode != 0) {
                         frag_t rv;
                         if constexpr (PRE_RES) {
                             rv = rres[i][pass];
                         } else {
-                            const int rh = p.res_mode == 2 ? (oh >> 1) : oh, rw = p.res_mode == 2 ? (ow >> 1) : ow;
-                            rv = *reinterpret_cast<const frag_t*>(res + (long long)nimg * p.res_stride_n + (long long)rh * p.res_stride_h +
-                                                                  (long long)rw * p.res_stride_w + co);
+                            rv = *reinterpret_cast<const frag_t*>(res + o_res);
                         }
                         if (p.res_mode == 3) {  // backward of a ReLU: keep the gradient where the forward activation was positive
 #pragma unroll
@@ -949,12 +970,11 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
                         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                     }
                     if (a.mask) {
-                        const frag_t mv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const TI*>(a.mask) + (long long)nimg * e_osn +
-                                                                          (long long)oh * e_osh + (long long)ow * p.out_stride_w + co);
+                        const frag_t mv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const TI*>(a.mask) + o_out);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = (float)mv[e] > 0.f ? v[e] : 0.f;
                     }
-                    store8_64<TO>(out + (long long)nimg * e_osn + (long long)oh * e_osh + (long long)ow * p.out_stride_w + co, v);
+                    store8_64<TO>(out + o_out, v);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -1286,6 +1306,15 @@ osr_status osr_conv64_run(const osr_conv_params* p, const void* in, const void* 
     a.in_bytes = (unsigned)in_bytes; a.w_bytes = (unsigned)w_bytes;
     a.stem = (p->pad_mode == 1 && p->cin == 32) ? 1 : 0;
     a.tap_minor = (!a.stem && p->kh * p->kw > 1) ? tap_minor_default() : 0;
+    {   // dense 1 x 1 layers (conv1 / conv3 of the bottlenecks, FC1 / FC2, their data gradients): see Conv64Args::pw_dense
+        const bool in_dense = p->in_stride_w == p->cin && p->in_stride_h == (long long)p->wi * p->cin && p->in_stride_n == (long long)p->hi * p->wi * p->cin;
+        const bool out_dense = p->out_stride_w == p->cout && p->out_stride_h == (long long)p->wo * p->cout && p->out_stride_n == (long long)p->ho * p->wo * p->cout;
+        const bool res_ok = p->res_mode == 0 || ((p->res_mode == 1 || p->res_mode == 3) && p->res_stride_w == p->out_stride_w &&
+                                                 p->res_stride_h == p->out_stride_h && p->res_stride_n == p->out_stride_n);
+        const long long widest = p->cin > p->cout ? p->cin : p->cout;
+        a.pw_dense = (!a.stem && p->kh == 1 && p->kw == 1 && p->stride_h == 1 && p->stride_w == 1 && p->pad_h == 0 && p->pad_w == 0 && p->pad_mode == 0 &&
+                      in_dense && out_dense && res_ok && a.M * widest < (1ll << 31)) ? 1 : 0;
+    }
     a.tiles_m = a.tiles_n = 0;
     a.tail_w = a.tail_b = nullptr; a.tail_deltas = a.tail_ctr = nullptr;
     a.w3 = nullptr; a.bias3 = nullptr; a.cout3 = 0; a.w3_bytes = a.out_bytes = 0;
