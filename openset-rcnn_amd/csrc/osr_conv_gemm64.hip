@@ -84,8 +84,9 @@ struct Conv64Args {
     int stem;              // 1: cin == 32 view, two taps per K slice
     int two_stage;         // 1: double-buffered staging (K-heavy layers); 0: one staging buffer, more workgroups per CU
     int tap_minor;         // 1: K runs channel-slice-major / tap-minor (L2-friendly for KH*KW > 1), 0: tap-major
-    int pw_dense = 0;      // 1: 1 x 1, stride 1, no padding, input / output / residual / mask all dense rows (row m at m * channels, < 2^31 elements):
-                           //    the row -> (image, y, x) decomposition and the strided addresses drop out of the prologue and the epilogue
+    int pw_dense = 0;      // dense-row shortcuts (row m of a dense (rows, channels) tensor starts at m * channels, < 2^31 elements): the row -> (image, y, x)
+                           // decomposition and the strided 64-bit addresses drop out. bit 0: the INPUT side (1 x 1, stride 1, no padding, dense input:
+                           // the gather descriptors of the prologue); bit 1: dense OUTPUT (and ReLU mask) rows; bit 2: dense RESIDUAL rows (modes 1 / 3)
     // fused CF-RPN tail (EPI == 1): 1x1 weights [5][256] (rows 0-3 ltrb deltas, row 4 centerness), biases, outputs
     const float* tail_w;
     const float* tail_b;
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
         const long long m = m0 + row;
         const bool ok = m < e_M;
         const int chunk = slot ^ ((row >> 1) & 7);
-        if (a.pw_dense) {  // (wave-uniform) a dense 1 x 1 layer: row m starts at m * cin, its only tap is always inside
+        if (a.pw_dense & 1) {  // (wave-uniform) a dense 1 x 1 layer: row m starts at m * cin, its only tap is always inside
             a_off0[j] = ok ? ((unsigned)m * (unsigned)p.cin + (unsigned)chunk * 8u) * 2u : 0u;
             a_mask[j] = ok ? 1u : 0u;
             continue;
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
                     for (int pass = 0; pass < NPASS; ++pass) {
                         const long long m = m0 + (wr * TM + i) * 32 + pass * RPP + (lane >> 3);
                         const bool ok = m < e_M && co < p.cout;
-                        if (a.pw_dense) {  // (wave-uniform) dense rows: the residual of row m starts at m * cout
+                        if (a.pw_dense & 4) {  // (wave-uniform) dense rows: the residual of row m starts at m * cout
                             rres[i][pass] = *reinterpret_cast<const frag_t*>(res + (ok ? (unsigned)m * (unsigned)p.cout + (unsigned)co : 0u));
                             continue;
                         }
@@ -940,12 +941,13 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
                     // element offsets of this lane's eight channels in the output (= the ReLU mask's layout) and in the residual. Dense rows
                     // everywhere (pw_dense, wave-uniform): ONE 32-bit offset m * cout + co serves all three; else row -> (image, y, x) and strides
                     long long o_out, o_res = 0;
-                    if (a.pw_dense) {
+                    const bool need_res = !PRE_RES && p.res_mode != 0;  // (the 128-wide tiles hold the residual in registers already)
+                    if ((a.pw_dense & 2) && (!need_res || (a.pw_dense & 4))) {
                         o_out = o_res = (long long)((unsigned)m * (unsigned)p.cout + (unsigned)co);
                     } else {
                         C64_ROW_TO_NHW(m, nimg, oh, ow);
                         o_out = (long long)nimg * e_osn + (long long)oh * e_osh + (long long)ow * p.out_stride_w + co;
-                        if (!PRE_RES && p.res_mode != 0) {
+                        if (need_res) {
                             const int rh = p.res_mode == 2 ? (oh >> 1) : oh, rw = p.res_mode == 2 ? (ow >> 1) : ow;
                             o_res = (long long)nimg * p.res_stride_n + (long long)rh * p.res_stride_h + (long long)rw * p.res_stride_w + co;
                         }
@@ -1309,11 +1311,15 @@ osr_status osr_conv64_run(const osr_conv_params* p, const void* in, const void* 
     {   // dense 1 x 1 layers (conv1 / conv3 of the bottlenecks, FC1 / FC2, their data gradients): see Conv64Args::pw_dense
         const bool in_dense = p->in_stride_w == p->cin && p->in_stride_h == (long long)p->wi * p->cin && p->in_stride_n == (long long)p->hi * p->wi * p->cin;
         const bool out_dense = p->out_stride_w == p->cout && p->out_stride_h == (long long)p->wo * p->cout && p->out_stride_n == (long long)p->ho * p->wo * p->cout;
-        const bool res_ok = p->res_mode == 0 || ((p->res_mode == 1 || p->res_mode == 3) && p->res_stride_w == p->out_stride_w &&
-                                                 p->res_stride_h == p->out_stride_h && p->res_stride_n == p->out_stride_n);
         const long long widest = p->cin > p->cout ? p->cin : p->cout;
-        a.pw_dense = (!a.stem && p->kh == 1 && p->kw == 1 && p->stride_h == 1 && p->stride_w == 1 && p->pad_h == 0 && p->pad_w == 0 && p->pad_mode == 0 &&
-                      in_dense && out_dense && res_ok && a.M * widest < (1ll << 31)) ? 1 : 0;
+        const bool fits = a.M * widest < (1ll << 31), res_dense = (p->res_mode == 1 || p->res_mode == 3) && p->res_stride_w == p->out_stride_w &&
+                                                                    p->res_stride_h == p->out_stride_h && p->res_stride_n == p->out_stride_n;
+        a.pw_dense = 0;
+        if (fits && !a.stem) {
+            if (p->kh == 1 && p->kw == 1 && p->stride_h == 1 && p->stride_w == 1 && p->pad_h == 0 && p->pad_w == 0 && p->pad_mode == 0 && in_dense) a.pw_dense |= 1;
+            if (out_dense) a.pw_dense |= 2;
+            if (out_dense && res_dense) a.pw_dense |= 4;
+        }
     }
     a.tiles_m = a.tiles_n = 0;
     a.tail_w = a.tail_b = nullptr; a.tail_deltas = a.tail_ctr = nullptr;
@@ -1439,6 +1445,9 @@ extern "C" osr_status osr_conv2d_fwd_levels(const osr_conv_params* p, int32_t nl
     if (s != OSR_OK) return s;
     a.tiles_n = p->cout / 256;
     a.tile0 = 0; a.ntile = a.tiles_m * a.tiles_n; a.ksplit = 1; a.split_stride = 0;
+    a.pw_dense = 2;  // every level's output is a dense (rows, cout) tensor
+    for (int l = 0; l < nlevels; ++l)
+        if (a.lv[l].M * p->cout >= (1ll << 31)) a.pw_dense = 0;
     a.two_stage = 2;
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = conv64_lds_bytes(256, 256, 2, 8);
