@@ -68,6 +68,9 @@ __device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv& f) {
     const int ow_ = (int)(rem_##nimg_ - (unsigned)oh_ * e_div_wo.d);
 
 #define C64_MAX_LEVELS 6
+#define C64_TW_LD 264  // elements per row of the fused CF-RPN tail's split weight matrix in LDS (528 B)
+// bytes of LDS behind the parked tile: the (16, C64_TW_LD) weight matrix, later overwritten by the (rows, 16) fp32 slab of the tail's accumulators
+#define C64_TAIL_LDS(bm) ((size_t)(16 * C64_TW_LD * 2) > (size_t)(bm) * 64 ? (size_t)(16 * C64_TW_LD * 2) : (size_t)(bm) * 64)
 static_assert(C64_MAX_LEVELS == OSR_MAX_CONV_LEVELS, "include/osr.h: OSR_MAX_CONV_LEVELS");
 struct Conv64Args {
     osr_conv_params p;
@@ -423,8 +426,20 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
     float tbias[EPI == 1 ? TN : 1][2];  // per-lane conv bias of its output columns ([.][1] only differs for 16x16 sub-tiles)
     if constexpr (EPI == 1) {
         // tail weights -> LDS (behind the staging / t-tile region); per-lane conv bias of its TN output columns
-        float* s_tw = reinterpret_cast<float*>(lds + a.tail_lds_off);
-        for (int i = tid; i < 5 * 256; i += NT) s_tw[i] = a.tail_w[i];
+        // The fp32 tail weights as THREE storage-dtype terms each (w = hi + mid + lo, every remainder exactly representable: 3 x 11
+        // or 3 x 8 significand bits cover fp32's 24) -> a (16, 256) B operand for the tail's MFMAs: rows q, 5 + q, 10 + q = hi, mid, lo
+        // of tail row q; row 15 zero. Row pitch C64_TW_LD elements (528 B: conflict-free fragment reads).
+        TI* s_w16 = reinterpret_cast<TI*>(lds + a.tail_lds_off);
+        for (int i = tid; i < 5 * 256; i += NT) {
+            const int q = i >> 8, k = i & 255;
+            const float w = a.tail_w[i];
+            const TI hi = (TI)w;
+            const float r1 = w - (float)hi;
+            const TI mid = (TI)r1;
+            const TI lo = (TI)(r1 - (float)mid);
+            s_w16[q * C64_TW_LD + k] = hi; s_w16[(5 + q) * C64_TW_LD + k] = mid; s_w16[(10 + q) * C64_TW_LD + k] = lo;
+        }
+        for (int i = tid; i < 256; i += NT) s_w16[15 * C64_TW_LD + i] = (TI)0.f;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             tbias[j][0] = e_bias[(wc * TN + j) * 32 + C64_COL(0)];
@@ -882,31 +897,59 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
                 if (m < e_M) *reinterpret_cast<frag_t*>(tout + m * 256 + ch8) = *reinterpret_cast<const frag_t*>(s_t + row * LDT + ch8);
             }
         }
-        const float* s_tw = reinterpret_cast<const float*>(lds + a.tail_lds_off);
-        static_assert(EPI == 0 || NT == 2 * BM, "two threads per pixel");
-        const int row = tid >> 1, hf = tid & 1;
-        float ss = 0.f, d[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int k = 0; k < 16; ++k) {
-            const int ch = (2 * k + hf) * 8;  // the two threads of a pixel take alternate 16-byte chunks
-            const frag_t tv = *reinterpret_cast<const frag_t*>(s_t + row * LDT + ch);
+        // The five 1x1 dot products and ||t||^2 on the matrix cores (round 5; until then two threads per pixel, 768 fp32 FMAs + 170 LDS reads
+        // each: 0.2 ms of the merged head launch). Per wave, its 32 pixels x 256 channels of s_t are the A operand (16 fragments);
+        //   D  = T . W16^T  (16 MFMAs): columns q, 5 + q, 10 + q of a pixel's row = its dot products with the hi / mid / lo terms of tail row q
+        //                    (products of two storage-dtype values are exact in fp32; the sum of the three columns is the fp32-weight dot
+        //                    product up to the accumulation order);
+        //   D2 = T . T^T    (16 MFMAs, B operand = the A fragments themselves): the diagonal is ||t||^2.
+        // The accumulators go through a (rows, 16) fp32 slab in LDS -- it takes the place of the weight matrix, once every wave holds its B
+        // fragments --, then one lane per pixel normalises, adds the biases and applies the sigmoid.
+        const TI* s_w16 = reinterpret_cast<const TI*>(lds + a.tail_lds_off);
+        float* s_d = reinterpret_cast<float*>(lds + a.tail_lds_off);
+        frag_t wb[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = (float)tv[e];
-                ss = __builtin_fmaf(v, v, ss);
+        for (int ks8 = 0; ks8 < 8; ++ks8) wb[ks8] = *reinterpret_cast<const frag_t*>(s_w16 + (lane & 15) * C64_TW_LD + ks8 * 32 + (lane >> 4) * 8);
+        __syncthreads();  // every wave has its weight fragments: the slab may overwrite the matrix
+        f32x4 dacc[2], sacc[2];
 #pragma unroll
-                for (int q = 0; q < 5; ++q) d[q] = __builtin_fmaf(v, s_tw[q * 256 + ch + e], d[q]);
+        for (int rt = 0; rt < 2; ++rt) { dacc[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; sacc[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks8 = 0; ks8 < 8; ++ks8)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const frag_t ta = *reinterpret_cast<const frag_t*>(s_t + (wid * 32 + rt * 16 + (lane & 15)) * LDT + ks8 * 32 + (lane >> 4) * 8);
+                dacc[rt] = Frag64<TI>::mfma16(ta, wb[ks8], dacc[rt]);
+                sacc[rt] = Frag64<TI>::mfma16(ta, ta, sacc[rt]);
             }
-        }
-        ss += __shfl_xor(ss, 1, 64);
+        // D element q of a lane: row (lane >> 4) * 4 + q, column lane & 15. Column 15 of D is zero (zero weight row): the diagonal of D2
+        // goes there (row r's lane is the one with column r, i.e. (lane & 15) >> 2 == lane >> 4, element (lane & 3)); same-wave LDS writes land in order
+        const int dcol = lane & 15, dgrp = lane >> 4;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) d[q] += __shfl_xor(d[q], 1, 64);
-        const long long m = m0 + row;
-        if (hf == 0 && m < e_M) {
-            const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-            *reinterpret_cast<float4*>(e_tail_deltas + m * 4) = make_float4(d[0] * inv + a.tail_b[0], d[1] * inv + a.tail_b[1],
-                                                                            d[2] * inv + a.tail_b[2], d[3] * inv + a.tail_b[3]);
-            e_tail_ctr[m] = 1.0f / (1.0f + expf(-(d[4] * inv + a.tail_b[4])));
+        for (int rt = 0; rt < 2; ++rt) {
+            float* sd = s_d + (wid * 32 + rt * 16) * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sd[(dgrp * 4 + q) * 16 + dcol] = dacc[rt][q];
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            float* sd = s_d + (wid * 32 + rt * 16) * 16;
+            const float dg = (dcol & 3) == 0 ? sacc[rt][0] : (dcol & 3) == 1 ? sacc[rt][1] : (dcol & 3) == 2 ? sacc[rt][2] : sacc[rt][3];
+            if ((dcol >> 2) == dgrp) sd[dcol * 16 + 15] = dg;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's slab rows are written
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 32) {
+            const int row = wid * 32 + lane;
+            const long long m = m0 + row;
+            const float4 v0 = *reinterpret_cast<const float4*>(s_d + row * 16), v1 = *reinterpret_cast<const float4*>(s_d + row * 16 + 4);
+            const float4 v2 = *reinterpret_cast<const float4*>(s_d + row * 16 + 8), v3 = *reinterpret_cast<const float4*>(s_d + row * 16 + 12);
+            if (m < e_M) {
+                const float inv = 1.0f / fmaxf(sqrtf(v3.w), 1e-12f);
+                const float d0 = v0.x + (v1.y + v2.z), d1 = v0.y + (v1.z + v2.w), d2 = v0.z + (v1.w + v3.x), d3 = v0.w + (v2.x + v3.y), d4 = v1.x + (v2.y + v3.z);
+                *reinterpret_cast<float4*>(e_tail_deltas + m * 4) = make_float4(d0 * inv + a.tail_b[0], d1 * inv + a.tail_b[1], d2 * inv + a.tail_b[2], d3 * inv + a.tail_b[3]);
+                e_tail_ctr[m] = 1.0f / (1.0f + expf(-(d4 * inv + a.tail_b[4])));
+            }
         }
         return;
     }
@@ -1256,7 +1299,7 @@ static osr_status cfrpn_fused_launch(Conv64Args& a, hipStream_t st) {
         a.ntile = a.tiles_m;
         const size_t t_bytes = (size_t)256 * (256 + 8) * 2, stages = (size_t)2 * (256 + 256) * 128;
         a.tail_lds_off = (int)(t_bytes > stages ? t_bytes : stages);
-        const size_t lds = (size_t)a.tail_lds_off + 5 * 256 * 4;
+        const size_t lds = (size_t)a.tail_lds_off + C64_TAIL_LDS(256);
         static osr_dev_mask attr8{0};
         osr_once_per_device(attr8, [] {
             allow_big_lds(conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1, 2>);
@@ -1278,7 +1321,7 @@ static osr_status cfrpn_fused_launch(Conv64Args& a, hipStream_t st) {
     a.ntile = a.tiles_m;
     const size_t t_bytes = (size_t)128 * (256 + 8) * 2, stage = (size_t)(128 + 256) * 128;
     a.tail_lds_off = (int)(t_bytes > stage ? t_bytes : stage);
-    const size_t lds = (size_t)a.tail_lds_off + 5 * 256 * 4;
+    const size_t lds = (size_t)a.tail_lds_off + C64_TAIL_LDS(128);
     static osr_dev_mask attr{0};
     osr_once_per_device(attr, [] { allow_big_lds(conv_igemm64_kernel<TI, TI, 128, 256, 2, 2, 1, 0>); });
     hipLaunchKernelGGL((conv_igemm64_kernel<TI, TI, 128, 256, 2, 2, 1, 0>), dim3((unsigned)a.tiles_m), dim3(256), lds, st, a);
@@ -1469,7 +1512,7 @@ static osr_status cfrpn_levels_launch(Conv64Args& a, hipStream_t st) {
     a.tiles_n = 1; a.tile0 = 0; a.ntile = a.tiles_m; a.ksplit = 1; a.split_stride = 0;
     const size_t t_bytes = (size_t)256 * (256 + 8) * 2, stages = (size_t)2 * (256 + 256) * 128;
     a.tail_lds_off = (int)(t_bytes > stages ? t_bytes : stages);
-    const size_t lds = (size_t)a.tail_lds_off + 5 * 256 * 4;
+    const size_t lds = (size_t)a.tail_lds_off + C64_TAIL_LDS(256);
     static osr_dev_mask attr{0};
     osr_once_per_device(attr, [] { allow_big_lds(conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1, 2>); });
     hipLaunchKernelGGL((conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1, 2>), dim3((unsigned)a.tiles_m), dim3(512), lds, st, a);
