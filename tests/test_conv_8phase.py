@@ -128,17 +128,19 @@ def test_8phase_ragged_row_lists_and_split_k_tail(osr, ops):
         assert (out[idx].double() - r64).abs().max().item() <= 2e-3 * max(1.0, r64.abs().max().item())  # fp16 output rounding
 
 
-def test_8phase_fused_head_matches_the_unfused_launches(ops):
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_8phase_fused_head_matches_the_unfused_launches(ops, dtype):
     """The fused CF-RPN head on 256-row tiles (>= 512 tiles: the kernel with the 8-phase loop) against osr_conv2d_fwd +
-    osr_cfrpn_head_tail; the hidden state it parks in LDS is the separate launch's output bit for bit."""
+    osr_cfrpn_head_tail; the hidden state it parks in LDS is the separate launch's output bit for bit. The tail runs on the matrix
+    cores (fp32 tail weights as three storage-dtype terms: three 8-bit significands for bf16): within 1e-5 of the un-fused fp32 FMA tail."""
     g = torch.Generator().manual_seed(9)
     n, h, w = 2, 200, 336
-    x = (torch.randn(n, h, w, 256, generator=g) * 0.5).half().to(DEV)
-    wt = (torch.randn(256, 3, 3, 256, generator=g) / 48).half().to(DEV)
+    x = (torch.randn(n, h, w, 256, generator=g) * 0.5).to(dtype).to(DEV)
+    wt = (torch.randn(256, 3, 3, 256, generator=g) / 48).to(dtype).to(DEV)
     b = (torch.randn(256, generator=g) * 0.1).to(DEV)
     wtail = (torch.randn(5, 256, generator=g) * 0.05).to(DEV)
     btail = (torch.randn(5, generator=g) * 0.1).to(DEV)
-    hidden = torch.empty(n * h * w, 256, dtype=torch.float16, device=DEV)
+    hidden = torch.empty(n * h * w, 256, dtype=dtype, device=DEV)
     d, c = ops.cfrpn_head_fused(x, wt, b, wtail, btail, hidden_out=hidden)
     t = ops.conv2d(x, wt, b, 1, 1, relu=True)
     d2, c2 = ops.cfrpn_head_tail(t.view(-1, 256), wtail[:4].contiguous(), btail[:4].contiguous(), wtail[4:].contiguous(), btail[4:].contiguous())
