@@ -326,7 +326,11 @@ def config4_leg(tdt, device, steps: int, warmup: int, dist=None, rank: int = 0, 
     g = np.random.default_rng(100 + rank)
     frames = [g.integers(0, 256, (fh, fw, 3), dtype=np.uint8) for _ in range(n)]  # decoded frames in host memory (each rank its own shard)
     rz = DeviceResizer(device)
-    batch = torch.empty((n, 3, h, w), dtype=torch.uint8, device=device)
+    # two batch buffers in turn: the copy stream fills one while the step launched before still reads the other; a buffer is refilled only
+    # after the step that consumed it has been ENQUEUED AND its event reached (the copy stream waits for that step's end-of-step event)
+    batches = [torch.empty((n, 3, h, w), dtype=torch.uint8, device=device) for _ in range(2)]
+    consumed = [None, None]
+    turn = [0]
     gt_g = torch.Generator().manual_seed(rank)
     ngt = 6
     ctr = torch.rand(n, ngt, 2, generator=gt_g) * torch.tensor([w * 0.8, h * 0.8]) + 40
@@ -343,17 +347,23 @@ def config4_leg(tdt, device, steps: int, warmup: int, dist=None, rank: int = 0, 
     dev_args = (hw, hp, wp, gt.to(device), gcls.to(device), gcnt.to(device), keys)
 
     def load():
+        slot = turn[0] & 1
+        turn[0] += 1
+        if consumed[slot] is not None:
+            rz.stream.wait_event(consumed[slot])
         for i, f in enumerate(frames):
-            rz(f, (h, w), out=batch[i], wait=False)
+            rz(f, (h, w), out=batches[slot][i], wait=False)
         torch.cuda.current_stream().wait_event(rz.done)
-        return batch
+        return slot, batches[slot]
 
     def run(k, with_collective=True):
         for _ in range(k):
-            losses = tr.step(load(), *dev_args, update=with_collective)
+            slot, images = load()
+            losses = tr.step(images, *dev_args, update=with_collective)
             if not with_collective:  # the same iteration without the gradient exchange: local update only
                 tr._update(1)
                 tr.buckets.reset()
+            consumed[slot] = torch.cuda.current_stream().record_event()
         return losses
 
     def timed_iters(k, **kw):
@@ -381,7 +391,7 @@ def config4_leg(tdt, device, steps: int, warmup: int, dist=None, rank: int = 0, 
                ms_per_iter=round(dt * 1e3, 3), images_per_sec=round(n * world / dt, 2), n_gpus=world, steps=steps, warmup=warmup, batch_per_gpu=n,
                num_known=K, num_classes=ecfg["num_classes"], unk_thr=ecfg["unk_thr"], pln_loss_weight=ecfg["pln_loss_weight"],
                loss_total_last=round(float(sum(float(v) for v in losses.values())), 4), overflow_skipped_steps=tr.overflow_steps,
-               gradient_bytes=tr.num_params * 4, input="host frames (uint8 HWC) -> pinned staging -> device, resized on the device inside the timed region")
+               gradient_bytes=tr.num_params * 4, input="host frames (uint8 HWC) -> pinned staging -> device, resized on the device inside the timed region (copy stream, two batch buffers: the upload of a batch overlaps the step before it)")
     if dist is not None and world > 1:
         # the collective alone: one all-reduce of the whole flat buffer, nothing else on the GPU
         flat = tr.grad_flat
