@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--gt", type=int, default=8, help="ground-truth boxes per image")
     ap.add_argument("--graph", action="store_true", help="capture one iteration into a hipGraph and replay it (single GPU)")
     ap.add_argument("--no-side-wgrad", action="store_true", help="weight gradients in the main stream (A/B of the second stream)")
+    ap.add_argument("--wgrad-on-main", default="", help="comma-separated block prefixes (e.g. backbone.bottom_up.res3.0) whose weight gradients ride on the main stream (A/B)")
     ap.add_argument("--no-overlap-targets", action="store_true", help="anchor targets in the main stream (A/B of the side stream)")
     ap.add_argument("--phases", action="store_true", help="also time forward / backward / update separately (extra syncs)")
     args = ap.parse_args()
@@ -47,6 +48,7 @@ def main():
     tr = OpensetRCNNTrainer(random_params(0), dtype=torch.float16, device=dev, lr=1e-5, loss_scale=1024.0)
     tr.overlap_targets = not args.no_overlap_targets
     tr.side_wgrad = not args.no_side_wgrad
+    tr.wgrad_on_main = set(x for x in args.wgrad_on_main.split(',') if x)
     g = torch.Generator().manual_seed(99 + rank)
     n, h, w = args.batch, 800, 1333
     images = torch.randint(0, 256, (n, 3, h, w), generator=g, dtype=torch.uint8).to(dev)

@@ -1,5 +1,5 @@
 """Experiment driver (not part of the product): the fused raw-image stem of a VARIANT library (OSR_VARIANT_LIB = a path from
-scripts/build_variant.sh, e.g. the SP_ABL ablations of osr_stem_pool.hip) at the bench's size; prints one time."""
+scripts/build_variant.sh: a previous revision of osr_stem_pool.hip, or one with sections stubbed out -- the round-5 ablations, -DSP_ABL=1..4, are in the history of that file) at the bench's size; prints one time."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
