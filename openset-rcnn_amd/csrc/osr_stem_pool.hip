@@ -6,19 +6,23 @@
 // "view" convolution on the generic implicit-GEMM kernel (K padded 147 -> 256, 0.29 ms) and osr_maxpool3x3s2 (0.16 ms), with the
 // 550 MB stem output written to HBM and read back in between.
 //
-// Design (MI355X): persistent workgroups (4 waves, 51 KB of LDS: three per CU; the weights stay in registers), one tile at a time = a 4 x 16 tile of POOLED pixels = a 9 x 33 region of stem
-// pixels (the pool's halo is recomputed: 297 / 256 = 1.16x) = a 23 x 72-pixel patch of the pre-padded NHWC4 image, staged in LDS
-// once (every input pixel feeds up to 16 stem pixels).
-//  * conv: v_mfma_f32_16x16x32 with the WEIGHTS as the A operand (m = 16 output channels: wave w owns channels 16 w .. 16 w + 15 and
-//    keeps its seven fragments -- one per kernel row -- in registers for the whole tile) and the PIXELS as the B operand (n = 16 stem
-//    pixels of the flattened 9 x 33 region, k = one kernel row: 8 pixels x 4 channels = 64 contiguous bytes of the patch, one
-//    ds_read_b128 per lane; the 8th pixel and the 4th channel meet zero weights). Seven K steps per 16 x 16 tile instead of the
-//    eight of the padded view, no tile tails (19 groups of 16 for 297 pixels).
+// Design (MI355X): persistent workgroups (4 waves, 51 KB of LDS: three per CU, each walks ~22 tiles at the bench's size; the weights stay
+// in registers), one tile at a time = a 4 x 16 tile of POOLED pixels = a 9 x 33 region of stem pixels (the pool's halo is recomputed:
+// 297 / 256 = 1.16x) = a 23 x 72-pixel patch of the pre-padded NHWC4 image, staged in LDS once (every input pixel feeds up to 16 stem pixels).
+//  * conv: v_mfma_f32_16x16x32 with the WEIGHTS as the A operand (m = 16 output channels; a wave owns the 32 channels of half w & 1 and
+//    keeps its 2 x 7 fragments -- one per kernel row -- in registers) and the PIXELS as the B operand (n = 16 stem pixels of the
+//    flattened 9 x 33 region -- a wave takes every second group of 16: w >> 1 --, k = one kernel row: 8 pixels x 4 channels = 64
+//    contiguous bytes of the patch, one ds_read_b128 per lane; the 8th pixel and the 4th channel meet zero weights). Seven K steps per
+//    16 x 16 tile instead of the eight of the padded view, no tile tails (19 groups of 16 for 297 pixels). The group loop is unrolled
+//    and a lane's per-group LDS offsets are computed once per workgroup (one packed register per group).
 //  * D = W X^T hands a lane four consecutive channels of one pixel: bias, ReLU, round to the storage dtype (the same rounding point
-//    as the separate launches), 8-byte write into the LDS image of the stem region; pixels outside the stem map are written as 0
-//    (post-ReLU values are >= 0, so a zero stands in for the pool's padding).
+//    as the separate launches; packed adds / conversions), 8-byte write into the LDS image of the stem region; pixels outside the stem
+//    map are written as 0 (post-ReLU values are >= 0, so a zero stands in for the pool's padding) -- only tiles on the map's border
+//    carry that select.
 //  * pool: thread = (pooled pixel, 16 channels): nine 32-byte LDS reads (pieces XOR-swizzled by the column so that neighbouring
-//    pooled pixels, two columns apart, do not share banks), fp32 max, two 16-byte stores; the tile's output rows are 2 KB runs.
+//    pooled pixels, two columns apart, do not share banks), maximum on the raw 16-bit patterns (v_pk_max_i16: the values are >= 0),
+//    two 16-byte stores; the tile's output rows are 2 KB runs.
+// Round 5 rebuilt the kernel from its counters (vector-ALU issue, then LDS reads: DESIGN.md section 3): 222 -> 161 us standalone.
 // Same K order (kernel rows ascending, fp32 accumulation) and rounding points as osr_conv2d_fwd(stem view) + osr_maxpool3x3s2.
 #include "osr_common.h"
 #include <type_traits>
