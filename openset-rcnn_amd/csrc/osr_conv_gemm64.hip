@@ -873,8 +873,8 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
 
     if constexpr (EPI == 1) {
         // ---- fused CF-RPN tail (classification_free_rpn.py:159-161): t = relu(conv + bias) is parked in LDS in the
-        // storage dtype (exactly what the unfused path writes to HBM), then two threads per pixel compute
-        // ||t||^2 and the five 1x1 dot products, normalise, add the 1x1 biases and apply the sigmoid. ----
+        // storage dtype (exactly what the unfused path writes to HBM); ||t||^2 and the five 1x1 dot products come from 32 MFMAs per
+        // wave on that tile (below), then one lane per pixel normalises, adds the 1x1 biases and applies the sigmoid. ----
         constexpr int LDT = 256 + 8;  // elements per t row (528 B: 16-B aligned, conflict-free chunk walk)
         TI* s_t = reinterpret_cast<TI*>(lds);
 #pragma unroll
