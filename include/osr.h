@@ -211,7 +211,9 @@ osr_status osr_cfrpn_head_tail(const void* t, int32_t t_dtype, int64_t rows, int
  * L2-normalise, both 1x1 convs and the sigmoid. p describes the 3x3 convolution (cout must be 256, cin %% 64 == 0,
  * no residual; p->relu/out_* are ignored). w_tail: (5, 256) fp32, rows 0-3 = anchor_deltas, row 4 = centerness;
  * b_tail: (5). deltas/ctr are indexed by pixel (n*ho + oh)*wo + ow. Returns OSR_ERR_UNSUPPORTED outside that
- * envelope: run osr_conv2d_fwd + osr_cfrpn_head_tail instead. */
+ * envelope: run osr_conv2d_fwd + osr_cfrpn_head_tail instead. The tail's dot products and ||t||^2 also run on the matrix
+ * cores (the fp32 tail weights as three exact storage-dtype terms each, fp32 accumulation): equal to the un-fused pair up to
+ * the fp32 summation order (1e-7 absolute on O(1) outputs), not bit for bit. */
 osr_status osr_cfrpn_head_fwd(const osr_conv_params* p, const void* in, const void* weight, const float* bias,
                               const float* w_tail, const float* b_tail, float* deltas, float* ctr, void* stream);
 /* One pyramid level of a multi-level launch: a dense NHWC input (n, hi, wi, cin) of the storage dtype and where its results go. */
