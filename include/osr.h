@@ -216,6 +216,17 @@ osr_status osr_cfrpn_head_tail(const void* t, int32_t t_dtype, int64_t rows, int
  * the fp32 summation order (1e-7 absolute on O(1) outputs), not bit for bit. */
 osr_status osr_cfrpn_head_fwd(const osr_conv_params* p, const void* in, const void* weight, const float* bias,
                               const float* w_tail, const float* b_tail, float* deltas, float* ctr, void* stream);
+/* TWO convolutions of the same input and geometry in ONE launch: [d2] BottleneckBlock.forward of a stage's first block applies
+ * `self.conv1` (1x1, stride s, FrozenBN folded, ReLU) and `self.shortcut` (1x1, stride s, no ReLU) to the same x
+ * (build_resnet_fpn_backbone selected by /root/reference/configs/Base-RCNN-FPN.yaml:3-8). p gives the shared geometry (n, hi, wi, cin,
+ * ho, wo, kernel, stride, pad, input strides, dtypes); its cout / relu / out strides / residual fields are ignored. Convolution A
+ * (w_a (cout_a, kh, kw, cin), bias_a, relu_a) writes the dense (n, ho, wo, cout_a) tensor out_a, B likewise; cout_a and cout_b are
+ * multiples of 128, cin of 64, storage f16 / bf16. Bit-identical to two osr_conv2d_fwd launches that run on the 128 x 128 tile.
+ * Returns OSR_ERR_UNSUPPORTED (nothing launched) outside that envelope. */
+osr_status osr_conv2d_fwd_pair(const osr_conv_params* p, const void* in, const void* w_a, const float* bias_a, int32_t cout_a,
+                               int32_t relu_a, void* out_a, const void* w_b, const float* bias_b, int32_t cout_b, int32_t relu_b,
+                               void* out_b, void* stream);
+
 /* One pyramid level of a multi-level launch: a dense NHWC input (n, hi, wi, cin) of the storage dtype and where its results go. */
 typedef struct osr_conv_level {
     const void* in;   /* (n, hi, wi, cin), dense */

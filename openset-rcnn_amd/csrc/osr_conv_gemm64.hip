@@ -112,6 +112,16 @@ struct Conv64Args {
     // convolution over several dense NHWC inputs -- the FPN output convs, the CF-RPN head over p2..p6 -- as ONE grid. The M tiles of
     // level l are the linear tiles [lv[l].tile_begin, lv[l + 1].tile_begin); a workgroup looks its level up and takes the fields below
     // from it instead of from the single-problem fields above. nlevels == 0: a single problem.
+    // Column groups (osr_conv2d_fwd_pair: EPI == 0, SPLIT == 0 instantiations): TWO convolutions of the same input and geometry -- the
+    // projection shortcut and conv1 of a stage's first bottleneck -- as one grid: the N tiles [cg[g].tile_begin, ...) belong to group g,
+    // which brings its own weights, bias, ReLU flag and dense output. ngroups <= 1: a single convolution.
+    int ngroups = 0;
+    struct Group {
+        const void* w; const float* bias; void* out;
+        long long out_stride_n, out_stride_h;
+        int tile_begin, cout, relu;
+        unsigned w_bytes;
+    } cg[2];
     int nlevels = 0;
     struct Level {
         const void* in; void* out; float* tail_deltas; float* tail_ctr;
@@ -228,8 +238,19 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
             tile_m -= L.tile_begin;
         }
     }
+    int e_cout = p.cout, e_relu = p.relu, tile_n_l = tile_n;
+    long long e_osw = p.out_stride_w;
+    unsigned e_w_bytes = a.w_bytes;
+    if constexpr (EPI == 0 && SPLIT == 0) {
+        if (a.ngroups > 1) {
+            const Conv64Args::Group& G = a.cg[tile_n >= a.cg[1].tile_begin ? 1 : 0];
+            e_w = G.w; e_bias = G.bias; e_out = G.out; e_osn = G.out_stride_n; e_osh = G.out_stride_h; e_osw = G.cout;
+            e_cout = G.cout; e_relu = G.relu; e_w_bytes = G.w_bytes;
+            tile_n_l = tile_n - G.tile_begin;
+        }
+    }
     const long long m0 = (long long)tile_m * BM;
-    const int n0 = tile_n * BN;
+    const int n0 = tile_n_l * BN;  // (first output channel of the tile, inside its column group)
     if (p.row_seg_counts) {  // segmented rows (padded per-image lists): a tile without a single data row has nothing to do (wave-uniform)
         const long long sr = p.row_seg_rows, mend = m0 + BM < e_M ? m0 + BM : e_M;
         bool any = false;
@@ -241,7 +262,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
     }
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(e_in), 0, e_in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(e_w), 0, a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(e_w), 0, e_w_bytes, 0x00020000);
 
     // ---- per-lane gather descriptors: this lane serves row (piece*8 + lane/8), LDS slot lane%8.
     //      a_off0 = byte offset of element (n, ih0, iw0, chunk) -- wraps below zero where the window starts in the padding --
@@ -299,7 +320,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
         // two 16-row sub-tiles are the eight consecutive channels 8g..8g+7 (one 16-byte chunk of the parked image / of the output)
         const int wrow = EPI == 2 ? c64_chain_perm(row) : row;
         const long long o = ((long long)(n0 + wrow) * a.K + chunk * 8) * 2;
-        b_off[j] = (n0 + wrow < p.cout && o < (long long)OOB_OFF) ? (unsigned)o : OOB_OFF;
+        b_off[j] = (n0 + wrow < e_cout && o < (long long)OOB_OFF) ? (unsigned)o : OOB_OFF;
     }
 
     int kh = 0, kw = 0, c0 = 0;  // tap / channel origin of the current K slice (non-stem)
@@ -384,7 +405,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
 #pragma unroll
         for (int jp = 0; jp < TNP; ++jp) {
             const int co = n0 + (wc * TN + jp * 2) * 32 + cseg;
-            const int cb = co < p.cout ? co : 0;
+            const int cb = co < e_cout ? co : 0;
             const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 b0 = SPLIT ? zero4 : *reinterpret_cast<const float4*>(e_bias + cb);
             const float4 b1 = SPLIT ? zero4 : *reinterpret_cast<const float4*>(e_bias + cb + 4);
@@ -399,9 +420,9 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
 #pragma unroll
                     for (int pass = 0; pass < NPASS; ++pass) {
                         const long long m = m0 + (wr * TM + i) * 32 + pass * RPP + (lane >> 3);
-                        const bool ok = m < e_M && co < p.cout;
+                        const bool ok = m < e_M && co < e_cout;
                         if (a.pw_dense & 4) {  // (wave-uniform) dense rows: the residual of row m starts at m * cout
-                            rres[i][pass] = *reinterpret_cast<const frag_t*>(res + (ok ? (unsigned)m * (unsigned)p.cout + (unsigned)co : 0u));
+                            rres[i][pass] = *reinterpret_cast<const frag_t*>(res + (ok ? (unsigned)m * (unsigned)e_cout + (unsigned)co : 0u));
                             continue;
                         }
                         const long long mm = ok ? m : 0;
@@ -975,7 +996,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
             for (int pass = 0; pass < NPASS; ++pass) {
                 const int row = pass * RPP + (lane >> 3);
                 const long long m = m0 + (wr * TM + i) * 32 + row;
-                if (m < e_M && co < p.cout) {
+                if (m < e_M && co < e_cout) {
                     const float4 v0 = *reinterpret_cast<const float4*>(slab + row * EPI_LD + cseg);
                     const float4 v1 = *reinterpret_cast<const float4*>(slab + row * EPI_LD + cseg + 4);
                     float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -986,10 +1007,10 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
                     long long o_out, o_res = 0;
                     const bool need_res = !PRE_RES && p.res_mode != 0;  // (the 128-wide tiles hold the residual in registers already)
                     if ((a.pw_dense & 2) && (!need_res || (a.pw_dense & 4))) {
-                        o_out = o_res = (long long)((unsigned)m * (unsigned)p.cout + (unsigned)co);
+                        o_out = o_res = (long long)((unsigned)m * (unsigned)e_cout + (unsigned)co);
                     } else {
                         C64_ROW_TO_NHW(m, nimg, oh, ow);
-                        o_out = (long long)nimg * e_osn + (long long)oh * e_osh + (long long)ow * p.out_stride_w + co;
+                        o_out = (long long)nimg * e_osn + (long long)oh * e_osh + (long long)ow * e_osw + co;
                         if (need_res) {
                             const int rh = p.res_mode == 2 ? (oh >> 1) : oh, rw = p.res_mode == 2 ? (ow >> 1) : ow;
                             o_res = (long long)nimg * p.res_stride_n + (long long)rh * p.res_stride_h + (long long)rw * p.res_stride_w + co;
@@ -1010,7 +1031,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
                             for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
                         }
                     }
-                    if (p.relu) {
+                    if (e_relu) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                     }
@@ -1424,6 +1445,71 @@ extern "C" osr_status osr_cfrpn_head_fwd_ex(const osr_conv_params* p, const void
 #endif
     hipStream_t st = (hipStream_t)stream;
     return p->in_dtype == OSR_F16 ? cfrpn_fused_launch<f16_t>(a, st) : cfrpn_fused_launch<bf16_t>(a, st);
+}
+
+// ---- two convolutions of one input in one launch (include/osr.h: osr_conv2d_fwd_pair) ---------------------------------------------
+// [d2] BottleneckBlock.forward of a stage's FIRST block reads its input twice: `out = self.conv1(x)` (1x1, stride s, ReLU) and
+// `shortcut = self.shortcut(x)` (1x1, stride s, no ReLU; build_resnet_fpn_backbone, Base-RCNN-FPN.yaml:3-8). Both are 1x1 layers of a few
+// K slices whose time is the strided gather of x and the per-tile latency chain, not their FLOPs: as ONE grid (column groups: the N
+// tiles of the shortcut, then those of conv1) the gather runs once per M tile row-block instead of in two launches, and the small conv1
+// launch no longer leaves the chip half empty. Bit-identical to the two osr_conv2d_fwd launches on the 128 x 128 tile.
+extern "C" osr_status osr_conv2d_fwd_pair(const osr_conv_params* p, const void* in, const void* w_a, const float* bias_a, int32_t cout_a, int32_t relu_a,
+                                          void* out_a, const void* w_b, const float* bias_b, int32_t cout_b, int32_t relu_b, void* out_b, void* stream) {
+    OSR_REQUIRE(p && in && w_a && bias_a && out_a && w_b && bias_b && out_b, OSR_ERR_INVALID_ARG, "osr_conv2d_fwd_pair: null pointer");
+    OSR_REQUIRE((p->in_dtype == OSR_F16 || p->in_dtype == OSR_BF16) && p->out_dtype == p->in_dtype, OSR_ERR_UNSUPPORTED, "osr_conv2d_fwd_pair: f16 / bf16 storage in and out");
+    OSR_REQUIRE(p->res_mode == 0 && p->pad_mode == 0 && !p->row_seg_counts, OSR_ERR_UNSUPPORTED, "osr_conv2d_fwd_pair: no residual / stem view / row segments");
+    OSR_REQUIRE(cout_a >= 128 && cout_b >= 128 && cout_a % 128 == 0 && cout_b % 128 == 0 && p->cin % 64 == 0, OSR_ERR_UNSUPPORTED,
+                "osr_conv2d_fwd_pair: both output widths multiples of 128, cin a multiple of 64");
+    OSR_REQUIRE(p->n >= 1 && p->hi >= 1 && p->wi >= 1 && p->kh >= 1 && p->kw >= 1 && p->kh * p->kw <= 31 && p->stride_h >= 1 && p->stride_w >= 1 && p->pad_h >= 0 && p->pad_w >= 0,
+                OSR_ERR_INVALID_ARG, "osr_conv2d_fwd_pair: bad geometry");
+    OSR_REQUIRE((p->hi + 2 * p->pad_h - p->kh) / p->stride_h + 1 == p->ho && (p->wi + 2 * p->pad_w - p->kw) / p->stride_w + 1 == p->wo, OSR_ERR_INVALID_ARG,
+                "osr_conv2d_fwd_pair: ho/wo inconsistent with hi/wi/kernel/stride/pad");
+    OSR_REQUIRE(p->in_stride_w % 8 == 0 && p->in_stride_h % 8 == 0 && p->in_stride_n % 8 == 0 && p->in_stride_n > 0, OSR_ERR_INVALID_ARG,
+                "osr_conv2d_fwd_pair: input strides must be multiples of 8 elements");
+    OSR_REQUIRE((((uintptr_t)in | (uintptr_t)w_a | (uintptr_t)w_b | (uintptr_t)bias_a | (uintptr_t)bias_b | (uintptr_t)out_a | (uintptr_t)out_b) & 15) == 0, OSR_ERR_INVALID_ARG,
+                "osr_conv2d_fwd_pair: pointers must be 16-byte aligned");
+    const long long M = (long long)p->n * p->ho * p->wo, K = (long long)p->kh * p->kw * p->cin, in_bytes = (long long)p->n * p->in_stride_n * 2;
+    const long long wide = cout_a > cout_b ? cout_a : cout_b;
+    OSR_REQUIRE(M < (1ll << 31) - 1024 && in_bytes < (1ll << 31) - 4096 && wide * K * 2 < (1ll << 31) - 4096 && M * wide < (1ll << 31), OSR_ERR_UNSUPPORTED,
+                "osr_conv2d_fwd_pair: tensor too large for 32-bit offsets");
+    Conv64Args a;
+    a.p = *p; a.p.cout = cout_a + cout_b;
+    a.in = in; a.w = w_a; a.bias = bias_a; a.res = nullptr; a.mask = nullptr; a.out = out_a;
+    a.M = M; a.K = (int)K;
+    a.div_howo = fastdiv_make((unsigned)(p->ho * p->wo));
+    a.div_wo = fastdiv_make((unsigned)p->wo);
+    a.in_bytes = (unsigned)in_bytes; a.w_bytes = (unsigned)(cout_a * K * 2);
+    a.stem = 0; a.tap_minor = p->kh * p->kw > 1 ? tap_minor_default() : 0;
+    a.tail_w = a.tail_b = nullptr; a.tail_deltas = a.tail_ctr = nullptr; a.tail_lds_off = 0;
+    a.w3 = nullptr; a.bias3 = nullptr; a.cout3 = 0; a.w3_bytes = a.out_bytes = 0;
+#ifdef C64_STAMPS
+    a.dbg = g_c64_stamps; a.p8 = nullptr;
+#endif
+    const bool in_dense = p->in_stride_w == p->cin && p->in_stride_h == (long long)p->wi * p->cin && p->in_stride_n == (long long)p->hi * p->wi * p->cin;
+    a.pw_dense = 2 | ((p->kh == 1 && p->kw == 1 && p->stride_h == 1 && p->stride_w == 1 && p->pad_h == 0 && p->pad_w == 0 && in_dense) ? 1 : 0);  // both outputs are dense
+    a.ngroups = 2;
+    const int couts[2] = {cout_a, cout_b}, relus[2] = {relu_a, relu_b};
+    const void* ws[2] = {w_a, w_b}; const float* bs[2] = {bias_a, bias_b}; void* outs[2] = {out_a, out_b};
+    int tb = 0;
+    for (int g = 0; g < 2; ++g) {
+        Conv64Args::Group& G = a.cg[g];
+        G.w = ws[g]; G.bias = bs[g]; G.out = outs[g]; G.cout = couts[g]; G.relu = relus[g] ? 1 : 0;
+        G.out_stride_h = (long long)p->wo * couts[g]; G.out_stride_n = (long long)p->ho * G.out_stride_h;
+        G.w_bytes = (unsigned)(couts[g] * K * 2);
+        G.tile_begin = tb;
+        tb += couts[g] / 128;
+    }
+    a.two_stage = 0;
+    a.tiles_m = (int)((M + 127) / 128);
+    a.tiles_n = tb;
+    a.tile0 = 0; a.ntile = a.tiles_m * a.tiles_n; a.ksplit = 1; a.split_stride = 0;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = conv64_lds_bytes(128, 128, 0, 4);
+    if (p->in_dtype == OSR_F16) hipLaunchKernelGGL((conv_igemm64_kernel<f16_t, f16_t, 128, 128, 2, 2, 0, 0, 0>), dim3((unsigned)a.ntile), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((conv_igemm64_kernel<bf16_t, bf16_t, 128, 128, 2, 2, 0, 0, 0>), dim3((unsigned)a.ntile), dim3(256), lds, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { osr_set_error("osr_conv2d_fwd_pair: launch failed: %s", hipGetErrorString(e)); return OSR_ERR_LAUNCH; }
+    return OSR_OK;
 }
 
 // ---- multi-level launches (include/osr.h: osr_conv2d_fwd_levels, osr_cfrpn_head_fwd_levels) ------------------------------------

@@ -114,6 +114,7 @@ PROTOTYPES = {
     "osr_cfrpn_head_tail": (I32, [P, I32, I64, I32, P, P, P, P, P, P, P]),
     "osr_cfrpn_head_fwd": (I32, [C.POINTER(ConvParams), P, P, P, P, P, P, P, P]),
     "osr_cfrpn_head_fwd_ex": (I32, [C.POINTER(ConvParams), P, P, P, P, P, P, P, P, P]),
+    "osr_conv2d_fwd_pair": (I32, [C.POINTER(ConvParams), P, P, P, I32, I32, P, P, P, I32, I32, P, P]),
     "osr_conv2d_fwd_levels": (I32, [C.POINTER(ConvParams), I32, C.POINTER(ConvLevel), P, P, P]),
     "osr_cfrpn_head_fwd_levels": (I32, [C.POINTER(ConvParams), I32, C.POINTER(ConvLevel), P, P, P, P, P]),
     "osr_rpn_select_capacity": (I32, [C.POINTER(RpnLevels), I32]),

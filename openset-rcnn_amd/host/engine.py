@@ -210,8 +210,12 @@ class OpensetRCNNEngine:
                     nbytes = x.numel() * x.element_size() + y.numel() * y.element_size() + sum(w[f"{pre}.{c}.w"].numel() for c in names) * x.element_size()
                     self.profile.append((pre + " (fused block)", flops, e0, e1, nbytes, flops))
                 return y
-        sc = self._conv(x, pre + ".shortcut", stride) if first else x
-        o = self._conv(x, pre + ".conv1", stride, relu=True)
+        pair = self._shortcut_conv1_one_launch(x, pre, stride) if first and self.fuse_levels else None
+        if pair is not None:
+            sc, o = pair
+        else:
+            sc = self._conv(x, pre + ".shortcut", stride) if first else x
+            o = self._conv(x, pre + ".conv1", stride, relu=True)
         if self.chain_res3 and w[pre + ".conv2.w"].shape[0] == 128 and w[pre + ".conv3.w"].shape[0] == 512:
             if self.profile is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -309,6 +313,23 @@ class OpensetRCNNEngine:
         """pool_rois' rows as (m, 7, 7, 256): what `keep` hands to tests and diagnostics."""
         m, P = pooled.shape[0], self.cfg["pooler_resolution"]
         return pooled.view(m, P, P, 256)
+
+    def _shortcut_conv1_one_launch(self, x, pre, stride):
+        """A stage's first bottleneck reads its input twice ([d2] BottleneckBlock.forward: self.shortcut(x), self.conv1(x)): both 1x1 layers
+        as ONE launch (ops.conv2d_pair, bit-identical to the two). Returns (shortcut output, relu(conv1 output)) or None."""
+        w = self.w
+        if self.profile is None:
+            return ops.conv2d_pair(x, w[pre + ".shortcut.w"], w[pre + ".shortcut.b"], False, w[pre + ".conv1.w"], w[pre + ".conv1.b"], True, stride, 0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = ops.conv2d_pair(x, w[pre + ".shortcut.w"], w[pre + ".shortcut.b"], False, w[pre + ".conv1.w"], w[pre + ".conv1.b"], True, stride, 0)
+        e1.record()
+        if out is not None:
+            px = out[0].numel() // out[0].shape[-1]
+            flops = 2.0 * px * (w[pre + ".shortcut.w"].numel() + w[pre + ".conv1.w"].numel())
+            nbytes = (x.numel() // (stride * stride) + out[0].numel() + out[1].numel() + w[pre + ".shortcut.w"].numel() + w[pre + ".conv1.w"].numel()) * x.element_size()
+            self.profile.append((pre + ".shortcut+conv1 (one launch)", flops, e0, e1, nbytes, flops))
+        return out
 
     def _fpn_outputs_one_launch(self, lats):
         ws = [self.w[f"backbone.fpn_output{l}.w"] for l in (2, 3, 4, 5)]

@@ -416,6 +416,30 @@ def cfrpn_head_fused(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, 
     return deltas, ctr
 
 
+def conv2d_pair(x: torch.Tensor, w_a: torch.Tensor, b_a: torch.Tensor, relu_a: bool, w_b: torch.Tensor, b_b: torch.Tensor, relu_b: bool,
+                stride: int = 1, pad: int = 0):
+    """Two convolutions of the same input and geometry in ONE launch (osr_conv2d_fwd_pair: the projection shortcut and conv1 of a
+    stage's first bottleneck). Returns (out_a, out_b), or None outside the launch's envelope (the caller runs conv2d twice)."""
+    lib = _lib.load()
+    ca, kh, kw, cin = w_a.shape
+    cb = w_b.shape[0]
+    if tuple(w_b.shape[1:]) != (kh, kw, cin) or ca % 128 or cb % 128 or cin % 64 or x.dtype not in (torch.float16, torch.bfloat16):
+        return None
+    _need(x, name="x"); _need(w_a, x.dtype, "w_a"); _need(w_b, x.dtype, "w_b"); _need(b_a, torch.float32, "b_a"); _need(b_b, torch.float32, "b_b")
+    n, hi, wi, _ = x.shape
+    ho, wo = (hi + 2 * pad - kh) // stride + 1, (wi + 2 * pad - kw) // stride + 1
+    out_a = torch.empty((n, ho, wo, ca), dtype=x.dtype, device=x.device)
+    out_b = torch.empty((n, ho, wo, cb), dtype=x.dtype, device=x.device)
+    p = _conv_params(n, hi, wi, cin, ho, wo, ca + cb, kh, kw, stride, pad, x.dtype, x.dtype)
+    st = lib.osr_conv2d_fwd_pair(C.byref(p), _p(x), _p(w_a), _p(b_a), ca, int(relu_a), _p(out_a), _p(w_b), _p(b_b), cb, int(relu_b), _p(out_b), _stream())
+    if st == _lib.ERR_UNSUPPORTED:
+        return None
+    check(st, "osr_conv2d_fwd_pair")
+    if FLOP_COUNT is not None:
+        FLOP_COUNT["conv"] += 2.0 * n * ho * wo * (ca + cb) * kh * kw * cin
+    return out_a, out_b
+
+
 def _conv_levels(xs: Sequence[torch.Tensor], outs, deltas=None, ctrs=None, weights=None, biases=None):
     assert 1 <= len(xs) <= _lib.MAX_CONV_LEVELS
     arr = (_lib.ConvLevel * len(xs))()

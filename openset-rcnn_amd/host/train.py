@@ -307,8 +307,12 @@ class OpensetRCNNTrainer:
                 stride = 2 if (b == 0 and si > 0) else 1
                 if si + 2 <= self.freeze_at:  # frozen stage: part of the prefix above (nothing of it is needed by the backward)
                     break
-                sc = e._conv(x, pre + ".shortcut", stride) if b == 0 else x
-                o1 = e._conv(x, pre + ".conv1", stride, relu=True)
+                pair = e._shortcut_conv1_one_launch(x, pre, stride) if b == 0 and e.fuse_levels else None  # (one launch for the two readers of x)
+                if pair is not None:
+                    sc, o1 = pair
+                else:
+                    sc = e._conv(x, pre + ".shortcut", stride) if b == 0 else x
+                    o1 = e._conv(x, pre + ".conv1", stride, relu=True)
                 # res3: conv2 -> conv3 + shortcut as ONE launch that also stores conv2's output for the backward (bit-identical to the two)
                 ch = ops.conv2d_chain(o1, e.w[pre + ".conv2.w"], e.w[pre + ".conv2.b"], e.w[pre + ".conv3.w"], e.w[pre + ".conv3.b"], sc, 1, 1,
                                       keep_mid=True) if (self.chain_forward and e.w[pre + ".conv2.w"].shape[0] == 128 and e.w[pre + ".conv3.w"].shape[0] == 512) else None

@@ -143,3 +143,36 @@ def test_levels_repeat_screen_under_a_second_stream(ops):
         for a, f in zip(outs, first):
             assert torch.equal(a, f), f"launch {it} differs"
     torch.cuda.synchronize()
+
+
+# ---- two convolutions of one input in one launch (osr_conv2d_fwd_pair: shortcut + conv1 of a stage's first bottleneck) ------------------
+PAIR_CASES = [  # (n, h, w, cin, cout_a, cout_b, k, stride): res3.0 / res4.0 / res5.0 geometry, a stride-1 pair, a 3 x 3 pair, ragged M tiles
+    (2, 40, 56, 256, 512, 128, 1, 2), (2, 21, 29, 512, 1024, 256, 1, 2), (1, 13, 19, 1024, 2048, 512, 1, 2),
+    (2, 17, 23, 256, 256, 128, 1, 1), (1, 15, 22, 128, 128, 256, 3, 1)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", PAIR_CASES)
+def test_conv_pair_equals_the_two_launches(ops, case, dtype):
+    n, h, w, cin, ca, cb, k, stride = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = (torch.randn(n, h, w, cin, generator=g) * 0.5).to(dtype).to(DEV)
+    wa = (torch.randn(ca, k, k, cin, generator=g) / math.sqrt(k * k * cin)).to(dtype).to(DEV)
+    wb = (torch.randn(cb, k, k, cin, generator=g) / math.sqrt(k * k * cin)).to(dtype).to(DEV)
+    ba, bb = torch.randn(ca, generator=g).to(DEV), torch.randn(cb, generator=g).to(DEV)
+    got = ops.conv2d_pair(x, wa, ba, False, wb, bb, True, stride, k // 2)
+    assert got is not None
+    ya, yb = got
+    ra = ops.conv2d(x, wa, ba, stride, k // 2, relu=False)
+    rb = ops.conv2d(x, wb, bb, stride, k // 2, relu=True)
+    assert ya.shape == ra.shape and yb.shape == rb.shape
+    assert torch.equal(ya, ra) and torch.equal(yb, rb)
+    assert float(yb.min()) >= 0.0 and float(ya.min()) < 0.0  # the ReLU flag is per convolution
+
+
+def test_conv_pair_refuses_what_it_cannot_take(ops):
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(1, 8, 8, 256, generator=g)).half().to(DEV)
+    w64 = (torch.randn(64, 1, 1, 256, generator=g) / 16).half().to(DEV)
+    w128 = (torch.randn(128, 1, 1, 256, generator=g) / 16).half().to(DEV)
+    assert ops.conv2d_pair(x, w128, torch.zeros(128, device=DEV), False, w64, torch.zeros(64, device=DEV), True) is None  # 64 output channels
