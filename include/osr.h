@@ -212,8 +212,10 @@ osr_status osr_cfrpn_head_tail(const void* t, int32_t t_dtype, int64_t rows, int
  * no residual; p->relu/out_* are ignored). w_tail: (5, 256) fp32, rows 0-3 = anchor_deltas, row 4 = centerness;
  * b_tail: (5). deltas/ctr are indexed by pixel (n*ho + oh)*wo + ow. Returns OSR_ERR_UNSUPPORTED outside that
  * envelope: run osr_conv2d_fwd + osr_cfrpn_head_tail instead. The tail's dot products and ||t||^2 also run on the matrix
- * cores (the fp32 tail weights as three exact storage-dtype terms each, fp32 accumulation): equal to the un-fused pair up to
- * the fp32 summation order (1e-7 absolute on O(1) outputs), not bit for bit. */
+ * cores (each tail row scaled by a power of two, then its fp32 weights as three storage-dtype terms each -- exact for every weight
+ * within 2^-11 of its row's largest, at most 2^-35 of that largest off below --, fp32 accumulation, the scale undone on the
+ * sums; subnormal fp16 terms are multiplied as they are): equal to the un-fused pair up to the fp32 summation order (1e-7
+ * absolute on O(1) outputs), not bit for bit. */
 osr_status osr_cfrpn_head_fwd(const osr_conv_params* p, const void* in, const void* weight, const float* bias,
                               const float* w_tail, const float* b_tail, float* deltas, float* ctr, void* stream);
 /* TWO convolutions of the same input and geometry in ONE launch: [d2] BottleneckBlock.forward of a stage's first block applies

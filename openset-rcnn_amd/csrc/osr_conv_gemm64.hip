@@ -70,6 +70,8 @@ __device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv& f) {
 #define C64_MAX_LEVELS 6
 #define C64_TW_LD 264  // elements per row of the fused CF-RPN tail's split weight matrix in LDS (528 B)
 // bytes of LDS behind the parked tile: the (16, C64_TW_LD) weight matrix, later overwritten by the (rows, 16) fp32 slab of the tail's accumulators
+// biased fp32 exponent of a tail row's largest |weight| (bit pattern b), kept in [11, 254] so that both 2^(10 - e) and 2^(e - 10) are normal floats
+#define C64_TAIL_EXP(b) (min(max((b) >> 23, 11u), 254u))
 #define C64_TAIL_LDS(bm) ((size_t)(16 * C64_TW_LD * 2) > (size_t)(bm) * 64 ? (size_t)(16 * C64_TW_LD * 2) : (size_t)(bm) * 64)
 static_assert(C64_MAX_LEVELS == OSR_MAX_CONV_LEVELS, "include/osr.h: OSR_MAX_CONV_LEVELS");
 struct Conv64Args {
@@ -447,13 +449,28 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
     float tbias[EPI == 1 ? TN : 1][2];  // per-lane conv bias of its output columns ([.][1] only differs for 16x16 sub-tiles)
     if constexpr (EPI == 1) {
         // tail weights -> LDS (behind the staging / t-tile region); per-lane conv bias of its TN output columns
-        // The fp32 tail weights as THREE storage-dtype terms each (w = hi + mid + lo, every remainder exactly representable: 3 x 11
-        // or 3 x 8 significand bits cover fp32's 24) -> a (16, 256) B operand for the tail's MFMAs: rows q, 5 + q, 10 + q = hi, mid, lo
-        // of tail row q; row 15 zero. Row pitch C64_TW_LD elements (528 B: conflict-free fragment reads).
+        // The fp32 tail weights as THREE storage-dtype terms each (w * 2^s = hi + mid + lo) -> a (16, 256) B operand for the tail's MFMAs:
+        // rows q, 5 + q, 10 + q = hi, mid, lo of tail row q; row 15 zero. Row pitch C64_TW_LD elements (528 B: conflict-free fragment reads).
+        // Each tail row is first scaled by a power of two that brings its largest weight to [2^10, 2^11) (exact; undone on the fp32 sums
+        // in the epilogue): bf16's three 8-bit terms cover fp32's 24 significand bits at any magnitude, but fp16's terms run out of
+        // EXPONENT first -- at this head's initial scale (std 0.01) `mid` was an fp16 subnormal and `lo` underflowed, a per-weight error
+        // of ~3e-6 relative that grew as weight decay shrank the row. Scaled, every weight down to 2^-11 of its row's
+        // largest splits exactly (lo >= 2^-24 = fp16's subnormal spacing; the MFMA takes subnormal inputs as they are:
+        // tests/test_conv_8phase.py, tiny-weight case), and a smaller one is off by at most 2^-35 of the row's largest.
         TI* s_w16 = reinterpret_cast<TI*>(lds + a.tail_lds_off);
+        unsigned int* s_tmax = reinterpret_cast<unsigned int*>(lds + a.tail_lds_off + C64_TAIL_LDS(BM));  // bit patterns of max |w| per tail row
+        if (tid < 8) s_tmax[tid] = 0u;
+        __syncthreads();
+        for (int i = tid; i < 5 * 256; i += NT) {  // (a wave's 64 consecutive i lie in one row; trip counts are wave-uniform)
+            unsigned int b = __float_as_uint(fabsf(a.tail_w[i]));
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) b = max(b, (unsigned int)__shfl_xor((int)b, o, 64));
+            if (lane == 0) atomicMax(&s_tmax[i >> 8], b);
+        }
+        __syncthreads();
         for (int i = tid; i < 5 * 256; i += NT) {
             const int q = i >> 8, k = i & 255;
-            const float w = a.tail_w[i];
+            const float w = a.tail_w[i] * __uint_as_float((264u - C64_TAIL_EXP(s_tmax[q])) << 23);  // x 2^(10 - exponent of the row's max)
             const TI hi = (TI)w;
             const float r1 = w - (float)hi;
             const TI mid = (TI)r1;
@@ -968,8 +985,13 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
             if (m < e_M) {
                 const float inv = 1.0f / fmaxf(sqrtf(v3.w), 1e-12f);
                 const float d0 = v0.x + (v1.y + v2.z), d1 = v0.y + (v1.z + v2.w), d2 = v0.z + (v1.w + v3.x), d3 = v0.w + (v2.x + v3.y), d4 = v1.x + (v2.y + v3.z);
-                *reinterpret_cast<float4*>(e_tail_deltas + m * 4) = make_float4(d0 * inv + a.tail_b[0], d1 * inv + a.tail_b[1], d2 * inv + a.tail_b[2], d3 * inv + a.tail_b[3]);
-                e_tail_ctr[m] = 1.0f / (1.0f + expf(-(d4 * inv + a.tail_b[4])));
+                // (undo each tail row's power-of-two weight scale: exact)
+                const unsigned int* s_tmax = reinterpret_cast<const unsigned int*>(lds + a.tail_lds_off + C64_TAIL_LDS(BM));
+#define C64_TAIL_UNSCALE(q) (inv * __uint_as_float((C64_TAIL_EXP(s_tmax[q]) - 10u) << 23))
+                *reinterpret_cast<float4*>(e_tail_deltas + m * 4) = make_float4(d0 * C64_TAIL_UNSCALE(0) + a.tail_b[0], d1 * C64_TAIL_UNSCALE(1) + a.tail_b[1],
+                                                                                d2 * C64_TAIL_UNSCALE(2) + a.tail_b[2], d3 * C64_TAIL_UNSCALE(3) + a.tail_b[3]);
+                e_tail_ctr[m] = 1.0f / (1.0f + expf(-(d4 * C64_TAIL_UNSCALE(4) + a.tail_b[4])));
+#undef C64_TAIL_UNSCALE
             }
         }
         return;
@@ -1320,7 +1342,7 @@ static osr_status cfrpn_fused_launch(Conv64Args& a, hipStream_t st) {
         a.ntile = a.tiles_m;
         const size_t t_bytes = (size_t)256 * (256 + 8) * 2, stages = (size_t)2 * (256 + 256) * 128;
         a.tail_lds_off = (int)(t_bytes > stages ? t_bytes : stages);
-        const size_t lds = (size_t)a.tail_lds_off + C64_TAIL_LDS(256);
+        const size_t lds = (size_t)a.tail_lds_off + C64_TAIL_LDS(256) + 32;
         static osr_dev_mask attr8{0};
         osr_once_per_device(attr8, [] {
             allow_big_lds(conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1, 2>);
@@ -1342,7 +1364,7 @@ static osr_status cfrpn_fused_launch(Conv64Args& a, hipStream_t st) {
     a.ntile = a.tiles_m;
     const size_t t_bytes = (size_t)128 * (256 + 8) * 2, stage = (size_t)(128 + 256) * 128;
     a.tail_lds_off = (int)(t_bytes > stage ? t_bytes : stage);
-    const size_t lds = (size_t)a.tail_lds_off + C64_TAIL_LDS(128);
+    const size_t lds = (size_t)a.tail_lds_off + C64_TAIL_LDS(128) + 32;
     static osr_dev_mask attr{0};
     osr_once_per_device(attr, [] { allow_big_lds(conv_igemm64_kernel<TI, TI, 128, 256, 2, 2, 1, 0>); });
     hipLaunchKernelGGL((conv_igemm64_kernel<TI, TI, 128, 256, 2, 2, 1, 0>), dim3((unsigned)a.tiles_m), dim3(256), lds, st, a);
@@ -1598,7 +1620,7 @@ static osr_status cfrpn_levels_launch(Conv64Args& a, hipStream_t st) {
     a.tiles_n = 1; a.tile0 = 0; a.ntile = a.tiles_m; a.ksplit = 1; a.split_stride = 0;
     const size_t t_bytes = (size_t)256 * (256 + 8) * 2, stages = (size_t)2 * (256 + 256) * 128;
     a.tail_lds_off = (int)(t_bytes > stages ? t_bytes : stages);
-    const size_t lds = (size_t)a.tail_lds_off + C64_TAIL_LDS(256);
+    const size_t lds = (size_t)a.tail_lds_off + C64_TAIL_LDS(256) + 32;
     static osr_dev_mask attr{0};
     osr_once_per_device(attr, [] { allow_big_lds(conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1, 2>); });
     hipLaunchKernelGGL((conv_igemm64_kernel<TI, TI, 256, 256, 2, 4, 1, 2>), dim3((unsigned)a.tiles_m), dim3(512), lds, st, a);

@@ -266,10 +266,16 @@ __device__ int tr_select_smallest(MemberF member, KeyF keyf, int cnt, int k, uns
     }
     int gt = 0, eq = 0;
     TR_WALK_BLOCKED({ if (mem) { if (all || v > T) ++gt; else if (v == T) ++eq; } })
+    // One packed scan: gt in bits 0..10 (the candidates above the threshold number fewer than k <= TR_MAXK in total), eq -- SATURATED at
+    // TR_MAXK per thread -- above. The count of candidates EQUAL to the threshold is unbounded (all-equal keys: the whole list), so the raw
+    // count would run over the packed field; only ranks below `remaining` <= TR_MAXK are ever used: while a thread's true prefix is below
+    // `remaining` no earlier thread was saturated and the saturated prefix IS the true one, and once one was, the prefix is >= TR_MAXK >=
+    // remaining as the true one is. 1024 threads x 512 << 11 = 2^30: the packed sum stays a positive int.
+    static_assert(TR_MAXK <= 512 && TR_THREADS <= 1024, "packed (gt, eq) scan: TR_THREADS * TR_MAXK << 11 must stay below 2^31");
     int tot;
-    const int packed = osr_block_excl_scan(gt | (eq << 16), s_scan, &tot);
-    int pg = packed & 0xffff, pe = packed >> 16;
-    const int ngt_total = tot & 0xffff;
+    const int packed = osr_block_excl_scan(gt | (min(eq, TR_MAXK) << 11), s_scan, &tot);
+    int pg = packed & 0x7ff, pe = packed >> 11;
+    const int ngt_total = tot & 0x7ff;
     TR_WALK_BLOCKED({
         if (mem) {
             const unsigned long long comp = ((unsigned long long)v << 32) | (unsigned int)(0xffffffffu - (unsigned int)i);

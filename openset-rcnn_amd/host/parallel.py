@@ -57,6 +57,15 @@ def merge_sharded(results: List[List[Any]]) -> List[Any]:
     return merged
 
 
+def poison_unless_(ok: torch.Tensor, grad_elem: torch.Tensor) -> None:
+    """Make a RANK-LOCAL verdict global without a collective of its own: when the one-element flag `ok` is 0, add +inf to `grad_elem`
+    (a one-element view into this rank's flat gradient) BEFORE its bucket is reduced. The sum over ranks is then non-finite on every
+    rank, and the finiteness check of the all-reduced buffer -- the one verdict that gates the update, the momentum and the loss scale
+    -- comes out the same everywhere. No host sync; two element-sized launches."""
+    inf = torch.full_like(grad_elem, float("inf"))
+    grad_elem.add_(torch.where(ok.to(torch.bool).view_as(grad_elem), torch.zeros_like(grad_elem), inf))
+
+
 def all_reduce_sum_(flat: torch.Tensor) -> int:
     """In-place sum of one flat buffer over all ranks (the training step's gradient exchange: a single RCCL all-reduce of
     the 166 MB fp32 gradient buffer; gloo on CPU in the tests). Returns the world size (1 when not distributed)."""

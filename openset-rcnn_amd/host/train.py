@@ -125,6 +125,9 @@ class OpensetRCNNTrainer:
         # the CF-RPN head's backward runs on the sampled anchors only and recomputes their hidden state (osr_rpn_sparse.hip); False:
         # the dense launches of rounds 1-3 (the fused head kernel then also writes the hidden state of every anchor: 0.7 GB)
         self.sparse_rpn_bwd = True
+        # None: the list's own capacity (n x 2 x RPN.BATCH_SIZE_PER_IMAGE). A smaller number makes an iteration whose list is longer
+        # count as not fitting (tests: the skipped-update path without a pathological sampler)
+        self.sparse_rows_cap: Optional[int] = None
         self.dtype, self.device = dtype, self.eng.device
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         self.scaler = DynamicLossScale(loss_scale, scale_growth_interval, self.eng.device)
@@ -515,9 +518,12 @@ class OpensetRCNNTrainer:
                 cap = n * 2 * int(c["rpn_batch_size"])
                 ids, rmap, cnt2 = ops.rpn_sparse_rows(d5, cap)
                 # count2 = {listed, found}: rows beyond the cap are dropped by the list (the reference sampler bounds them by 2 x 256 per image;
-                # another sampler, or NaN spilling into unsampled rows, could exceed it). _update() skips the iteration's update when that
-                # happened, like a gradient overflow, instead of applying an update that misses the coarsest levels' gradients
-                self._sparse_rows_fit = (cnt2[1:2] <= cap).to(torch.int32)
+                # another sampler, or NaN spilling into unsampled rows, could exceed it). The iteration's update is then skipped like a
+                # gradient overflow, instead of applying an update that misses the coarsest levels' gradients -- on EVERY rank: the verdict
+                # is rank-local (this rank's list), so it is folded into the gradient itself (an inf in this layer's bias gradient, below,
+                # in front of its bucket's all-reduce) and reaches the other ranks through the sum; _update() then sees a non-finite
+                # all-reduced buffer everywhere. (the flag used to gate this rank's update only; the peers applied theirs.)
+                rows_fit = (cnt2[1:2] <= min(cap, self.sparse_rows_cap or cap)).to(torch.int32)
                 cols, d5r = ops.rpn_gather_cols(sel["levels"], [p[k_] for k_ in lvl_keys], n, ids, d5)
                 w3 = e.w[rn + ".w"].view(256, 9 * 256)
                 t_rows = ops.linear(cols, w3, e.w[rn + ".b"], relu=True)
@@ -526,6 +532,7 @@ class OpensetRCNNTrainer:
                 g["rpn_tail.b"].copy_(db_tail)
                 ops.conv2d_wgrad(cols.view(1, cap, 1, 9 * 256), dt_rows.view(1, cap, 1, 256), 1, 1, dw=g[rn + ".w"].view(256, 1, 1, 9 * 256))
                 ops.bias_grad(dt_rows, g[rn + ".b"])
+                parallel.poison_unless_(rows_fit, g[rn + ".b"].view(-1)[:1])
                 y_rows = ops.linear(dt_rows, w3.t().contiguous(), ops._zero_bias(9 * 256, self.device), out_dtype=torch.float32)
                 return (rmap, y_rows), torch.cuda.current_stream(self.device).record_event()
             dta, dw_tail, db_tail = ops.cfrpn_tail_bwd(s["rpn_t"], e.rpn_wtail, d5)
@@ -684,10 +691,6 @@ class OpensetRCNNTrainer:
         gs = 1.0 / (getattr(self, "_scale_used", self.loss_scale) * world)
         self._ok.fill_(1)
         ops.check_finite_(self.grad_flat, self._ok)
-        fit = getattr(self, "_sparse_rows_fit", None)
-        if fit is not None:  # the sparse CF-RPN backward listed every row with a gradient (see rpn_chain); else: skip, counted with the overflows
-            self._ok.mul_(fit)
-            self._sparse_rows_fit = None
         if self.multi_tensor_update:
             # every parameter tensor in ONE launch (osr_sgd_step_multi over a device-resident table), then every backward-data weight in
             # one more (_refresh_derived): ~145 launches of a few microseconds of work each became two; same bits per element

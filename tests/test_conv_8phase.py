@@ -149,6 +149,39 @@ def test_8phase_fused_head_matches_the_unfused_launches(ops, dtype):
     assert (d - d2.view_as(d)).abs().max().item() <= 1e-5 and (c - c2.view_as(c)).abs().max().item() <= 1e-6
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("scale", [1e-4, 1e-2, 30.0])
+def test_fused_head_tail_weights_of_any_magnitude_keep_fp32_accuracy(ops, dtype, scale):
+    """the tail's fp32 weights enter the matrix cores as three storage-dtype terms. fp16 terms run out of exponent range for
+    small weights (mid subnormal, lo flushed) unless each tail row is first scaled by a power of two: with weights around 1e-4 (what
+    weight decay drives the rows towards), at the init scale and at 30, the fused head stays within fp32 rounding of the fp64 value
+    computed from the parked hidden state -- relative to the row's own magnitude, so a truncated low term would show."""
+    g = torch.Generator().manual_seed(21)
+    n, h, w = 1, 64, 96
+    x = (torch.randn(n, h, w, 256, generator=g) * 0.5).to(dtype).to(DEV)
+    wt = (torch.randn(256, 3, 3, 256, generator=g) / 48).to(dtype).to(DEV)
+    b = (torch.randn(256, generator=g) * 0.1).to(DEV)
+    wtail = torch.randn(5, 256, generator=g) * scale
+    wtail[1] *= 37.0  # rows of different magnitude: the scale is per row
+    wtail[2, ::3] *= 2.0 ** -9  # weights far below their row's largest
+    wtail = wtail.to(DEV)
+    btail = torch.zeros(5, device=DEV)
+    hidden = torch.empty(n * h * w, 256, dtype=dtype, device=DEV)
+    d, c = ops.cfrpn_head_fused(x, wt, b, wtail, btail, hidden_out=hidden)
+    torch.cuda.synchronize()
+    t = hidden.double()
+    tn = t / t.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    ref = tn @ wtail.double().t()  # (rows, 5)
+    got = torch.cat((d.view(-1, 4).double(), torch.logit(c.view(-1, 1).double().clamp(1e-7, 1 - 1e-7))), dim=1)
+    for q in range(4):  # the four delta rows: relative to the row's typical output (|t_n| = 1, so ~ |w_q| in the mean)
+        mag = float(wtail[q].abs().max()) * 4
+        err = float((got[:, q] - ref[:, q]).abs().max())
+        assert err <= 3e-6 * mag, (q, err, mag)  # fp32 accumulation of 256 terms; the fp16 truncation was ~3e-6 x 16 x |w| and up
+    # centerness goes through a sigmoid: checked where it is not saturated
+    keep = ref[:, 4].abs() < 6
+    assert float((got[keep, 4] - ref[keep, 4]).abs().max()) <= 1e-5 * max(1.0, float(wtail[4].abs().max()) * 4) + 2e-5
+
+
 def test_8phase_repeat_screen_beside_a_second_stream(ops):
     """Forty launches each of a 3 x 3 and a deep 1 x 1 layer while another stream streams 256 MB through HBM: every output equal to the
     first (a unit read before it landed, or restaged before its last read retired, would differ in some tile)."""

@@ -206,3 +206,53 @@ def test_bucketed_all_reduce_equals_single_shot_and_loss_reduce():
     # the second pass reduced the already-summed buffer again: (a+b) + (a+b)
     assert torch.equal(flat, single * 2)
     assert red == {"loss_a": 15.0, "loss_b": 1.5}  # averaged on rank 0, sorted keys
+
+
+def _poison_worker(rank, world, port, bad_rank, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as ge
+    ge.load_package()
+    from openset_rcnn_amd.host import parallel as P
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sizes = [4096, 12, 70000, 256, 33000]
+    layout, off = [], 0
+    for i, n in enumerate(sizes):
+        layout.append((f"p{i}", off, n))
+        off += n
+    flat = torch.randn(off, generator=torch.Generator().manual_seed(7 + rank))
+    buckets = P.GradBuckets(flat, layout, bucket_bytes=100_000)
+    # the trainer's rpn_chain: the rank-local verdict ("my sparse row list fitted") goes into one element of the layer's bias
+    # gradient BEFORE that bucket is marked done
+    fit = torch.tensor([0 if rank == bad_rank else 1], dtype=torch.int32)
+    name, o, _ = layout[3]
+    P.poison_unless_(fit, flat[o:o + 1])
+    local_finite = bool(torch.isfinite(flat).all())
+    for nm, _, _ in reversed(layout):
+        buckets.mark_done(nm)
+    buckets.finish()
+    q.put((rank, local_finite, bool(torch.isfinite(flat).all())))
+    dist.destroy_process_group()
+
+
+def test_a_rank_local_verdict_reaches_every_rank_through_the_gradient():
+    """ADVICE r05 (host/train.py: the sparse CF-RPN row list's 'did not fit' flag): only rank 1's list overflows; after the bucketed
+    all-reduce BOTH ranks hold a non-finite gradient, so both skip the update and halve the loss scale together. With no rank
+    overflowing the buffer stays finite."""
+    ctx = mp.get_context("spawn")
+    for bad, want in ((1, False), (-1, True)):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_poison_worker, args=(r, 2, port, bad, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        got = sorted(q.get(timeout=120) for _ in range(2))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert [g[0] for g in got] == [0, 1]
+        assert got[0][1] is True  # rank 0's own list fitted: its local gradient was clean ...
+        assert got[1][1] is (bad != 1)
+        assert got[0][2] is want and got[1][2] is want  # ... and the reduced buffer tells both ranks the same thing

@@ -125,6 +125,35 @@ def test_rpn_targets_full_size(ops):
     _check_rpn_losses(ops, c, lr, lo, mb, ct, 36)
 
 
+@pytest.mark.parametrize("kind", ["all_equal", "two_values", "equal_tail"])
+def test_subsample_heavily_tied_keys_against_the_oracle(ops, kind):
+    """the compaction's packed (gt, eq) scan must survive more than 65 535 candidates whose key EQUALS the selection
+    threshold (all-equal keys: every label-0 anchor of the 89 523). Tie rule: lower index wins (tests/test_oracle_kat.py)."""
+    r, n = 89523, 3
+    gg = g(91)
+    lab = torch.zeros(n, r, dtype=torch.int8)
+    lab[:, torch.randperm(r, generator=gg)[:3000]] = -1
+    lab[0, torch.randperm(r, generator=gg)[:700]] = 1
+    lab[1, torch.randperm(r, generator=gg)[:40]] = 1
+    if kind == "all_equal":
+        keys = torch.full((n, r), 0.5)
+    elif kind == "two_values":  # 80 000+ at the threshold value, the rest above it
+        keys = torch.where(torch.rand(n, r, generator=gg) < 0.93, torch.tensor(0.25), torch.tensor(0.75))
+    else:  # a few distinct small keys, then one huge tie group that the threshold lands in
+        keys = torch.full((n, r), 0.5)
+        keys[:, torch.randperm(r, generator=gg)[:100]] = torch.rand(n, 100, generator=gg) * 0.4
+    assert int((lab[2] == 0).sum()) > 65536
+    out = lab.clone().to(DEV)
+    np_, nn_ = ops.subsample_labels_(out, keys.to(DEV), 256, 0.5)
+    for i in range(n):
+        p, q = O.subsample_by_keys(lab[i], keys[i], 256, 0.5, 0)
+        ref = torch.full_like(lab[i], -1)
+        ref[p] = 1
+        ref[q] = 0
+        assert torch.equal(out[i].cpu(), ref), f"{kind}, image {i}: sampled labels differ from the oracle's"
+        assert int(np_[i]) == p.numel() and int(nn_[i]) == q.numel()
+
+
 # ------------------------------------------------------------------------------------------------------
 def _roi_case(seed, n, pcap, counts_p, counts_g, hw=(600, 800), gmax=8, ties=False):
     gg = g(seed)

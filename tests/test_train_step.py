@@ -288,6 +288,31 @@ def test_multi_tensor_update_is_bit_identical_to_one_launch_per_tensor(setup):
             assert torch.equal(a, state[False][group][k]), (group, k)
 
 
+def test_sparse_row_list_overflow_poisons_the_gradient_and_skips_the_update(setup):
+    """'the sparse CF-RPN row list did not fit' is a rank-local verdict; it must reach every rank. It is folded into the
+    gradient (inf in the head conv's bias gradient, in front of that bucket's all-reduce), so the finiteness check of the reduced
+    buffer fails everywhere. Here, one rank: an iteration whose list exceeds the (lowered) cap leaves a non-finite bias gradient,
+    changes no parameter and counts as an overflow; with the cap back the same trainer steps normally."""
+    from openset_rcnn_amd.host.train import OpensetRCNNTrainer
+    d = setup["dev"]
+    args = (d["images"], d["hw"], setup["h"], setup["w"], d["gt"], d["gcls"], d["gcnt"], d["keys"])
+    tr = OpensetRCNNTrainer(setup["params"], dtype=torch.float16, device=DEV, lr=0.01, loss_scale=512.0)
+    rn = "proposal_generator.rpn_head.conv"
+    before = {k: v.clone() for k, v in tr.master.items()}
+    tr.sparse_rows_cap = 3  # every real iteration lists more rows than this
+    tr.step(*args)
+    torch.cuda.synchronize()
+    assert not bool(torch.isfinite(tr.grad[rn + ".b"]).all()), "the verdict must be visible in the gradient itself"
+    assert all(torch.equal(before[k], tr.master[k]) for k in before), "an iteration whose list did not fit must not touch the masters"
+    assert tr.poll_overflow(wait=True)
+    tr.sparse_rows_cap = None
+    tr.step(*args)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(tr.grad_flat).all())
+    assert not tr.poll_overflow(wait=True)
+    assert sum(int(not torch.equal(before[k], tr.master[k])) for k in before) == len(before)
+
+
 def test_chained_res3_forward_gives_the_same_step(setup):
     """The trainer's res3 blocks run conv2 -> conv3 + shortcut as one launch that also stores conv2's output
     (osr_conv2d_chain_fwd_ex); against the two launches: identical losses and gradients, bit for bit (the chain kernel is bit-identical
