@@ -32,7 +32,25 @@
 #define RA_FWD_MAXX 96  // (forward) steps of the streamed (shorter) side of the footprint; beyond: the per-bin loop. This model's pyramid: <= 44
 #endif
 #ifndef RA_PAIR
-#define RA_PAIR 1   // 2-byte features: two steps per wave instruction (16-byte loads), see ra_bin_row_pair
+#define RA_PAIR 0   // 1: 2-byte features take two steps per wave instruction (16-byte loads, ra_bin_row_pair). Rounds 2-5 ran it: with the
+                    // dead prefetches of the old loops the kernel sat at the vector-memory instruction rate and halving the instructions paid.
+                    // With exact-length streams (ra_stream, round 6) the instruction count is 2.3x lower and the binding resource is
+                    // the L1-miss traffic (5.4 GB per pass from L2 at 0.6-0.7 of the L2 -> L1 ceiling) under memory latency: the
+                    // one-step form's 28 accumulator registers (against 56) let FIVE waves per SIMD in instead of three, which is worth
+                    // more than the wider loads (same box: 1.20 ms round 5, 1.15 pair / 3 waves, 1.11 one-step / 4 waves, 1.08 / 5 waves)
+#endif
+#ifndef RA_PD1
+#define RA_PD1 6  // pipeline depth of the pair path by pixels per step (NY = 1..4)
+#define RA_PD2 4
+#define RA_PD3 2
+#define RA_PD4 2
+#endif
+#ifndef RA_SD1
+#define RA_SD1 8  // pipeline depth of the one-step-per-instruction path by pixels per step (NY = 1, 2, 3, 4-5, 6): with the
+#define RA_SD2 4  // (2 D - 1) NY loads of 8 bytes per lane a stream holds, 94 registers = five waves per SIMD
+#define RA_SD3 3
+#define RA_SD4 2
+#define RA_SD6 2
 #endif
 #define RA_MAXD 16  // zero rows after the last step of S.wfull: the forward stream runs up to this many steps past the footprint
 
@@ -234,6 +252,39 @@ template <> struct Buf4<bf16_t> {
     }
 };
 
+// A software-pipelined stream of n steps with D groups of loads in flight and NO load past the last step (round 6).
+// Until then the loops below prefetched D groups ahead with the step index clamped to the last one and ran in whole D-groups, so every
+// stream issued D + (rounding) groups of dead loads (L1 hits with zero weights). On the bench's proposals (scripts/sim_roi_loads.py:
+// seven streams per RoI of 6-7 wave steps in the median against D = 2..6) those were 56 % of all load instructions -- 445 per RoI
+// against 194 -- in a kernel that is bound by the CU's vector-memory instruction rate, and a load that is out of the buffer's range
+// costs 3/4 of one that hits L1 (scripts/exp_ta_oob.hip: 16 against 22 cycles per wave instruction), so the dead ones have to go, not
+// just miss. n = q D + r: the first q D steps run the classic rotation over the D register groups v (every load unconditional: the
+// compiler's counted waits stay exact); the last r < D steps get register groups of their own (u), loaded -- behind wave-uniform
+// branches -- in front of the drain of v and consumed after it. (A conditional reload of v inside the drain would make every later
+// wait of the drain assume it was not issued, i.e. wait for it: one full memory latency per step.) Steps are consumed in ascending
+// order, as before: same summation order, same values.
+template <int D, class G, class LoadF, class ConsF>
+__device__ __forceinline__ void ra_stream(int n, LoadF load, ConsF cons) {
+    G v[D], u[D > 1 ? D - 1 : 1];
+    const int q = n / D, r = n - q * D;  // (wave-uniform)
+    if (q >= 1) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) load(v[d], d);
+        for (int i = 0; i + 1 < q; ++i) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) { cons(v[d], i * D + d); load(v[d], (i + 1) * D + d); }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) if (d < r) load(u[d], q * D + d);
+    if (q >= 1) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) cons(v[d], (q - 1) * D + d);
+    }
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) if (d < r) cons(u[d], q * D + d);
+}
+
 template <class TO>
 __device__ __forceinline__ void ra_store_bins(const ra_f2 (&acc)[7][2], float inv_count, TO* __restrict__ outrow, size_t ostride, bool cok, int P) {
     if (!cok) return;
@@ -249,40 +300,34 @@ __device__ __forceinline__ void ra_store_bins(const ra_f2 (&acc)[7][2], float in
 // pixels of the step inside the bin; NY is wave-uniform and a template parameter), their weighted sum with the bin's NY inner
 // weights (scalar registers), and 7 multiply-adds of that sum into the 7 bins of the outer axis with the step's row of S.wfull
 // (zeros outside a bin's footprint). No branch, no store and no vector address arithmetic inside the loop, so the loads of the
-// next D steps are in flight behind counted waits; steps past the footprint re-read its last column (an L1 hit) with zero
-// weights. The 7 bins are stored when the stream ends. Summation order per bin: steps ascending, as the reference's ix loop.
+// next D steps are in flight behind counted waits (ra_stream: nothing is loaded past the last step). The 7 bins are stored when
+// the stream ends. Summation order per bin: steps ascending, as the reference's ix loop.
 template <int NY, class TI, class TO>
 __device__ __forceinline__ void ra_bin_row(__amdgpu_buffer_rsrc_t rs, int voff, int base, int istride_b, int sstride_b, int ncol, const RaWaveLds& S,
                                            const float (&wy)[6], float inv_count, TO* __restrict__ outrow, size_t ostride, bool cok, int P) {
-    constexpr int D = NY <= 2 ? 8 : NY == 3 ? 6 : NY <= 5 ? 4 : 3;  // steps in flight (D * NY loads of 8 or 16 bytes per lane)
+    constexpr int D = NY == 1 ? RA_SD1 : NY == 2 ? RA_SD2 : NY == 3 ? RA_SD3 : NY <= 5 ? RA_SD4 : RA_SD6;  // steps in flight (D * NY loads of 8 or 16 bytes per lane)
     static_assert(D <= RA_MAXD, "S.wfull is padded with RA_MAXD zero rows");
     ra_f2 acc[7][2];
 #pragma unroll
     for (int b = 0; b < 7; ++b) { acc[b][0] = ra_f2{0.f, 0.f}; acc[b][1] = ra_f2{0.f, 0.f}; }
-    Buf4<TI> v[D][NY];
-    const int last = ncol - 1;
+    struct Grp { Buf4<TI> p[NY]; };
+    ra_stream<D, Grp>(
+        ncol,
+        [&](Grp& g, int x) {
+            const int so = base + x * sstride_b;
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const int so = base + min(d, last) * sstride_b;
-#pragma unroll
-        for (int j = 0; j < NY; ++j) v[d][j].load(rs, voff, so + j * istride_b);
-    }
-    for (int x0 = 0; x0 < ncol; x0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int x = x0 + d;
+            for (int j = 0; j < NY; ++j) g.p[j].load(rs, voff, so + j * istride_b);
+        },
+        [&](Grp& g, int x) {
             ra_f2 c0 = ra_f2{0.f, 0.f}, c1 = ra_f2{0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < NY; ++j) {
                 ra_f2 lo, hi;
-                v[d][j].get(lo, hi);
+                g.p[j].get(lo, hi);
                 const ra_f2 wj = ra_f2{wy[j], wy[j]};
                 c0 = __builtin_elementwise_fma(wj, lo, c0);
                 c1 = __builtin_elementwise_fma(wj, hi, c1);
             }
-            const int so = base + min(x + D, last) * sstride_b;
-#pragma unroll
-            for (int j = 0; j < NY; ++j) v[d][j].load(rs, voff, so + j * istride_b);
             const float4 wa = *reinterpret_cast<const float4*>(&S.wfull[x][0]), wb = *reinterpret_cast<const float4*>(&S.wfull[x][4]);
             const float wv[7] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z};
 #pragma unroll
@@ -291,8 +336,7 @@ __device__ __forceinline__ void ra_bin_row(__amdgpu_buffer_rsrc_t rs, int voff, 
                 acc[b][0] = __builtin_elementwise_fma(wq, c0, acc[b][0]);
                 acc[b][1] = __builtin_elementwise_fma(wq, c1, acc[b][1]);
             }
-        }
-    }
+        });
     ra_store_bins<TO>(acc, inv_count, outrow, ostride, cok, P);
 }
 
@@ -348,32 +392,28 @@ template <> struct Buf8<float> {  // (never instantiated for a load: the pair pa
 template <int NY, class TI, class TO>
 __device__ __forceinline__ void ra_bin_row_pair(__amdgpu_buffer_rsrc_t rs, int voff, int base, int istride_b, int sstride_b, int ncol, const RaWaveLds& S,
                                                 int half, const float (&wy)[6], float inv_count, TO* __restrict__ outrow, size_t ostride, bool cok, int P) {
-    constexpr int D = NY == 1 ? 6 : NY == 2 ? 4 : NY == 3 ? 3 : 2;  // wave steps in flight (D * NY loads of 16 bytes per lane: <= 36 registers)
+    // wave steps in flight (D * NY loads of 16 bytes per lane in the rotation + (D - 1) * NY for the last steps: <= 60 registers)
+    constexpr int D = NY == 1 ? RA_PD1 : NY == 2 ? RA_PD2 : NY == 3 ? RA_PD3 : RA_PD4;
     static_assert(2 * D + 1 <= RA_MAXD, "S.wfull is padded with RA_MAXD zero rows");
     ra_f2 acc[7][4];
 #pragma unroll
     for (int b = 0; b < 7; ++b)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[b][q] = ra_f2{0.f, 0.f};
-    Buf8<TI> v[D][NY];
-    const int nws = (ncol + 1) >> 1, lastw = nws - 1, step2_b = 2 * sstride_b;
+    struct Grp { Buf8<TI> p[NY]; };
+    const int nws = (ncol + 1) >> 1, step2_b = 2 * sstride_b;
+    ra_stream<D, Grp>(
+        nws,
+        [&](Grp& g, int ws) {
+            const int so = base + ws * step2_b;
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const int so = base + min(d, lastw) * step2_b;
-#pragma unroll
-        for (int j = 0; j < NY; ++j) v[d][j].load(rs, voff, so + j * istride_b);
-    }
-    for (int w0 = 0; w0 < nws; w0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int ws = w0 + d;
+            for (int j = 0; j < NY; ++j) g.p[j].load(rs, voff, so + j * istride_b);
+        },
+        [&](Grp& g, int ws) {
             float cs[8];
-            v[d][0].template fma_into<true>(wy[0], cs);
+            g.p[0].template fma_into<true>(wy[0], cs);
 #pragma unroll
-            for (int j = 1; j < NY; ++j) v[d][j].template fma_into<false>(wy[j], cs);
-            const int so = base + min(ws + D, lastw) * step2_b;
-#pragma unroll
-            for (int j = 0; j < NY; ++j) v[d][j].load(rs, voff, so + j * istride_b);
+            for (int j = 1; j < NY; ++j) g.p[j].template fma_into<false>(wy[j], cs);
             const float* wr = &S.wfull[2 * ws + half][0];
             const float4 wa = *reinterpret_cast<const float4*>(wr), wb = *reinterpret_cast<const float4*>(wr + 4);
             const float wv[7] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z};
@@ -383,8 +423,7 @@ __device__ __forceinline__ void ra_bin_row_pair(__amdgpu_buffer_rsrc_t rs, int v
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[b][q] = __builtin_elementwise_fma(wq, ra_f2{cs[2 * q], cs[2 * q + 1]}, acc[b][q]);
             }
-        }
-    }
+        });
 #pragma unroll
     for (int k2 = 0; k2 < 4; ++k2) {
         float tot[8];
@@ -443,10 +482,10 @@ __device__ __forceinline__ void ra_bin_row_tall(__amdgpu_buffer_rsrc_t rs, int v
 // reduced with the bin's weights (software pipelined, the next step's loads in flight) and the sum goes into a 3-bin
 // sliding window of register accumulators along the streamed axis.
 #ifndef RA_MINW
-#define RA_MINW 3  // waves per SIMD the register allocation must allow (155 registers; unconstrained the compiler takes 179 = 2 waves)
+#define RA_MINW (RA_PAIR ? 3 : 5)  // waves per SIMD the register allocation must allow (one-step path: 94 registers, no scratch; pair path: 168)
 #endif
 template <class TI, class TO>
-__global__ __launch_bounds__(RA_THREADS, RA_MINW) void roi_align_kernel(RoiAlignArgs a) {
+__global__ __launch_bounds__(RA_THREADS, (sizeof(TI) == 4 ? 3 : RA_MINW)) void roi_align_kernel(RoiAlignArgs a) {  // (fp32 features: 16-byte pixel images, 3 waves)
     __shared__ RaWaveLds s_all[RA_WPB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
