@@ -177,8 +177,8 @@ def test_fast_mode_detection_agreement_is_reported(world):
     # bf16 storage (8 significant bits) is a TRAINING storage type here (bench.py does not offer it for inference): reported only
     _, dets_bf = _run(world, torch.bfloat16)
     _report("fast mode, bf16 storage (training-only storage type)", dets_bf, ref)
-    # measured 0.91 on MI355X (rounds 2 and 3): a regression of the fp16 path's agreement below 0.85 fails
-    assert frac >= 0.85 and lfrac >= frac, (frac, lfrac)
+    # measured 0.8975-0.91 on MI355X in rounds 2-5: a regression of the fp16 path's agreement below 0.88 fails
+    assert frac >= 0.88 and lfrac >= frac, (frac, lfrac)
 
 
 def test_which_fp16_storage_point_costs_the_agreement(world):

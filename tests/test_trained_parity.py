@@ -6,6 +6,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+HARD_APK_TOL = 0.1  # north_star's tolerance, now on a split where AP@K has hundreds of decision points
 
 
 def test_fast_and_config5_modes_keep_ap_at_k_on_trained_weights(osr):
@@ -23,3 +24,13 @@ def test_fast_and_config5_modes_keep_ap_at_k_on_trained_weights(osr):
     # the strict per-detection agreement (IoU >= 0.99, |score difference| <= 1e-2) stays where it is on random weights: it counts
     # last-digit box differences that AP@K (IoU 0.5, 1-decimal coordinates) does not see
     assert out["agreement_fast_vs_fp32"] >= 0.80
+    # round 6: the same checkpoint on the crowded / occluded split (128 images, ~590 known + ~390 unknown objects, boxes overlapping up
+    # to IoU 0.35): the detector is far from perfect there, so AP@K, WI and A-OSE all have decision points a precision mode could flip
+    hard = out["hard"]
+    print("[trained parity, hard split]", {k: hard[k] for k in ("APk_fp32", "APk_fast", "APk_config5", "known_detections_fp32", "ground_truth", "delta_vs_fp32")})
+    assert hard["ground_truth"]["known"] >= 500 and hard["known_detections_fp32"] >= 500, hard
+    assert 5.0 <= hard["APk_fp32"] <= 99.0, hard  # neither nothing nor everything right
+    m = hard["metrics_fp32"]
+    assert float(m["AOSE"]) > 0 or float(m["WI"]) > 0, m  # unknown objects ARE taken for known ones there
+    assert abs(hard["APk_fast"] - hard["APk_fp32"]) <= HARD_APK_TOL, hard
+    assert abs(hard["APk_config5"] - hard["APk_fp32"]) <= HARD_APK_TOL, hard

@@ -41,24 +41,38 @@ def _draw(img: np.ndarray, box, cls: int) -> None:
     img[y0:y1, x0:x1] = patch
 
 
-def make_split(n_images: int, seed: int, with_unknown: bool) -> Tuple[torch.Tensor, List[List[Tuple[Tuple[int, int, int, int], int]]]]:
-    """-> images (n, 3, H, W) uint8 BGR, per image a list of ((x0, y0, x1, y1), class 0..23): 0-19 known, 20-23 unknown kinds."""
+def _iou(a, b) -> float:
+    iw, ih = min(a[2], b[2]) - max(a[0], b[0]), min(a[3], b[3]) - max(a[1], b[1])
+    if iw <= 0 or ih <= 0:
+        return 0.0
+    inter = iw * ih
+    return inter / ((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter)
+
+
+def make_split(n_images: int, seed: int, with_unknown: bool, hard: bool = False) -> Tuple[torch.Tensor, List[List[Tuple[Tuple[int, int, int, int], int]]]]:
+    """-> images (n, 3, H, W) uint8 BGR, per image a list of ((x0, y0, x1, y1), class 0..23): 0-19 known, 20-23 unknown kinds.
+    hard (round 6, a TEST split only): 5-10 smaller objects per image that may overlap (IoU up to 0.35; a later one is drawn over an
+    earlier one) and 40 % unknown kinds -- occluded, crowded, out of the training distribution: the detector makes mistakes of every
+    kind there (missed / duplicate / unknown-as-known), so AP@K, WI and AOSE have decision points for a precision mode to flip."""
     g = np.random.default_rng(seed)
     imgs = np.empty((n_images, H, W, 3), dtype=np.uint8)
     objs = []
     for i in range(n_images):
         img = g.integers(96, 160, (H, W, 3), dtype=np.uint8)
         cur = []
-        for _ in range(int(g.integers(1, 5))):
+        for _ in range(int(g.integers(5, 11)) if hard else int(g.integers(1, 5))):
             for _try in range(20):
-                w, h = int(g.integers(36, 150)), int(g.integers(36, 130))
+                w, h = (int(g.integers(28, 110)), int(g.integers(28, 100))) if hard else (int(g.integers(36, 150)), int(g.integers(36, 130)))
                 x0, y0 = int(g.integers(0, W - w)), int(g.integers(0, H - h))
                 b = (x0, y0, x0 + w, y0 + h)
-                if all(min(b[2], o[0][2]) - max(b[0], o[0][0]) <= 4 or min(b[3], o[0][3]) - max(b[1], o[0][1]) <= 4 for o in cur):
+                if hard:
+                    if all(_iou(b, o[0]) <= 0.35 for o in cur):
+                        break
+                elif all(min(b[2], o[0][2]) - max(b[0], o[0][0]) <= 4 or min(b[3], o[0][3]) - max(b[1], o[0][1]) <= 4 for o in cur):
                     break
             else:
                 continue
-            cls = int(g.integers(20, 24)) if (with_unknown and g.random() < 0.3) else int(g.integers(0, 20))
+            cls = int(g.integers(20, 24)) if (with_unknown and g.random() < (0.4 if hard else 0.3)) else int(g.integers(0, 20))
             _draw(img, b, cls)
             cur.append((b, cls))
         imgs[i] = img
@@ -113,13 +127,13 @@ def train(device: str = "cuda:0", iters: int = 400, batch: int = 8, n_train: int
     return out, curve
 
 
-def evaluate(params: Dict[str, torch.Tensor], device: str = "cuda:0", n_test: int = 64, batch: int = 8, seed: int = 0, cfg=None) -> Dict[str, object]:
+def evaluate(params: Dict[str, torch.Tensor], device: str = "cuda:0", n_test: int = 64, batch: int = 8, seed: int = 0, cfg=None, hard: bool = False) -> Dict[str, object]:
     """AP@K / WI / AOSE / AP@U of the three engine modes on the test split + detection agreement of the fp16 modes with fp32."""
     from openset_rcnn_amd.host.agreement import detection_agreement
     from openset_rcnn_amd.host.datasets import VOC_COCO_CATEGORIES
     from openset_rcnn_amd.host.engine import OpensetRCNNEngine
     from openset_rcnn_amd.host.evaluation import PascalVOCDetectionEvaluator
-    images, objs = make_split(n_test, 5000 + seed, with_unknown=True)
+    images, objs = make_split(n_test, (9000 if hard else 5000) + seed, with_unknown=True, hard=hard)
     names = list(VOC_COCO_CATEGORIES)
     ids = [f"t{i:04d}" for i in range(n_test)]
     # VOC's 1-based inclusive pixel boxes (the evaluator adds 1 to the detections' xmin / ymin: pascal_voc_evaluation.py:66-70)
@@ -149,6 +163,13 @@ def evaluate(params: Dict[str, torch.Tensor], device: str = "cuda:0", n_test: in
         out[f"matched_{m}"] = [a["matched"], a["reference_detections"]]
     out["detections_fp32"] = int(sum(len(d[1]) for d in dets["fp32"]))
     out["known_detections_fp32"] = int(sum(int((d[2] < 20).sum()) for d in dets["fp32"]))
+    out["ground_truth"] = dict(images=n_test, known=int(sum(1 for o in objs for _, c in o if c < 20)), unknown=int(sum(1 for o in objs for _, c in o if c >= 20)))
+
+    def _num(v):  # (the evaluator reports WI / AOSE / AP@U as numbers or as {recall level: value})
+        return v if isinstance(v, (int, float)) else None
+    # what a precision mode changes in every scalar the evaluator reports (pascal_voc_evaluation.py:182-202), next to AP@K
+    out["delta_vs_fp32"] = {m: {k: round(float(res[m][k]) - float(res["fp32"][k]), 4) for k in res["fp32"] if _num(res["fp32"][k]) is not None and _num(res[m].get(k)) is not None}
+                            for m in ("fast", "config5")}
     return out
 
 
@@ -158,6 +179,8 @@ TOY_CFG = dict(pln_loss_weight=4.0)
 def run(device: str = "cuda:0", iters: int = 1000, seed: int = 0, log=None) -> Dict[str, object]:
     params, curve = train(device, iters=iters, seed=seed, log=log, cfg=TOY_CFG)
     out = evaluate(params, device, seed=seed, cfg=TOY_CFG)
+    # the same checkpoint on the crowded / occluded split (128 images, ~950 objects): enough decision points for "|delta| <= 0.1" to mean something
+    out["hard"] = evaluate(params, device, n_test=128, seed=seed, cfg=TOY_CFG, hard=True)
     out["train"] = dict(iterations=iters, batch=8, images=128, image_size=[H, W], lr=0.001, pln_loss_weight=TOY_CFG["pln_loss_weight"],
                         loss_first=round(curve[0], 4), loss_last=round(curve[-1], 4),
                         data="synthetic VOC-layout set: 20 known (colour, stripe) classes, 4 unknown kinds in the test images only; random_params init, stem + res2 frozen")
