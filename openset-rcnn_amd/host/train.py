@@ -691,6 +691,19 @@ class OpensetRCNNTrainer:
         gs = 1.0 / (getattr(self, "_scale_used", self.loss_scale) * world)
         self._ok.fill_(1)
         ops.check_finite_(self.grad_flat, self._ok)
+        self._apply_sgd(self.lr, self.momentum, self.weight_decay, gs)
+        self.scaler.record(self._ok, getattr(self, "_proposal_status", None))
+        self._proposal_status = None
+
+    def null_update(self) -> None:
+        """The update's launches with nothing to apply (bench.py's no-collective timing): the caller has zeroed the gradient; learning
+        rate 0, weight decay 0 and momentum factor 1 make p' = p - 0 * (1 * v + 0) and v' = 1 * v + 0 -- parameters, momentum buffers,
+        low-precision copies and backward-data weights come out bit for bit as they went in, no verdict is queued in the loss scaler."""
+        self._ok.fill_(1)
+        ops.check_finite_(self.grad_flat, self._ok)
+        self._apply_sgd(0.0, 1.0, 0.0, 1.0)
+
+    def _apply_sgd(self, lr: float, momentum: float, weight_decay: float, gs: float) -> None:
         if self.multi_tensor_update:
             # every parameter tensor in ONE launch (osr_sgd_step_multi over a device-resident table), then every backward-data weight in
             # one more (_refresh_derived): ~145 launches of a few microseconds of work each became two; same bits per element
@@ -698,15 +711,13 @@ class OpensetRCNNTrainer:
             if self._sgd_plan is None or self._sgd_plan[0] != sig:
                 self._sgd_plan = (sig, ops.sgd_multi_plan([(pm, self.grad[k], self.mom[k], self.row_scale.get(k), self.lowp.get(k))
                                                            for k, pm in self.master.items()], self.device))
-            ops.sgd_step_multi_(self._sgd_plan[1], self.lr, self.momentum, self.weight_decay, gs, self._ok)
+            ops.sgd_step_multi_(self._sgd_plan[1], lr, momentum, weight_decay, gs, self._ok)
         else:
             # ~75 in-place launches of a few microseconds each (one per parameter tensor), then ~70 repacking launches: dealt over the
             # three streams of the trainer they run three abreast instead of one behind the other
-            self._fan([lambda k=k, pm=pm: ops.sgd_step_(pm, self.grad[k], self.mom[k], self.lr, self.momentum, self.weight_decay, gs, self.row_scale.get(k),
+            self._fan([lambda k=k, pm=pm: ops.sgd_step_(pm, self.grad[k], self.mom[k], lr, momentum, weight_decay, gs, self.row_scale.get(k),
                                                        self.lowp.get(k), self._ok) for k, pm in self.master.items()])
         self._refresh_derived()
-        self.scaler.record(self._ok, getattr(self, "_proposal_status", None))
-        self._proposal_status = None
 
     # several ranks: step k applies the verdicts of the updates up to k - 1 - MULTI_RANK_LAG, waited for -- the same set on every rank
     # (they are functions of the all-reduced gradient), so the scales cannot drift apart, and the host still runs two iterations ahead

@@ -313,6 +313,34 @@ def test_sparse_row_list_overflow_poisons_the_gradient_and_skips_the_update(setu
     assert sum(int(not torch.equal(before[k], tr.master[k])) for k in before) == len(before)
 
 
+def test_null_update_changes_nothing(setup):
+    """bench.py's no-collective timing (config 4's `all_reduce_hidden_fraction`) runs the update's launches with nothing to apply
+    (it used to apply the LOCAL gradient on every rank): masters, momentum, low-precision copies and backward-data weights
+    are bit for bit unchanged after a real step's momentum is in place, and no verdict reaches the loss scaler."""
+    from openset_rcnn_amd.host.train import OpensetRCNNTrainer
+    d = setup["dev"]
+    args = (d["images"], d["hw"], setup["h"], setup["w"], d["gt"], d["gcls"], d["gcnt"], d["keys"])
+    tr = OpensetRCNNTrainer(setup["params"], dtype=torch.float16, device=DEV, lr=0.01, loss_scale=512.0)
+    tr.step(*args)  # non-zero momentum
+    tr.poll_overflow(wait=True)
+    torch.cuda.synchronize()
+    snap = dict(master={k: v.clone() for k, v in tr.master.items()}, mom={k: v.clone() for k, v in tr.mom.items()},
+                lowp={k: v.clone() for k, v in tr.lowp.items() if v is not None}, wd={k: v.clone() for k, v in tr.wd.items()})
+    assert any(float(v.abs().max()) > 0 for v in snap["mom"].values())
+    pending = len(tr.scaler.pending) if hasattr(tr.scaler, "pending") else None
+    tr.step(*args, update=False)
+    tr.buckets.reset()
+    tr.grad_flat.zero_()
+    tr.null_update()
+    torch.cuda.synchronize()
+    for group, cur in (("master", tr.master), ("mom", tr.mom), ("lowp", tr.lowp), ("wd", tr.wd)):
+        for k, a in snap[group].items():
+            assert torch.equal(a, cur[k]), (group, k)
+    if pending is not None:
+        assert len(tr.scaler.pending) == pending
+    assert not tr.poll_overflow(wait=True)
+
+
 def test_chained_res3_forward_gives_the_same_step(setup):
     """The trainer's res3 blocks run conv2 -> conv3 + shortcut as one launch that also stores conv2's output
     (osr_conv2d_chain_fwd_ex); against the two launches: identical losses and gradients, bit for bit (the chain kernel is bit-identical
