@@ -665,7 +665,12 @@ def parity_leg(tdt, dev, images, image_hw, flops_per_step: float, steps: int = 1
         out["trained"] = dict(APk_fp32=t["APk_fp32"], APk_fast=t["APk_fast"], APk_config5=t["APk_config5"],
                               agreement_fast_vs_fp32=t["agreement_fast_vs_fp32"], agreement_config5_vs_fp32=t["agreement_config5_vs_fp32"],
                               detections_fp32=t["detections_fp32"], known_detections_fp32=t["known_detections_fp32"],
-                              metrics_fp32=t["metrics_fp32"], metrics_fast=t["metrics_fast"], train=t["train"],
+                              metrics_fp32=t["metrics_fp32"], metrics_fast=t["metrics_fast"], train=t["train"], delta_vs_fp32=t.get("delta_vs_fp32"),
+                              hard_split={k: t["hard"][k] for k in ("APk_fp32", "APk_fast", "APk_config5", "agreement_fast_vs_fp32", "agreement_config5_vs_fp32",
+                                                                    "known_detections_fp32", "ground_truth", "metrics_fp32", "delta_vs_fp32")}
+                              if isinstance(t.get("hard"), dict) else None,
+                              hard_split_note="the same checkpoint on 128 crowded / occluded test images (5-10 objects, IoU up to 0.35 between them, 40 % unknown kinds of "
+                                              "which half share a known class's colour): AP@K, WI and A-OSE with hundreds of decision points (tests/trained_parity.py)",
                               note="AP@K of host/evaluation.py (restatement of openset_rcnn/evaluation/pascal_voc_evaluation.py) on 64 synthetic test images with "
                                    "known and unknown objects; the released checkpoint / VOC-COCO images needed for README.md:98's 59.12 are not reachable offline")
     except Exception as e:  # noqa: BLE001
