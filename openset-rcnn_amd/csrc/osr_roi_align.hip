@@ -1239,7 +1239,10 @@ struct RoiBwdDenseArgs {
 };
 
 template <class TG, class TO>
-__global__ __launch_bounds__(256) void roi_align_bwd_dense_kernel(RoiBwdDenseArgs a) {
+#ifndef RD_MINW
+#define RD_MINW 4    // waves per SIMD the register allocation must allow (128 registers, no scratch)
+#endif
+__global__ __launch_bounds__(256, RD_MINW) void roi_align_bwd_dense_kernel(RoiBwdDenseArgs a) {
     __shared__ float s_w[2][2][RD_T][8];  // [buffer][axis: 0 = y, 1 = x][pixel row / column of the tile][bin] (axis 0 already / count)
     __shared__ unsigned short s_hits[1024];
     __shared__ unsigned char s_flag[1024];
@@ -1320,31 +1323,59 @@ __global__ __launch_bounds__(256) void roi_align_bwd_dense_kernel(RoiBwdDenseArg
             s_w[buf][axis][pix][bin] = wsum;
         }
         __syncthreads();  // (the buffer written two hits ago was read before the previous hit's barrier)
-        const TG* g = reinterpret_cast<const TG*>(a.dout) + (size_t)r * P * P * C + ch;
-        for (int by = 0; by < P; ++by) {
-            float wy[RD_T];
-            bool any = false;
+        // Which bins have weight inside this tile (the same in every lane: scalar). Lanes 0..55 look at entry (pixel lane / 7, bin lane % 7) of
+        // each axis; bit p * 7 + b of the ballot = "pixel p has weight in bin b".
+        unsigned long long my = 0ull, mx = 0ull;
+        {
+            const int pp = lane / 7, bb = lane - pp * 7;
+            const bool in = lane < RD_T * 7;
+            my = __ballot(in && s_w[buf][0][pp][bb] != 0.f);
+            mx = __ballot(in && s_w[buf][1][pp][bb] != 0.f);
+        }
+        unsigned acty = 0u, actx = 0u;
 #pragma unroll
-            for (int y = 0; y < RD_T; ++y) { wy[y] = s_w[buf][0][y][by]; any |= wy[y] != 0.f; }
-            if (!__builtin_amdgcn_readfirstlane((int)any)) continue;  // (the weights are the same in every lane)
+        for (int bb = 0; bb < 7; ++bb) {
+            const unsigned long long col = 0x0002040810204081ull << bb;  // bits bb, 7 + bb, .., 49 + bb: the 8 pixels of bin bb
+            acty |= (my & col) ? (1u << bb) : 0u;
+            actx |= (mx & col) ? (1u << bb) : 0u;
+        }
+        if (acty == 0u || actx == 0u) continue;  // (wave-uniform; the hit test is conservative: no weight in this tile after all)
+        // Round 6: the bins with weight form a contiguous range of rows rb0..rb1 (and columns). The old loop loaded one value of g and used
+        // it at once -- one exposed L2 latency per (by, bx) pair, up to 49 per hit, and a tile under a ground-truth box is hit by a
+        // hundred sampled RoIs. Now a row of g (all 7 bx, unconditionally: a bin without weight multiplies a zero) is in flight while
+        // the previous row is multiplied in; the loads are unconditional so that the compiler's counted waits leave the next row in flight.
+        const int rb0 = __builtin_ctz(acty), rb1 = 31 - __builtin_clz(acty);
+        const TG* g = reinterpret_cast<const TG*>(a.dout) + (size_t)r * P * P * C + (chok ? ch : 0);
+        float cur[7], nxt[7];
+#define RD_LOAD_ROW(dst, byy)                                                                                       \
+        _Pragma("unroll") for (int bx = 0; bx < 7; ++bx) dst[bx] = osr_to_float(g[(size_t)((byy) * P + min(bx, P - 1)) * C]);
+        RD_LOAD_ROW(cur, rb0)
+        for (int by = rb0; by <= rb1; ++by) {
+            const int byn = min(by + 1, rb1);
+            // (compiler fence: the next row's loads go out HERE, ahead of this row's arithmetic, and the x weights are re-read from LDS per row
+            // instead of being hoisted into 56 registers across the row loop -- hoisted: 166 registers, three waves per SIMD and 1.33 ms;
+            // with the fence 128 registers, four waves and 0.73 ms; the loop before round 6: 1.16 ms. scripts/ab_roibwd6.sh, same box)
+            asm volatile("" ::: "memory");
+            RD_LOAD_ROW(nxt, byn)
             float trow[RD_T];
 #pragma unroll
-            for (int x = 0; x < RD_T; ++x) trow[x] = 0.f;
-            for (int bx = 0; bx < P; ++bx) {
-                float wx[RD_T];
-                bool anyx = false;
-#pragma unroll
-                for (int x = 0; x < RD_T; ++x) { wx[x] = s_w[buf][1][x][bx]; anyx |= wx[x] != 0.f; }
-                if (!__builtin_amdgcn_readfirstlane((int)anyx)) continue;
-                const float gv = chok ? osr_to_float(g[(size_t)(by * P + bx) * C]) : 0.f;
-#pragma unroll
-                for (int x = 0; x < RD_T; ++x) trow[x] = __builtin_fmaf(wx[x], gv, trow[x]);
+            for (int x = 0; x < RD_T; ++x) {
+                const float4 w0 = *reinterpret_cast<const float4*>(&s_w[buf][1][x][0]), w1 = *reinterpret_cast<const float4*>(&s_w[buf][1][x][4]);
+                float t = w0.x * cur[0];
+                t = __builtin_fmaf(w0.y, cur[1], t); t = __builtin_fmaf(w0.z, cur[2], t); t = __builtin_fmaf(w0.w, cur[3], t);
+                t = __builtin_fmaf(w1.x, cur[4], t); t = __builtin_fmaf(w1.y, cur[5], t); t = __builtin_fmaf(w1.z, cur[6], t);
+                trow[x] = t;
             }
 #pragma unroll
-            for (int y = 0; y < RD_T; ++y)
+            for (int y = 0; y < RD_T; ++y) {
+                const float wyv = s_w[buf][0][y][by];
 #pragma unroll
-                for (int x = 0; x < RD_T; ++x) acc[y * RD_T + x] = __builtin_fmaf(wy[y], trow[x], acc[y * RD_T + x]);
+                for (int x = 0; x < RD_T; ++x) acc[y * RD_T + x] = __builtin_fmaf(wyv, trow[x], acc[y * RD_T + x]);
+            }
+#pragma unroll
+            for (int bx = 0; bx < 7; ++bx) cur[bx] = nxt[bx];
         }
+#undef RD_LOAD_ROW
     }
     // ---- 3. the tile, once ----
     if (chok) {

@@ -20,6 +20,17 @@ ctr = torch.rand(n * S, 2, generator=g) * torch.tensor([1333.0, 800.0])
 size = torch.exp(torch.rand(n * S, 2, generator=g) * 3.2 + 2.8)  # 16 .. 400 px
 boxes = torch.cat((ctr - size / 2, ctr + size / 2), dim=1).clamp_(min=0)
 boxes[:, 2].clamp_(max=1333); boxes[:, 3].clamp_(max=800)
+if len(sys.argv) > 1 and sys.argv[1] == "clustered":
+    # what a training step's sampler produces: a quarter of each image's 512 RoIs are positives, jittered copies of its 8 ground-truth boxes
+    # (IoU >= 0.5), so the tiles under a ground-truth box are reached by dozens of RoIs each
+    for i in range(n):
+        gtc = torch.rand(8, 2, generator=g) * torch.tensor([1100.0, 650.0]) + 100
+        gts = torch.exp(torch.rand(8, 2, generator=g) * 2.0 + 3.6)  # 36 .. 270 px
+        which = torch.randint(0, 8, (128,), generator=g)
+        pc = gtc[which] + (torch.rand(128, 2, generator=g) - 0.5) * 0.25 * gts[which]
+        s2 = gts[which] * (0.8 + 0.4 * torch.rand(128, 2, generator=g))
+        boxes[i * S:i * S + 128] = torch.cat((pc - s2 / 2, pc + s2 / 2), dim=1).clamp_(min=0)
+    boxes[:, 2].clamp_(max=1333); boxes[:, 3].clamp_(max=800)
 bidx = torch.arange(n, dtype=torch.int32).repeat_interleave(S)
 dout = torch.randn(n * S, 7, 7, c, generator=g).half().to(dev)
 boxes, bidx = boxes.to(dev), bidx.to(dev)
