@@ -732,7 +732,8 @@ def main(argv=None) -> int:
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--dense-rpn-bwd", action="store_true", help="train step: the CF-RPN head's backward over every anchor row (rounds 1-3), for A/B")
-    ap.add_argument("--train-only", action="store_true", help="(internal) run only the train-step leg and print its object")
+    ap.add_argument("--train-only", action="store_true", help="(internal) run only the train-step leg (and config 4's) and print its object")
+    ap.add_argument("--no-config4", action="store_true", help="with --train-only: skip the config-4 leg (profiles of the config-3 train step alone)")
     ap.add_argument("--streams", type=int, default=1, help="micro-batch streams inside one pass (1 = the pass is one stream of launches)")
     ap.add_argument("--passes-in-flight", type=int, default=4,
                     help="hipGraph mode: consecutive passes (steps) alternate over this many lanes, each with its own images, buffers and stream; "
@@ -805,10 +806,11 @@ def main(argv=None) -> int:
         # parent it inherited that process's hardware-queue rotation, the very thing this child exists to avoid for the train step)
         del images
         torch.cuda.empty_cache()
-        try:
-            obj["config4"] = config4_leg(tdt, dev, max(args.train_steps, 8), 4)
-        except Exception as e:  # noqa: BLE001
-            obj["config4"] = {"error": repr(e)[:400]}
+        if not args.no_config4:
+            try:
+                obj["config4"] = config4_leg(tdt, dev, max(args.train_steps, 8), 4)
+            except Exception as e:  # noqa: BLE001
+                obj["config4"] = {"error": repr(e)[:400]}
         print(json.dumps(obj), flush=True)
         return 0
     eng = OpensetRCNNEngine(params, dtype=tdt, device=dev)

@@ -36,8 +36,8 @@
                     // dead prefetches of the old loops the kernel sat at the vector-memory instruction rate and halving the instructions paid.
                     // With exact-length streams (ra_stream, round 6) the instruction count is 2.3x lower and the binding resource is
                     // the L1-miss traffic (5.4 GB per pass from L2 at 0.6-0.7 of the L2 -> L1 ceiling) under memory latency: the
-                    // one-step form's 28 accumulator registers (against 56) let FIVE waves per SIMD in instead of three, which is worth
-                    // more than the wider loads (same box: 1.20 ms round 5, 1.15 pair / 3 waves, 1.11 one-step / 4 waves, 1.08 / 5 waves)
+                    // one-step form's 28 accumulator registers (against 56) let four or five waves per SIMD in instead of three, which is worth
+                    // more than the wider loads (same box: 1.20 ms round 5, 1.15 pair / 3 waves, 1.11 one-step / 4 waves, 1.08 / 5 waves; RA_MINW below)
 #endif
 #ifndef RA_PD1
 #define RA_PD1 6  // pipeline depth of the pair path by pixels per step (NY = 1..4)
@@ -47,7 +47,7 @@
 #endif
 #ifndef RA_SD1
 #define RA_SD1 8  // pipeline depth of the one-step-per-instruction path by pixels per step (NY = 1, 2, 3, 4-5, 6): with the
-#define RA_SD2 4  // (2 D - 1) NY loads of 8 bytes per lane a stream holds, 94 registers = five waves per SIMD
+#define RA_SD2 4  // (2 D - 1) NY loads of 8 bytes per lane a stream holds: 94 registers
 #define RA_SD3 3
 #define RA_SD4 2
 #define RA_SD6 2
@@ -482,7 +482,11 @@ __device__ __forceinline__ void ra_bin_row_tall(__amdgpu_buffer_rsrc_t rs, int v
 // reduced with the bin's weights (software pipelined, the next step's loads in flight) and the sum goes into a 3-bin
 // sliding window of register accumulators along the streamed axis.
 #ifndef RA_MINW
-#define RA_MINW (RA_PAIR ? 3 : 5)  // waves per SIMD the register allocation must allow (one-step path: 94 registers, no scratch; pair path: 168)
+#define RA_MINW (RA_PAIR ? 3 : 4)  // waves per SIMD the register allocation must allow (pair path: 168 registers). One-step path: four, not the
+                                   // five its 94 registers would allow -- end to end (bench.py, four passes in flight, same box, two rounds:
+                                   // scripts/ab_bench6.sh) 1600-1606 img/s with four against 1602-1605 with five, 1585-1595 with the pair
+                                   // path and 1583-1588 with round 5's kernel; the kernel alone 1.094-1.10 / 1.11-1.12 / 1.14-1.19 / 1.21-1.25 ms;
+                                   // five waves keep 5 120 RoIs in flight against 32 MiB of L2: hit rate 0.64 instead of 0.73, +0.6 GB from HBM
 #endif
 template <class TI, class TO>
 __global__ __launch_bounds__(RA_THREADS, (sizeof(TI) == 4 ? 3 : RA_MINW)) void roi_align_kernel(RoiAlignArgs a) {  // (fp32 features: 16-byte pixel images, 3 waves)
