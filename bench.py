@@ -768,11 +768,17 @@ def main(argv=None) -> int:
         sys.stdout.flush()
         out_stream = os.fdopen(os.dup(1), "w")
         os.dup2(2, 1)
+        import datetime
         import torch.distributed as dist
+        # Collective timeout 600 s, stated rather than inherited: the longest stretch in which ranks 1..N-1 sit in a collective while
+        # rank 0 works alone is the host-only CPU baseline at the very end (~20-30 s, behind the last collective: they wait in
+        # destroy_process_group, not in a collective), and the train-step / config-4 legs carry their own 300-s watchdogs (below), which
+        # fire first. DESIGN.md section 6 has the arithmetic of the N = 8 run against the driver's limit.
+        pg_timeout = datetime.timedelta(seconds=600)
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)  # RCCL over xGMI
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=pg_timeout)
 
     pkg = ge.load_package()
     pkg._lib.load()
