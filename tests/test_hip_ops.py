@@ -292,6 +292,32 @@ def test_roi_align_vs_oracle(ops, dt, odt):
         assert_close(out, ref, rtol=2.0 ** -10, atol=2e-3, name="roi_align f16 out")
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+def test_roi_align_every_stream_length_and_inner_depth(ops, dt):
+    """Round 6 (ra_stream: q * D steps in a rotation of D register groups + r < D steps in groups of their own, D = 2..8 by the
+    pixels per step): RoIs whose footprint is 1..40 pixels along the streamed axis and 1..6 pixels per bin along the other, in both
+    orientations, so that every (q, r) split of every pipeline depth and the no-rotation case (n < D) run -- against the C oracle."""
+    gg = g(29)
+    h, w, c = 56, 72, 16
+    f = torch.randn(1, c, h, w, generator=gg).to(dt).float()
+    boxes = []
+    for n_out in range(1, 41):            # footprint length along the streamed (shorter or equal) side, in level pixels
+        for per_bin in (0.4, 1.0, 2.3, 3.1, 4.2, 5.5):  # bin size along the other side: 1..6 pixels per bin
+            long_side = min(7 * per_bin, 52.0)
+            short_side = max(n_out - 1.3, 0.2)
+            x0, y0 = 3.3 + (n_out % 5) * 0.37, 2.6 + (n_out % 3) * 0.41
+            boxes.append([x0, y0, x0 + long_side, y0 + short_side])    # streamed along y
+            boxes.append([y0, x0, y0 + short_side, x0 + long_side])    # streamed along x
+    boxes = torch.tensor(boxes, dtype=torch.float32) * 4.0  # one level at stride 4 (min_level = 2): image coordinates
+    boxes[:, 2].clamp_(max=w * 4.0 - 1)
+    boxes[:, 3].clamp_(max=h * 4.0 - 1)
+    bidx = torch.zeros(len(boxes), dtype=torch.int32)
+    lib_out = ops.roi_align([nhwc(f).to(dt).to(DEV)], (0.25,), boxes.to(DEV), bidx.to(DEV), 7, torch.float32, min_level=2)
+    out = lib_out.cpu().float().permute(0, 3, 1, 2)
+    ref = CO.roi_align(f, torch.cat((bidx.float().unsqueeze(1), boxes), dim=1), 0.25)
+    assert_close(out, ref, rtol=1e-4, atol=1e-5, name="roi_align stream sweep")
+
+
 def test_roi_align_wide_bins_take_the_sample_loop(ops):
     # one coarse level only: a 600 px RoI at stride 4 has 21 px bins (> the 13 px LDS table) -> 4-tap fallback
     gg = g(22)
