@@ -97,10 +97,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(WgradArgs a
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid / WN, wc = wid % WN;
 
-    // tile decode: consecutive workgroups share the M chunk (same dy / x rows in L2), then the dy columns
+    // tile decode: consecutive work items share the M chunk (same dy / x rows), then the dy columns. Round 6: workgroups b and b + 8 share an
+    // XCD (its L2), so CONSECUTIVE workgroup ids land on eight different L2s -- the nine taps of a 3 x 3 layer (or the ci / co tiles of a
+    // 1 x 1 layer) that read the same rows each fetched them into an L2 of their own, and the rows came from the Infinity Cache / HBM up
+    // to nine times. The same bijective remap as the forward kernel's: every XCD walks one contiguous run of the linear work index, so the
+    // tiles of a row chunk run on ONE XCD, back to back (WG_XCD_REMAP 0: the old order, for A/B; partial sums land in the same slots either way)
+#ifndef WG_XCD_REMAP
+#define WG_XCD_REMAP 1
+#endif
     const int ntiles = a.tiles_co * a.tiles_ci * a.taps;
-    const int split = blockIdx.x / ntiles;
-    int t = blockIdx.x - split * ntiles;
+    int bid = (int)blockIdx.x;
+    if (WG_XCD_REMAP) {
+        const int nwg = (int)gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int split = bid / ntiles;
+    int t = bid - split * ntiles;
     const int tile_ci = t % a.tiles_ci; t /= a.tiles_ci;
     const int tap = t % a.taps;
     const int tile_co = t / a.taps;

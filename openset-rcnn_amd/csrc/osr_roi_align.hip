@@ -1253,10 +1253,14 @@ __global__ __launch_bounds__(256, RD_MINW) void roi_align_bwd_dense_kernel(RoiBw
     __shared__ int s_nhit;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (Plain workgroup order on purpose. An XCD-aware order -- every XCD walking one contiguous run of the tile list, as the conv and
+    // weight-gradient kernels do -- measured 0.73 -> 0.87 ms on uniform boxes and 0.80 -> 1.02 ms on the sampler's clustered positives:
+    // the tiles under a ground-truth box carry most of the work, and a contiguous run puts them all on one XCD; round-robin spreads them.)
+    const int bid = (int)blockIdx.x;
     int lv = 0;
-    while (lv + 1 < a.num_levels && (int)blockIdx.x >= a.tile_off[lv + 1]) ++lv;
+    while (lv + 1 < a.num_levels && bid >= a.tile_off[lv + 1]) ++lv;
     const int tpi = a.tiles_x[lv] * a.tiles_y[lv];
-    const int rel = (int)blockIdx.x - a.tile_off[lv];
+    const int rel = bid - a.tile_off[lv];
     const int b = rel / tpi, tt = rel - b * tpi;
     const int ty0 = (tt / a.tiles_x[lv]) * RD_T, tx0 = (tt % a.tiles_x[lv]) * RD_T;
     const int H = a.h[lv], W = a.w[lv], P = a.pooled, C = a.c;
