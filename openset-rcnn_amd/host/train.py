@@ -261,7 +261,17 @@ class OpensetRCNNTrainer:
             sig = tuple(t.data_ptr() for pr in pairs for t in pr)
             if self._pack_plan is None or self._pack_plan[0] != sig:
                 self._pack_plan = (sig, ops.pack_dgrad_multi_plan(pairs, self.device))
-            ops.pack_dgrad_weight_multi_(self._pack_plan[1])
+            # The backward-data weights are read by the NEXT BACKWARD only (the next forward reads the low-precision copies the update
+            # kernel has just written): with the second stream in use the repack (0.15 ms, one launch) leaves the end of the iteration
+            # -- it runs on that stream, idle until the next backward, behind the update, and the next backward waits for its event
+            if self.side_wgrad and self._wside is not None and self.device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+                self._wside.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(self._wside):
+                    ops.pack_dgrad_weight_multi_(self._pack_plan[1])
+                    self._pack_done = self._wside.record_event()
+            else:
+                ops.pack_dgrad_weight_multi_(self._pack_plan[1])
+                self._pack_done = None
         else:
             jobs = [lambda n=n: ops.pack_dgrad_weight(e.w[n + ".w"], wd[n]) for n in self.conv_names]
             jobs.append(lambda: ops.pack_dgrad_weight(e.fc1_w, wd["fc1"].view(e.fc1_w.shape[1], e.fc1_w.shape[0])))
@@ -497,6 +507,9 @@ class OpensetRCNNTrainer:
         self._scale_used = self.loss_scale  # the update divides out the scale THIS backward multiplied in, whatever a poll does in between
         self._overlap = overlap and parallel.is_dist()
         self.buckets.reset()
+        if getattr(self, "_pack_done", None) is not None:  # the repack of the backward-data weights behind the previous update (_refresh_derived)
+            torch.cuda.current_stream(self.device).wait_event(self._pack_done)
+            self._pack_done = None
         dt = self.dtype
         p = s["p"]
         # --- CF-RPN: losses -> tail -> weight gradient of the 3x3 conv (weights shared by the five levels). This chain depends on
