@@ -52,7 +52,7 @@
 #define RA_SD4 2
 #define RA_SD6 2
 #endif
-#define RA_MAXD 16  // zero rows after the last step of S.wfull: the forward stream runs up to this many steps past the footprint
+#define RA_MAXD 16  // zero rows after the last step of S.wfull (the pair path's odd last step reads one row past; until round 6 the streams ran up to D steps past the footprint)
 
 struct RoiAlignArgs {
     const void* data[4];
